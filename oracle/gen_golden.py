@@ -1,0 +1,312 @@
+"""ORACLE tooling -- generates tests/golden/*.npz by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference); the GPU box never
+runs it.  Nothing from the reference is copied: only numbers (inputs/outputs)
+are written.  Three shims are applied from outside:
+
+1. ``torch.Tensor.cuda`` -> identity (hard-coded ``.cuda()`` at
+   models/IRR_PWC.py:68-71, models/pwc_modules.py:111,129).
+2. train mode only: ``rescale_flow`` replaced by an alias-preserving,
+   autograd-legal equivalent (in-place ``mul_`` on the argument, returns a
+   clone) -- the as-is function raises under modern autograd.
+3. robust-mask mode: ``WarpingLayer.forward`` twin with threshold 0.9999.
+
+Usage:  python oracle/gen_golden.py  [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as tf
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+REF = "/root/reference"
+sys.path.insert(0, REF)
+
+torch.Tensor.cuda = lambda self, *a, **k: self          # shim 1
+
+import models  # noqa: E402  (reference package)
+import losses  # noqa: E402
+import irr_pwc_oracle as O  # noqa: E402
+
+ref_irr = sys.modules["models.IRR_PWC"]
+ref_pwc = sys.modules["models.pwc_modules"]
+ref_irrm = sys.modules["models.irr_modules"]
+_orig_rescale = ref_irr.rescale_flow
+_orig_warp_forward = ref_pwc.WarpingLayer.forward
+
+
+def _rescale_alias(flow, div_flow, width_im, height_im, to_local=True):   # shim 2
+    if to_local:
+        u = float(flow.size(3) / width_im / div_flow)
+        v = float(flow.size(2) / height_im / div_flow)
+    else:
+        u = float(width_im * div_flow / flow.size(3))
+        v = float(height_im * div_flow / flow.size(2))
+    flow.mul_(torch.tensor([u, v]).view(1, 2, 1, 1))
+    return flow.clone()
+
+
+def _make_warp_forward(thr):                                               # shim 3
+    def fwd(self, x, flow, height_im, width_im, div_flow):
+        flo_w = flow[:, 0] * 2 / max(width_im - 1, 1) / div_flow
+        flo_h = flow[:, 1] * 2 / max(height_im - 1, 1) / div_flow
+        grid = torch.add(ref_pwc.get_grid(x), torch.stack([flo_w, flo_h]).transpose(0, 1))
+        grid = grid.transpose(1, 2).transpose(2, 3)
+        xw = tf.grid_sample(x, grid, align_corners=True)
+        m = tf.grid_sample(torch.ones(x.size()), grid, align_corners=True)
+        return xw * (m >= thr).float()
+    return fwd
+
+
+def set_mode(train_patch: bool, robust: bool):
+    ref_irr.rescale_flow = _rescale_alias if train_patch else _orig_rescale
+    ref_pwc.WarpingLayer.forward = _make_warp_forward(0.9999) if robust else _orig_warp_forward
+
+
+def ref_model(params=None, seed=None):
+    args = types.SimpleNamespace(batch_size=2, model_div_flow=0.05)
+    if seed is not None:
+        torch.manual_seed(seed)
+    m = models.IRR_PWC(args)
+    if params is not None:
+        missing = m.load_state_dict(params, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+    return m, args
+
+
+def npf(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+# ---------------------------------------------------------------- per-op fixtures
+def gen_ops(out_dir):
+    set_mode(False, False)
+    g = torch.Generator().manual_seed(77)
+    d = {}
+    # cost volume: fwd + grads (reference Python path actually used by the model)
+    for name, (b, c, h, w) in {"a": (2, 8, 12, 14), "b": (1, 32, 24, 28), "c": (1, 196, 6, 7),
+                               "d": (2, 5, 9, 33)}.items():
+        f1 = torch.randn(b, c, h, w, generator=g, requires_grad=True)
+        f2 = torch.randn(b, c, h, w, generator=g, requires_grad=True)
+        go = torch.randn(b, 81, h, w, generator=g)
+        o = ref_pwc.compute_cost_volume(f1, f2, {"max_disp": 4})
+        o.backward(go)
+        d.update({f"corr_{name}_f1": npf(f1), f"corr_{name}_f2": npf(f2), f"corr_{name}_go": npf(go),
+                  f"corr_{name}_out": npf(o), f"corr_{name}_g1": npf(f1.grad), f"corr_{name}_g2": npf(f2.grad)})
+    # warp: out, mask bits, grads.  Flow magnitudes chosen so many samples leave the frame.
+    wl = ref_pwc.WarpingLayer()
+    for name, (b, c, h, w, H, W, amp) in {"a": (2, 3, 16, 24, 64, 96, 0.5), "b": (1, 32, 12, 14, 384, 448, 0.08),
+                                          "c": (2, 2, 10, 17, 40, 68, 0.3), "z": (1, 4, 8, 8, 64, 64, 0.0)}.items():
+        for thr_name, robust in (("asis", False), ("robust", True)):
+            set_mode(False, robust)
+            gg = torch.Generator().manual_seed(ord(name[0]) + 5)
+            x = torch.randn(b, c, h, w, generator=gg, requires_grad=True)
+            fl = (torch.randn(b, 2, h, w, generator=gg) * amp).requires_grad_(True)
+            go = torch.randn(b, c, h, w, generator=gg)
+            o = wl(x, fl, H, W, 0.05)
+            o.backward(go)
+            # mask bits as the reference computes them
+            with torch.no_grad():
+                ones = wl(torch.ones(b, 1, h, w), fl, H, W, 0.05)
+            key = f"warp_{name}_{thr_name}"
+            d.update({key + "_x": npf(x), key + "_flow": npf(fl), key + "_go": npf(go), key + "_out": npf(o),
+                      key + "_mask": npf(ones), key + "_gx": npf(x.grad), key + "_gflow": npf(fl.grad),
+                      key + "_HW": np.array([H, W], np.int64)})
+    set_mode(False, False)
+    # bilinear align_corners resize (up and down), fwd + grad
+    for name, (b, c, h, w, oh, ow) in {"up": (2, 2, 6, 7, 12, 14), "down": (1, 3, 64, 96, 8, 12),
+                                       "odd": (1, 1, 5, 9, 11, 13)}.items():
+        x = torch.randn(b, c, h, w, generator=g, requires_grad=True)
+        go = torch.randn(b, c, oh, ow, generator=g)
+        o = tf.interpolate(x, [oh, ow], mode="bilinear", align_corners=True)
+        o.backward(go)
+        d.update({f"resize_{name}_x": npf(x), f"resize_{name}_go": npf(go), f"resize_{name}_out": npf(o),
+                  f"resize_{name}_gx": npf(x.grad)})
+    np.savez_compressed(os.path.join(out_dir, "ops_basic.npz"), **d)
+
+    # module-level fixtures with synthetic weights (refine heads, occ upsampler, dense, context)
+    P = O.synthetic_params(0)
+    m, _ = ref_model(P)
+    m.eval()
+    d = {}
+    b, h, w = 2, 12, 14
+    flow = torch.randn(b, 2, h, w, generator=g, requires_grad=True)
+    dimg = torch.randn(b, 3, h, w, generator=g, requires_grad=True)
+    feat = torch.randn(b, 32, h, w, generator=g, requires_grad=True)
+    go = torch.randn(b, 2, h, w, generator=g)
+    o = m.refine_flow(flow, dimg, feat)
+    o.backward(go)
+    d.update(rf_flow=npf(flow), rf_dimg=npf(dimg), rf_feat=npf(feat), rf_go=npf(go), rf_out=npf(o),
+             rf_gflow=npf(flow.grad), rf_gdimg=npf(dimg.grad), rf_gfeat=npf(feat.grad))
+    occ = torch.randn(b, 1, h, w, generator=g, requires_grad=True)
+    f1 = torch.randn(b, 32, h, w, generator=g, requires_grad=True)
+    f2 = torch.randn(b, 32, h, w, generator=g, requires_grad=True)
+    go = torch.randn(b, 1, h, w, generator=g)
+    o = m.refine_occ(occ, f1, f2)
+    o.backward(go)
+    d.update(ro_occ=npf(occ), ro_f1=npf(f1), ro_f2=npf(f2), ro_go=npf(go), ro_out=npf(o),
+             ro_gocc=npf(occ.grad), ro_gf1=npf(f1.grad), ro_gf2=npf(f2.grad))
+    occ = torch.randn(b, 1, h, w, generator=g, requires_grad=True)
+    guide = torch.randn(b, 10, 2 * h, 2 * w, generator=g, requires_grad=True)
+    go = torch.randn(b, 1, 2 * h, 2 * w, generator=g)
+    o = m.occ_shuffle_upsample(occ, guide)
+    o.backward(go)
+    d.update(ou_occ=npf(occ), ou_guide=npf(guide), ou_go=npf(go), ou_out=npf(o),
+             ou_gocc=npf(occ.grad), ou_gguide=npf(guide.grad))
+    x = torch.randn(1, 115, h, w, generator=g, requires_grad=True)
+    xi, fo = m.flow_estimators(x)
+    gi = torch.randn(xi.shape, generator=g)
+    gf = torch.randn(fo.shape, generator=g)
+    (xi * gi).sum().add((fo * gf).sum()).backward()
+    d.update(de_x=npf(x), de_gi=npf(gi), de_gf=npf(gf), de_xi=npf(xi), de_out=npf(fo), de_gx=npf(x.grad))
+    m.zero_grad()
+    x = torch.randn(1, 565, 20, 24, generator=g, requires_grad=True)
+    o = m.context_networks(x)
+    go = torch.randn(o.shape, generator=g)
+    o.backward(go)
+    d.update(cn_x=npf(x), cn_go=npf(go), cn_out=npf(o), cn_gx=npf(x.grad),
+             cn_gw0=npf(m.context_networks.convs[0][0].weight.grad)[:, :8],
+             cn_gb0=npf(m.context_networks.convs[0][0].bias.grad),
+             cn_gw4=npf(m.context_networks.convs[4][0].weight.grad)[:8],
+             cn_gw6=npf(m.context_networks.convs[6][0].weight.grad))
+    np.savez_compressed(os.path.join(out_dir, "ops_modules.npz"), **d)
+
+
+# ---------------------------------------------------------------- end-to-end fixtures
+def _flat_stats(out):
+    st = []
+    for key in ("flow", "occ"):
+        for lvl in out[key]:
+            for t in lvl:
+                st.append([float(t.mean()), float(t.abs().mean()), float(t.std())])
+    return np.array(st, np.float64)
+
+
+def gen_e2e(out_dir, B=2, H=128, W=192):
+    P = O.synthetic_params(0)
+    batch = O.synthetic_batch(B, H, W, 1234)
+    d = {"weight_checksum": np.array([float(sum(v.double().sum() for v in P.values())),
+                                      float(sum(v.double().abs().sum() for v in P.values()))]),
+         "input_checksum": np.array([float(batch[k].double().sum()) for k in
+                                     ("input1", "input2", "target1", "target2", "target_occ1", "target_occ2")])}
+    names = sorted(P.keys())
+    d["param_names"] = np.array(names)
+    for mode, robust in (("asis", False), ("robust", True)):
+        # eval, as-is reference (unpatched rescale)
+        set_mode(False, robust)
+        m, args = ref_model(P)
+        m.eval()
+        with torch.no_grad():
+            ev = m({"input1": batch["input1"], "input2": batch["input2"]})
+        d[f"{mode}_eval_flow"] = npf(ev["flow"])
+        d[f"{mode}_eval_occ"] = npf(ev["occ"])
+        lossm = losses.MultiScaleEPE_PWC_Bi_Occ_upsample(args)
+        lossm.eval()
+        em = lossm(ev, batch)
+        d[f"{mode}_eval_metrics"] = np.array([float(em["epe"]), float(em["F1"])])
+        # eval with the alias patch must be bit-identical (finding 3)
+        set_mode(True, robust)
+        with torch.no_grad():
+            ev2 = m({"input1": batch["input1"], "input2": batch["input2"]})
+        assert torch.equal(ev["flow"], ev2["flow"]) and torch.equal(ev["occ"], ev2["occ"]), "alias patch changed eval"
+        # train step quantities
+        m.train()
+        lossm.train()
+        out = m({"input1": batch["input1"].clone().requires_grad_(True),
+                 "input2": batch["input2"].clone().requires_grad_(True)})
+        ld = lossm(out, batch)
+        ld["total_loss"].backward()
+        sd = dict(m.named_parameters())
+        d[f"{mode}_train_losses"] = np.array([float(ld["flow_loss"]), float(ld["occ_loss"]), float(ld["total_loss"])])
+        d[f"{mode}_train_gradnorm"] = np.array([float(sd[n].grad.double().norm()) for n in names])
+        d[f"{mode}_train_gradsum"] = np.array([float(sd[n].grad.double().sum()) for n in names])
+        d[f"{mode}_train_outstats"] = _flat_stats(out)
+        # level-4 outputs in full for one sample (flow_f refined + occ_f refined), and finest occ
+        d[f"{mode}_train_l4_flow_f"] = npf(out["flow"][4][2][:1])
+        d[f"{mode}_train_l4_occ_f"] = npf(out["occ"][4][2][:1])
+        d[f"{mode}_train_l6_occ_f"] = npf(out["occ"][6][0][:1, :, ::4, ::4])
+        # one Adam step, post-step parameter checksum (A14)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=4e-4)
+        opt.step()
+        d[f"{mode}_poststep_sum"] = np.array([float(sd[n].detach().double().sum()) for n in names])
+        # Sintel-variant loss for the same outputs (secondary)
+        m.zero_grad()
+        out = m({"input1": batch["input1"], "input2": batch["input2"]})
+        ls = losses.MultiScaleEPE_PWC_Bi_Occ_upsample_Sintel(args)
+        ls.train()
+        l2 = ls(out, batch)
+        d[f"{mode}_train_losses_sintel"] = np.array([float(l2["flow_loss"]), float(l2["occ_loss"]), float(l2["total_loss"])])
+    set_mode(False, False)
+    np.savez_compressed(os.path.join(out_dir, f"e2e_B{B}_{H}x{W}.npz"), **d)
+
+
+def gen_e2e_big(out_dir, B=1, H=384, W=448):
+    """384x448: 4096 sampled output pixels + stats, both modes, eval only."""
+    P = O.synthetic_params(0)
+    batch = O.synthetic_batch(B, H, W, 1234)
+    g = torch.Generator().manual_seed(99)
+    idx = torch.randperm(H * W, generator=g)[:4096]
+    d = {"sample_idx": idx.numpy()}
+    for mode, robust in (("asis", False), ("robust", True)):
+        set_mode(False, robust)
+        m, _ = ref_model(P)
+        m.eval()
+        with torch.no_grad():
+            ev = m({"input1": batch["input1"], "input2": batch["input2"]})
+        d[f"{mode}_flow_samples"] = npf(ev["flow"].reshape(B, 2, -1)[:, :, idx])
+        d[f"{mode}_occ_samples"] = npf(ev["occ"].reshape(B, 1, -1)[:, :, idx])
+        d[f"{mode}_stats"] = np.array([float(ev["flow"].mean()), float(ev["flow"].abs().mean()),
+                                       float(ev["occ"].mean()), float(ev["occ"].abs().mean())])
+    set_mode(False, False)
+    np.savez_compressed(os.path.join(out_dir, f"e2e_B{B}_{H}x{W}.npz"), **d)
+
+
+def gen_init(out_dir):
+    """Fingerprint of the reference's own MSRA init under torch.manual_seed(0)."""
+    m, _ = ref_model(None, seed=0)
+    sd = m.state_dict()
+    names = list(sd.keys())
+    np.savez_compressed(os.path.join(out_dir, "init_seed0.npz"), names=np.array(names),
+                        shapes=np.array([str(tuple(sd[n].shape)) for n in names]),
+                        sums=np.array([float(sd[n].double().sum()) for n in names]),
+                        abssums=np.array([float(sd[n].double().abs().sum()) for n in names]),
+                        n_params=np.array([sum(v.numel() for v in sd.values())]))
+
+
+def gen_pwcnet_plumbing(out_dir):
+    """BASELINE config 0: pwcnet.py forward on one random 128x192 pair (plumbing)."""
+    set_mode(False, False)
+    args = types.SimpleNamespace(batch_size=1, model_div_flow=0.05)
+    torch.manual_seed(0)
+    m = models.PWCNet(args)
+    m.eval()
+    g = torch.Generator().manual_seed(4321)
+    i1 = torch.rand(1, 3, 128, 192, generator=g)
+    i2 = torch.rand(1, 3, 128, 192, generator=g)
+    with torch.no_grad():
+        o = m({"input1": i1, "input2": i2})
+    np.savez_compressed(os.path.join(out_dir, "pwcnet_plumbing.npz"), flow=npf(o["flow"]),
+                        stats=np.array([float(o["flow"].mean()), float(o["flow"].abs().mean())]))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    torch.set_num_threads(8)
+    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "pwcnet": gen_pwcnet_plumbing}
+    for k, fn in steps.items():
+        if a.only and k not in a.only.split(","):
+            continue
+        print("generating", k, flush=True)
+        fn(a.out)
+    print("done")
