@@ -1,0 +1,89 @@
+/*
+ * irr_hip.h -- C ABI of libirr_hip.so, the MI355X (gfx950) kernels behind the IRR-PWC hot path.
+ *
+ * This is the drop-in boundary.  It replaces, for visinf/irr:
+ *   - the legacy pybind module ``correlation_cuda`` (models/correlation_package/correlation_cuda.cc:8-14,
+ *     86-93, 165-168: forward(in1,in2,rbot1,rbot2,out, pad,k,md,s1,s2,mult) / backward(...)), and
+ *   - every stock-torch operator call site of ``PWCNet.forward`` (models/IRR_PWC.py:51-184), see the
+ *     per-function citations below.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer to fp32 data unless stated;
+ *   - tensors are NCHW with dense H*W planes: element (b,c,y,x) of tensor T lives at
+ *     T + b*T_bs + c*H*W + y*W + x, where the batch stride ``T_bs`` (in elements) is passed
+ *     explicitly so that a tensor may be a channel slice of a larger buffer (the DenseNet concat
+ *     buffers of FlowEstimatorDense are written in place, no torch.cat copies);
+ *   - ``stream`` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - no allocation inside: the caller owns every buffer (the reference instead resize_()s and
+ *     fill_(0)s inside the C++ glue, correlation_cuda.cc:34-40,104-112);
+ *   - return value: 0 on success, otherwise the hipError_t of the failing call / launch
+ *     (the reference returns 1 on success and raises AT_ERROR on failure, correlation_cuda.cc:78-83);
+ *     IRR_EINVAL (-22) for arguments outside the supported range.
+ *   - launchers are re-entrant and keep no global mutable state (backward runs on autograd's thread).
+ */
+#ifndef IRR_HIP_H
+#define IRR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRR_EINVAL (-22)
+
+/* library / device probe.  Returns the ABI version (increases when a signature changes). */
+int irr_abi_version(void);
+
+/* ---- 81-channel cost volume -------------------------------------------------------------------
+ * out[b,(dy+4)*9+(dx+4),y,x] = (1/C) * sum_c f1[b,c,y,x] * f2[b,c,y+dy,x+dx]   (zero outside), dy,dx in [-4,4]
+ * == compute_cost_volume (models/pwc_modules.py:42-62, call sites models/IRR_PWC.py:90-91)
+ * == Correlation(pad_size=4,kernel_size=1,max_displacement=4,stride1=1,stride2=1)
+ *    (models/correlation_package/correlation.py:47-61, correlation_cuda_kernel.cu:41-114).
+ * fuse_lrelu != 0 additionally applies LeakyReLU(0.1) (models/IRR_PWC.py:94-95).
+ */
+int irr_corr81_fwd_f32(const float* f1, const float* f2, float* out,
+                       int B, int C, int H, int W,
+                       long f1_bs, long f2_bs, long out_bs,
+                       int fuse_lrelu, void* stream);
+
+/* Gradients of the above (correlation_cuda_kernel.cu:116-300, both in gather form).
+ * ``out`` (nullable) is the forward result when fuse_lrelu was set: gout is then multiplied by the
+ * LeakyReLU derivative (1 where out>0, else 0.1).  g1/g2 are fully overwritten. */
+int irr_corr81_bwd_f32(const float* f1, const float* f2, const float* gout, const float* out,
+                       float* g1, float* g2,
+                       int B, int C, int H, int W,
+                       long f1_bs, long f2_bs, long gout_bs, long out_bs, long g1_bs, long g2_bs,
+                       void* stream);
+
+/* ---- flow warping with validity mask -----------------------------------------------------------
+ * WarpingLayer.forward (models/pwc_modules.py:115-133) incl. get_grid (:107-112):
+ *   grid = linspace(-1,1) + flow*2/max(size_im-1,1)/div_flow ; bilinear, zeros padding,
+ *   align_corners=True ; out = sample(x) * (sample(ones) >= mask_thr).
+ * gridx[W], gridy[H] are the two torch.linspace(-1,1,n) vectors (device), so that the base grid is
+ * bit-identical to the reference's.  mask_thr = 1.0 is the reference as-is.
+ */
+int irr_warp_fwd_f32(const float* x, const float* flow, const float* gridx, const float* gridy,
+                     float* out, int B, int C, int H, int W,
+                     long x_bs, long flow_bs, long out_bs,
+                     int height_im, int width_im, float div_flow, float mask_thr, void* stream);
+
+/* gx (nullable) receives the scatter-add gradient w.r.t. x (zeroed inside), gflow (nullable) the
+ * gradient w.r.t. flow.  No gradient flows through the mask (piecewise constant). */
+int irr_warp_bwd_f32(const float* x, const float* flow, const float* gridx, const float* gridy,
+                     const float* gout, float* gx, float* gflow,
+                     int B, int C, int H, int W,
+                     long x_bs, long flow_bs, long gout_bs, long gx_bs, long gflow_bs,
+                     int height_im, int width_im, float div_flow, float mask_thr, void* stream);
+
+/* ---- bilinear resize, align_corners=True --------------------------------------------------------
+ * upsample2d_as (models/pwc_modules.py:65-67).  out = alpha * resize(x).
+ */
+int irr_resize_bilinear_ac_fwd_f32(const float* x, float* out, int B, int C, int H, int W, int OH, int OW,
+                                   long x_bs, long out_bs, float alpha, void* stream);
+/* gx = alpha * resize^T(gout); gx fully overwritten (gather form, deterministic). */
+int irr_resize_bilinear_ac_bwd_f32(const float* gout, float* gx, int B, int C, int H, int W, int OH, int OW,
+                                   long gout_bs, long gx_bs, float alpha, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRR_HIP_H */

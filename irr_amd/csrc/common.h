@@ -1,0 +1,22 @@
+// Shared helpers for the gfx950 kernels of libirr_hip.so.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/irr_hip.h"
+
+#define IRR_LAUNCH_CHECK()                      \
+  do {                                          \
+    hipError_t e__ = hipGetLastError();         \
+    if (e__ != hipSuccess) return (int)e__;     \
+  } while (0)
+
+#define IRR_HIP_TRY(expr)                       \
+  do {                                          \
+    hipError_t e__ = (expr);                    \
+    if (e__ != hipSuccess) return (int)e__;     \
+  } while (0)
+
+static inline int irr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float irr_lrelu(float v) { return v > 0.f ? v : 0.1f * v; }
+__device__ __forceinline__ float irr_lrelu_grad(float y) { return y > 0.f ? 1.f : 0.1f; }

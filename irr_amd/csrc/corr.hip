@@ -1,0 +1,165 @@
+// 81-channel cost volume (search range 4, stride 1) -- forward and both gradients.
+//
+// Reference semantics: compute_cost_volume (models/pwc_modules.py:42-62) ==
+// correlation_forward / correlation_backward_input{1,2} (models/correlation_package/
+// correlation_cuda_kernel.cu:41-300) at (pad,k,md,s1,s2)=(4,1,4,1,1).
+//
+// MI355X design (not the reference's one-block-per-pixel / serial-reduction scheme):
+//   * a workgroup owns a 16x16 pixel tile; lanes run along x so every global access is a
+//     coalesced 64 B row segment and the 81-plane output is written as dense 64 B rows;
+//   * the "other" feature map is staged in LDS with a 4-pixel halo, CC channels at a time
+//     ((16+8) x (16+8) x CC floats, row pitch 25 to keep the 9 x-shifts on distinct banks);
+//   * each lane keeps all 81 displacement accumulators in VGPRs -> no cross-lane reduction at
+//     all, the channel sum is a private FMA chain; HBM sees f1, f2 once and the output once;
+//   * both gradients are gathers with the same LDS tile (no atomics, deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 16;            // tile side
+constexpr int HALO = 4;
+constexpr int TP = TS + 2 * HALO; // 24
+constexpr int PITCH = TP + 1;     // 25
+constexpr int CC = 16;            // channels per LDS stage
+
+__device__ __forceinline__ void stage_tile(float (*tile)[TP][PITCH], const float* __restrict__ src, long plane,
+                                           int c0, int C, int y0, int x0, int H, int W, int tid) {
+  // tile[c][ty][tx] = src[c0+c][y0-4+ty][x0-4+tx], zero outside image / channel range
+  for (int i = tid; i < CC * TP * TP; i += TS * TS) {
+    int c = i / (TP * TP);
+    int r = i - c * (TP * TP);
+    int ty = r / TP, tx = r - ty * TP;
+    int y = y0 - HALO + ty, x = x0 - HALO + tx;
+    float v = 0.f;
+    if (c0 + c < C && y >= 0 && y < H && x >= 0 && x < W) v = src[(long)(c0 + c) * plane + (long)y * W + x];
+    tile[c][ty][tx] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void corr81_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                        float* __restrict__ out, int C, int H, int W, long f1_bs,
+                                                        long f2_bs, long out_bs, int fuse_lrelu) {
+  __shared__ float tile[CC][TP][PITCH];
+  const int tid = threadIdx.x;
+  const int tx = tid & (TS - 1), ty = tid >> 4;
+  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS, b = blockIdx.z;
+  const int x = x0 + tx, y = y0 + ty;
+  const bool inside = (x < W) && (y < H);
+  const long plane = (long)H * W;
+  const float* f1b = f1 + (long)b * f1_bs;
+  const float* f2b = f2 + (long)b * f2_bs;
+
+  float acc[81];
+#pragma unroll
+  for (int d = 0; d < 81; ++d) acc[d] = 0.f;
+
+  for (int c0 = 0; c0 < C; c0 += CC) {
+    __syncthreads();
+    stage_tile(tile, f2b, plane, c0, C, y0, x0, H, W, tid);
+    __syncthreads();
+    const int cn = min(CC, C - c0);
+    for (int c = 0; c < cn; ++c) {
+      const float a = inside ? f1b[(long)(c0 + c) * plane + (long)y * W + x] : 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 9; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 9; ++dx) acc[dy * 9 + dx] = fmaf(a, tile[c][ty + dy][tx + dx], acc[dy * 9 + dx]);
+    }
+  }
+  if (!inside) return;
+  float* o = out + (long)b * out_bs + (long)y * W + x;
+  const float cf = (float)C;
+#pragma unroll
+  for (int d = 0; d < 81; ++d) {
+    float v = acc[d] / cf;     // mean over channels (torch.mean = sum / C)
+    if (fuse_lrelu) v = irr_lrelu(v);
+    o[(long)d * plane] = v;
+  }
+}
+
+// SECOND == false: g1[c,p] = (1/C) sum_d g[d][p]     * f2[c][p+d]   (tile = f2, shift +d)
+// SECOND == true : g2[c,p] = (1/C) sum_d g[d][p-d]   * f1[c][p-d]   (tile = f1, shift -d)
+template <bool SECOND>
+__global__ __launch_bounds__(256) void corr81_bwd_kernel(const float* __restrict__ other, const float* __restrict__ gout,
+                                                        const float* __restrict__ fwd_out, float* __restrict__ gin,
+                                                        int C, int H, int W, long other_bs, long gout_bs, long out_bs,
+                                                        long gin_bs) {
+  __shared__ float tile[CC][TP][PITCH];
+  const int tid = threadIdx.x;
+  const int tx = tid & (TS - 1), ty = tid >> 4;
+  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS, b = blockIdx.z;
+  const int x = x0 + tx, y = y0 + ty;
+  const bool inside = (x < W) && (y < H);
+  const long plane = (long)H * W;
+  const float* ob = other + (long)b * other_bs;
+  const float* gb = gout + (long)b * gout_bs;
+  const float* fb = fwd_out ? fwd_out + (long)b * out_bs : nullptr;
+  const float inv_c = 1.f / (float)C;
+
+  float wgt[81];
+#pragma unroll
+  for (int dy = 0; dy < 9; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 9; ++dx) {
+      const int d = dy * 9 + dx;
+      int yy = y, xx = x;
+      if (SECOND) { yy = y - (dy - 4); xx = x - (dx - 4); }
+      float g = 0.f;
+      if (inside && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const long off = (long)d * plane + (long)yy * W + xx;
+        g = gb[off];
+        if (fb) g *= irr_lrelu_grad(fb[off]);
+      }
+      wgt[d] = g;
+    }
+
+  for (int c0 = 0; c0 < C; c0 += CC) {
+    __syncthreads();
+    stage_tile(tile, ob, plane, c0, C, y0, x0, H, W, tid);
+    __syncthreads();
+    const int cn = min(CC, C - c0);
+    for (int c = 0; c < cn; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 9; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 9; ++dx) {
+          const float t = SECOND ? tile[c][ty + 8 - dy][tx + 8 - dx] : tile[c][ty + dy][tx + dx];
+          s = fmaf(wgt[dy * 9 + dx], t, s);
+        }
+      if (inside) gin[(long)b * gin_bs + (long)(c0 + c) * plane + (long)y * W + x] = s * inv_c;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int irr_corr81_fwd_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, long f1_bs,
+                                  long f2_bs, long out_bs, int fuse_lrelu, void* stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !f1 || !f2 || !out) return IRR_EINVAL;
+  if (B > 65535) return IRR_EINVAL;
+  dim3 grid(irr_cdiv(W, TS), irr_cdiv(H, TS), B);
+  hipLaunchKernelGGL(corr81_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, f1, f2, out, C, H, W, f1_bs, f2_bs,
+                     out_bs, fuse_lrelu);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_corr81_bwd_f32(const float* f1, const float* f2, const float* gout, const float* out, float* g1,
+                                  float* g2, int B, int C, int H, int W, long f1_bs, long f2_bs, long gout_bs,
+                                  long out_bs, long g1_bs, long g2_bs, void* stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !f1 || !f2 || !gout) return IRR_EINVAL;
+  if (B > 65535) return IRR_EINVAL;
+  dim3 grid(irr_cdiv(W, TS), irr_cdiv(H, TS), B);
+  if (g1) {
+    hipLaunchKernelGGL(corr81_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, f2, gout, out, g1, C, H, W,
+                       f2_bs, gout_bs, out_bs, g1_bs);
+    IRR_LAUNCH_CHECK();
+  }
+  if (g2) {
+    hipLaunchKernelGGL(corr81_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, f1, gout, out, g2, C, H, W,
+                       f1_bs, gout_bs, out_bs, g2_bs);
+    IRR_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -1,0 +1,101 @@
+// Bilinear resize with align_corners=True -- upsample2d_as (models/pwc_modules.py:65-67), used for the
+// x2 flow/occ upsampling between pyramid levels, the raw-image downsizing per level
+// (models/IRR_PWC.py:82-85,126-127,151-152) and the eval output (:176-177).
+//
+// ATen semantics: scale = (in-1)/(out-1) (0 when out==1); src = scale*dst; i0 = floor(src);
+// i1 = min(i0+1, in-1); l1 = src-i0; l0 = 1-l1;  out = l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11).
+// Backward is written as a gather over the (few) output pixels that touch an input pixel, so it is
+// deterministic and needs no atomics.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int C,
+                                                        int H, int W, int OH, int OW, long x_bs, long out_bs,
+                                                        float alpha) {
+  const long oplane = (long)OH * OW;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= oplane) return;
+  const int b = blockIdx.z;
+  const int oy = (int)(p / OW), ox = (int)(p - (long)oy * OW);
+  const float sy = ac_scale(H, OH) * oy, sx = ac_scale(W, OW) * ox;
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  const float* xb = x + (long)b * x_bs;
+  float* ob = out + (long)b * out_bs + p;
+  const long plane = (long)H * W;
+  for (int c = blockIdx.y; c < C; c += gridDim.y) {
+    const float* xc = xb + (long)c * plane;
+    const float v = ly0 * (lx0 * xc[(long)y0 * W + x0] + lx1 * xc[(long)y0 * W + x1]) +
+                    ly1 * (lx0 * xc[(long)y1 * W + x0] + lx1 * xc[(long)y1 * W + x1]);
+    ob[(long)c * oplane] = alpha * v;
+  }
+}
+
+// 1-D contribution of output index o to input index i (hat function sampled on the output lattice)
+__device__ __forceinline__ float tap_weight(int i, int o, int in, float scale) {
+  const float s = scale * o;
+  const int i0 = (int)s;
+  const int i1 = min(i0 + 1, in - 1);
+  const float l1 = s - i0;
+  float w = 0.f;
+  if (i0 == i) w += 1.f - l1;
+  if (i1 == i) w += l1;
+  return w;
+}
+
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gx, int C,
+                                                        int H, int W, int OH, int OW, long gout_bs, long gx_bs,
+                                                        float alpha) {
+  const long plane = (long)H * W;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  const int b = blockIdx.z;
+  const int iy = (int)(p / W), ix = (int)(p - (long)iy * W);
+  const float scy = ac_scale(H, OH), scx = ac_scale(W, OW);
+  // candidate output range touching input row iy: src in (iy-1, iy+1)
+  int oy_lo, oy_hi, ox_lo, ox_hi;
+  if (scy > 0.f) { oy_lo = max(0, (int)floorf((iy - 1) / scy) - 1); oy_hi = min(OH - 1, (int)ceilf((iy + 1) / scy) + 1); }
+  else { oy_lo = 0; oy_hi = OH - 1; }
+  if (scx > 0.f) { ox_lo = max(0, (int)floorf((ix - 1) / scx) - 1); ox_hi = min(OW - 1, (int)ceilf((ix + 1) / scx) + 1); }
+  else { ox_lo = 0; ox_hi = OW - 1; }
+  const long oplane = (long)OH * OW;
+  for (int c = blockIdx.y; c < C; c += gridDim.y) {
+    const float* gc = gout + (long)b * gout_bs + (long)c * oplane;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const float wy = tap_weight(iy, oy, H, scy);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const float wx = tap_weight(ix, ox, W, scx);
+        if (wx != 0.f) acc += wy * wx * gc[(long)oy * OW + ox];
+      }
+    }
+    gx[(long)b * gx_bs + (long)c * plane + p] = alpha * acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int irr_resize_bilinear_ac_fwd_f32(const float* x, float* out, int B, int C, int H, int W, int OH, int OW,
+                                              long x_bs, long out_bs, float alpha, void* stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || !x || !out || B > 65535) return IRR_EINVAL;
+  dim3 grid(irr_cdiv((long)OH * OW, 256), C < 8 ? C : 8, B);
+  hipLaunchKernelGGL(resize_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, C, H, W, OH, OW, x_bs, out_bs,
+                     alpha);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_resize_bilinear_ac_bwd_f32(const float* gout, float* gx, int B, int C, int H, int W, int OH, int OW,
+                                              long gout_bs, long gx_bs, float alpha, void* stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || !gout || !gx || B > 65535) return IRR_EINVAL;
+  dim3 grid(irr_cdiv((long)H * W, 256), C < 8 ? C : 8, B);
+  hipLaunchKernelGGL(resize_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs,
+                     gx_bs, alpha);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,157 @@
+"""Autograd-visible operators of the IRR-PWC hot path, each a thin shell around one C-ABI call
+(include/irr_hip.h).  No CPU path: CPU tensors raise.
+
+Reference call sites: models/IRR_PWC.py:82-95,126-129,141-142,151-158 and the helpers in
+models/pwc_modules.py:42-133.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import hip
+
+_GRID_CACHE = {}
+
+
+def _linspace_dev(n: int, device: torch.device) -> torch.Tensor:
+    """torch.linspace(-1, 1, n) computed by torch on the HOST (bit-identical to the reference's
+    get_grid, models/pwc_modules.py:107-112) and cached on the device."""
+    key = (n, device.index)
+    t = _GRID_CACHE.get(key)
+    if t is None:
+        t = torch.linspace(-1.0, 1.0, n).float().to(device)
+        _GRID_CACHE[key] = t
+    return t
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("irr_amd operators run on the HIP device only (no CPU fallback)")
+
+
+# ----------------------------------------------------------------------------------------------
+# cost volume
+# ----------------------------------------------------------------------------------------------
+class _CostVolume(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f1, f2, lrelu: bool):
+        _need_cuda(f1, f2)
+        f1, f2 = f1.contiguous(), f2.contiguous()
+        B, C, H, W = f1.shape
+        out = torch.empty(B, 81, H, W, device=f1.device, dtype=torch.float32)
+        hip.call("irr_corr81_fwd_f32", hip.ptr(f1), hip.ptr(f2), hip.ptr(out), B, C, H, W,
+                 hip.bs(f1), hip.bs(f2), hip.bs(out), int(lrelu), hip.stream())
+        ctx.lrelu = lrelu
+        ctx.save_for_backward(f1, f2, out if lrelu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        f1, f2, out = ctx.saved_tensors
+        gout = gout.contiguous()
+        B, C, H, W = f1.shape
+        g1 = torch.empty_like(f1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
+        hip.call("irr_corr81_bwd_f32", hip.ptr(f1), hip.ptr(f2), hip.ptr(gout), hip.ptr(out), hip.ptr(g1), hip.ptr(g2),
+                 B, C, H, W, hip.bs(f1), hip.bs(f2), hip.bs(gout), hip.bs(out) if out is not None else 0,
+                 hip.bs(g1) if g1 is not None else 0, hip.bs(g2) if g2 is not None else 0, hip.stream())
+        return g1, g2, None
+
+
+def cost_volume(feat1: torch.Tensor, feat2: torch.Tensor, lrelu: bool = False) -> torch.Tensor:
+    """81-channel cost volume, optionally with the LeakyReLU(0.1) of models/IRR_PWC.py:94-95 fused."""
+    if feat1.shape != feat2.shape:
+        raise ValueError(f"feature maps must have equal shapes, got {tuple(feat1.shape)} vs {tuple(feat2.shape)}")
+    return _CostVolume.apply(feat1, feat2, lrelu)
+
+
+def compute_cost_volume(feat1, feat2, param_dict):
+    """Functional twin with the reference's signature (models/pwc_modules.py:42-53).  The reference
+    reads only ``max_disp`` and silently assumes k=1, s1=s2=1; unsupported values are rejected here."""
+    if int(param_dict.get("max_disp", 4)) != 4:
+        raise ValueError("only max_disp=4 (81 displacements) is implemented")
+    for key, want in (("kernel_size", 1), ("stride1", 1), ("stride2", 1)):
+        if int(param_dict.get(key, want)) != want:
+            raise ValueError(f"{key} must be {want}")
+    return cost_volume(feat1, feat2, False)
+
+
+# ----------------------------------------------------------------------------------------------
+# warp
+# ----------------------------------------------------------------------------------------------
+class _Warp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flow, height_im: int, width_im: int, div_flow: float, mask_thr: float):
+        _need_cuda(x, flow)
+        x, flow = x.contiguous(), flow.contiguous()
+        B, C, H, W = x.shape
+        gx, gy = _linspace_dev(W, x.device), _linspace_dev(H, x.device)
+        out = torch.empty_like(x)
+        hip.call("irr_warp_fwd_f32", hip.ptr(x), hip.ptr(flow), hip.ptr(gx), hip.ptr(gy), hip.ptr(out), B, C, H, W,
+                 hip.bs(x), hip.bs(flow), hip.bs(out), height_im, width_im, div_flow, mask_thr, hip.stream())
+        ctx.cfg = (height_im, width_im, div_flow, mask_thr)
+        ctx.save_for_backward(x, flow)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, flow = ctx.saved_tensors
+        height_im, width_im, div_flow, mask_thr = ctx.cfg
+        gout = gout.contiguous()
+        B, C, H, W = x.shape
+        gxg, gyg = _linspace_dev(W, x.device), _linspace_dev(H, x.device)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gf = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
+        hip.call("irr_warp_bwd_f32", hip.ptr(x), hip.ptr(flow), hip.ptr(gxg), hip.ptr(gyg), hip.ptr(gout),
+                 hip.ptr(gx), hip.ptr(gf), B, C, H, W, hip.bs(x), hip.bs(flow), hip.bs(gout),
+                 hip.bs(gx) if gx is not None else 0, hip.bs(gf) if gf is not None else 0,
+                 height_im, width_im, div_flow, mask_thr, hip.stream())
+        return gx, gf, None, None, None, None
+
+
+def warp(x, flow, height_im: int, width_im: int, div_flow: float, mask_threshold: float = 1.0):
+    """WarpingLayer.forward (models/pwc_modules.py:119-133)."""
+    if x.shape[0] != flow.shape[0] or x.shape[2:] != flow.shape[2:] or flow.shape[1] != 2:
+        raise ValueError(f"bad shapes for warp: x {tuple(x.shape)} flow {tuple(flow.shape)}")
+    return _Warp.apply(x, flow, int(height_im), int(width_im), float(div_flow), float(mask_threshold))
+
+
+# ----------------------------------------------------------------------------------------------
+# bilinear resize, align_corners=True
+# ----------------------------------------------------------------------------------------------
+class _ResizeAC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, oh: int, ow: int, alpha: float):
+        _need_cuda(x)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty(B, C, oh, ow, device=x.device, dtype=torch.float32)
+        hip.call("irr_resize_bilinear_ac_fwd_f32", hip.ptr(x), hip.ptr(out), B, C, H, W, oh, ow,
+                 hip.bs(x), hip.bs(out), alpha, hip.stream())
+        ctx.cfg = (H, W, oh, ow, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        H, W, oh, ow, alpha = ctx.cfg
+        gout = gout.contiguous()
+        B, C = gout.shape[:2]
+        gx = torch.empty(B, C, H, W, device=gout.device, dtype=torch.float32)
+        hip.call("irr_resize_bilinear_ac_bwd_f32", hip.ptr(gout), hip.ptr(gx), B, C, H, W, oh, ow,
+                 hip.bs(gout), hip.bs(gx), alpha, hip.stream())
+        return gx, None, None, None
+
+
+def resize_bilinear_ac(x, oh: int, ow: int, alpha: float = 1.0):
+    """alpha * F.interpolate(x, [oh, ow], mode='bilinear', align_corners=True)."""
+    return _ResizeAC.apply(x, int(oh), int(ow), float(alpha))
+
+
+def upsample2d_as(inputs, target_as, mode="bilinear"):
+    """models/pwc_modules.py:65-67."""
+    if mode != "bilinear":
+        raise ValueError("only bilinear is implemented")
+    return resize_bilinear_ac(inputs, target_as.shape[2], target_as.shape[3])

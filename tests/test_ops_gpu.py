@@ -1,0 +1,114 @@
+"""GPU parity of the HIP operators against vectors produced by the reference (tests/golden/ops_basic.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_basic.npz"))
+
+
+def D(a, grad=False):
+    t = torch.from_numpy(np.array(a)).cuda()
+    return t.requires_grad_(True) if grad else t
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_cost_volume(golden_dir, case):
+    from irr_amd import functional as Fn
+    g = _g(golden_dir)
+    f1, f2 = D(g[f"corr_{case}_f1"], True), D(g[f"corr_{case}_f2"], True)
+    out = Fn.compute_cost_volume(f1, f2, {"max_disp": 4, "kernel_size": 1, "stride1": 1, "stride2": 1})
+    out.backward(D(g[f"corr_{case}_go"]))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"corr_{case}_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(f1.grad.cpu().numpy(), g[f"corr_{case}_g1"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(f2.grad.cpu().numpy(), g[f"corr_{case}_g2"], rtol=1e-5, atol=1e-6)
+
+
+def test_cost_volume_fused_lrelu(golden_dir):
+    from irr_amd import functional as Fn
+    g = _g(golden_dir)
+    f1c, f2c = torch.from_numpy(g["corr_a_f1"]).requires_grad_(True), torch.from_numpy(g["corr_a_f2"]).requires_grad_(True)
+    go = torch.from_numpy(g["corr_a_go"])
+    ref = torch.nn.functional.leaky_relu(torch.from_numpy(g["corr_a_out"]), 0.1)
+    # reference gradient of lrelu(corr): chain rule on the golden pieces
+    from oracle import irr_pwc_oracle as O
+    o = torch.nn.functional.leaky_relu(O.cost_volume(f1c, f2c), 0.1)
+    o.backward(go)
+    f1, f2 = D(g["corr_a_f1"], True), D(g["corr_a_f2"], True)
+    out = Fn.cost_volume(f1, f2, lrelu=True)
+    out.backward(go.cuda())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(f1.grad.cpu().numpy(), f1c.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(f2.grad.cpu().numpy(), f2c.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_cost_volume_rejects_unsupported():
+    from irr_amd import functional as Fn
+    x = torch.zeros(1, 4, 8, 8, device="cuda")
+    with pytest.raises(ValueError):
+        Fn.compute_cost_volume(x, x, {"max_disp": 3})
+    with pytest.raises(ValueError):
+        Fn.cost_volume(x, torch.zeros(1, 4, 8, 9, device="cuda"))
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "z"])
+@pytest.mark.parametrize("mode,thr", [("asis", 1.0), ("robust", 0.9999)])
+def test_warp(golden_dir, case, mode, thr):
+    from irr_amd import functional as Fn
+    g = _g(golden_dir)
+    k = f"warp_{case}_{mode}"
+    H, W = [int(v) for v in g[k + "_HW"]]
+    x, fl = D(g[k + "_x"], True), D(g[k + "_flow"], True)
+    out = Fn.warp(x, fl, H, W, 0.05, thr)
+    out.backward(D(g[k + "_go"]))
+    # mask bits: bit-equal to the reference's (sample(ones) >= thr)
+    with torch.no_grad():
+        m = Fn.warp(torch.ones(x.shape[0], 1, *x.shape[2:], device="cuda"), fl.detach(), H, W, 0.05, thr)
+    assert np.array_equal(m.cpu().numpy(), g[k + "_mask"]), "warp validity mask differs from the reference"
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[k + "_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[k + "_gx"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(fl.grad.cpu().numpy(), g[k + "_gflow"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["up", "down", "odd"])
+def test_resize(golden_dir, case):
+    from irr_amd import functional as Fn
+    g = _g(golden_dir)
+    x = D(g[f"resize_{case}_x"], True)
+    go = D(g[f"resize_{case}_go"])
+    out = Fn.resize_bilinear_ac(x, go.shape[2], go.shape[3])
+    out.backward(go)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"resize_{case}_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"resize_{case}_gx"], rtol=1e-5, atol=1e-5)
+
+
+def test_warp_full_size_properties():
+    """384x448-level shapes: zero flow is the identity (mask all ones), linearity in x."""
+    from irr_amd import functional as Fn
+    torch.manual_seed(0)
+    x = torch.randn(4, 32, 96, 112, device="cuda")
+    z = torch.zeros(4, 2, 96, 112, device="cuda")
+    out = Fn.warp(x, z, 384, 448, 0.05, 0.9999)
+    assert torch.allclose(out, x, atol=1e-6)
+    fl = torch.randn(4, 2, 96, 112, device="cuda") * 0.1
+    a = Fn.warp(x, fl, 384, 448, 0.05)
+    b = Fn.warp(2 * x, fl, 384, 448, 0.05)
+    assert torch.allclose(2 * a, b, atol=1e-5)
+
+
+def test_cost_volume_full_size_properties():
+    """level-4 shape at bs8: centre channel equals the channel-mean of f1*f2; shifted input shifts channels."""
+    from irr_amd import functional as Fn
+    torch.manual_seed(0)
+    f1 = torch.randn(8, 32, 96, 112, device="cuda")
+    f2 = torch.randn(8, 32, 96, 112, device="cuda")
+    cv = Fn.cost_volume(f1, f2)
+    assert torch.allclose(cv[:, 40], (f1 * f2).mean(1), atol=1e-5)
+    # displacement (dy,dx)=(+1,-2): channel (1+4)*9+(-2+4)=47
+    ref = (f1[:, :, :-1, 2:] * f2[:, :, 1:, :-2]).mean(1)
+    assert torch.allclose(cv[:, 47, :-1, 2:], ref, atol=1e-5)
