@@ -23,7 +23,7 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
           "-Wno-unused-function"]
 # per-file extras.  warp.hip reproduces ATen's fp32 rounding sequence: no contraction there.
-EXTRA = {"warp.hip": ["-ffp-contract=off"]}
+EXTRA = {"warp.hip": ["-ffp-contract=off"], "resize.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:
@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
-           [os.path.join(ROOT, "include", "irr_hip.h")]
+           [os.path.join(ROOT, "include", "irr_hip.h"), os.path.abspath(__file__)]
     jobs = []
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s[:-4] + ".o")
