@@ -83,6 +83,50 @@ int irr_resize_bilinear_ac_fwd_f32(const float* x, float* out, int B, int C, int
 int irr_resize_bilinear_ac_bwd_f32(const float* gout, float* gx, int B, int C, int H, int W, int OH, int OW,
                                    long gout_bs, long gx_bs, float alpha, void* stream);
 
+/* ---- convolution family (fp32 MFMA implicit GEMM) -----------------------------------------------
+ * conv() helper (models/pwc_modules.py:8-19, models/irr_modules.py:7-18): Conv2d(k in {1,3}, stride in {1,2},
+ * dilation d, padding (k-1)*d/2, bias) followed by an optional LeakyReLU(0.1).
+ *
+ * Weights are consumed in a packed layout produced by irr_conv_pack_weights_f32:
+ *   wp[((cp*KK + tap)*2 + half)*CoP + co] = w[co][2*cp+half][tap]   (0 where ci or co is padding),
+ *   CoP = roundup(Cout,32), cp in [0, ceil(Cin/2)), KK = k*k.
+ * With transpose != 0 the roles of Cin/Cout are swapped and the taps flipped, which turns the same
+ * forward kernel into the data-gradient (stride 1 only).
+ */
+long irr_conv_packed_weight_elems(int Cin, int Cout, int k);
+int irr_conv_pack_weights_f32(const float* w, float* wp, int Cin, int Cout, int k, int transpose, void* stream);
+
+/* y = epilogue(conv(x, wp) + bias):
+ *   v = acc + bias[co] (bias nullable);  if (lrelu) v = v>0 ? v : 0.1 v;
+ *   y = res ? res + alpha*v : alpha*v      (res nullable; OccUpsampleNetwork residual adds,
+ *                                           models/irr_modules.py:51-54, and flow + flow_res, models/IRR_PWC.py:110-114)
+ *   accumulate != 0: y += previous y        (data-gradient accumulation into DenseNet gradient buffers).
+ * Cin >= 2.  The batch is split internally so that all in-kernel byte offsets stay below 4 GiB.
+ */
+int irr_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, const float* res, float* y,
+                       int B, int Cin, int H, int W, int Cout, int OH, int OW,
+                       int k, int stride, int dil,
+                       long x_bs, long y_bs, long res_bs,
+                       int lrelu, float alpha, int accumulate, void* stream);
+
+/* dW[co][ci][tap] (+)= sum_{b,y,x} gy[b,co,y,x] * x[b,ci,y*stride+(ty-pad), x*stride+(tx-pad)]
+ * gw is the plain (Cout,Cin,k,k) tensor and is ACCUMULATED into with atomics (caller zeroes it). */
+int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw,
+                         int B, int Cin, int H, int W, int Cout, int OH, int OW,
+                         int k, int stride, int dil, long x_bs, long gy_bs, void* stream);
+
+/* gpre = gy * (y>0 ? 1 : 0.1) (if lrelu) ; gbias[co] += sum gpre (gbias nullable, accumulated).
+ * gpre may alias gy. */
+int irr_lrelu_bwd_bias_f32(const float* gy, const float* y, float* gpre, float* gbias,
+                           int B, int C, int HW, long gy_bs, long y_bs, long gpre_bs,
+                           int lrelu, void* stream);
+
+/* strided data-gradient for the stride-2 pyramid convs (gather form):
+ * gx[b,ci,iy,ix] = sum_{co,tap : iy = oy*stride + (ty-pad)*dil ...} w[co][ci][tap] * gy[b,co,oy,ox] */
+int irr_conv2d_dgrad_strided_f32(const float* gy, const float* w, float* gx,
+                                 int B, int Cin, int H, int W, int Cout, int OH, int OW,
+                                 int k, int stride, int dil, long gy_bs, long gx_bs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

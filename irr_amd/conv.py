@@ -1,0 +1,208 @@
+"""conv() blocks of IRR-PWC on the fp32-MFMA kernels of libirr_hip.so.
+
+Mirrors the reference helper ``conv(in_planes, out_planes, kernel_size, stride, dilation, isReLU)``
+(models/pwc_modules.py:8-19, models/irr_modules.py:7-18): Conv2d with "same" padding and bias,
+optionally followed by LeakyReLU(0.1).  All tensors may be channel-slice views of larger NCHW buffers
+(dense H*W planes, arbitrary batch stride), which is how the DenseNet decoders avoid ``torch.cat``.
+
+``IRR_CONV_BACKEND=miopen`` swaps in torch's GPU convolution (bring-up / A-B comparison only; it is not
+the product path and is never selected implicitly).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import hip
+
+BACKEND = os.environ.get("IRR_CONV_BACKEND", "hip")
+
+
+def set_backend(name: str) -> None:
+    global BACKEND
+    if name not in ("hip", "miopen"):
+        raise ValueError(name)
+    BACKEND = name
+
+
+def out_hw(h: int, w: int, k: int, stride: int, dil: int) -> Tuple[int, int]:
+    pad = ((k - 1) * dil) // 2
+    return ((h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1)
+
+
+# ----------------------------------------------------------------------------------------------
+# packed-weight cache: weights are re-packed only when the parameter changed (optimizer step)
+# ----------------------------------------------------------------------------------------------
+_PACK_CACHE = {}
+
+
+def packed_weights(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
+    w = weight.detach()
+    key = (w.data_ptr(), bool(transpose))
+    ver = w._version
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[2] == tuple(w.shape):
+        return hit[1]
+    cout, cin, k, _ = w.shape
+    if transpose:
+        lcin, lcout = cout, cin
+    else:
+        lcin, lcout = cin, cout
+    n = hip.lib().irr_conv_packed_weight_elems(lcin, lcout, k)
+    wp = hit[1] if (hit is not None and hit[1].numel() == n) else torch.empty(n, device=w.device, dtype=torch.float32)
+    wc = w.contiguous()
+    hip.call("irr_conv_pack_weights_f32", hip.ptr(wc), hip.ptr(wp), lcin, lcout, k, int(transpose), hip.stream())
+    _PACK_CACHE[key] = (ver, wp, tuple(w.shape))
+    return wp
+
+
+def clear_pack_cache() -> None:
+    _PACK_CACHE.clear()
+
+
+# ----------------------------------------------------------------------------------------------
+# primitives (no autograd)
+# ----------------------------------------------------------------------------------------------
+def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, dil: int,
+                 lrelu: bool, out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+                 alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
+    """out = [res +] alpha * act(conv(x, weight) + bias)   (accumulate: out += ...)."""
+    B, cin, H, W = x.shape
+    cout, cin_w, k, _ = weight.shape
+    assert cin == cin_w, (x.shape, weight.shape)
+    oh, ow = out_hw(H, W, k, stride, dil)
+    if out is None:
+        out = torch.empty(B, cout, oh, ow, device=x.device, dtype=torch.float32)
+    assert out.shape == (B, cout, oh, ow), (out.shape, (B, cout, oh, ow))
+    if BACKEND == "miopen":
+        v = F.conv2d(x, weight.detach(), bias.detach() if bias is not None else None, stride=stride,
+                     padding=((k - 1) * dil) // 2, dilation=dil)
+        if lrelu:
+            v = F.leaky_relu(v, 0.1)
+        v = v * alpha if res is None else res + alpha * v
+        if accumulate:
+            out += v
+        else:
+            out.copy_(v)
+        return out
+    wp = packed_weights(weight, False)
+    hip.call("irr_conv2d_fwd_f32", hip.ptr(x), hip.ptr(wp), hip.ptr(bias.detach() if bias is not None else None),
+             hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, oh, ow, k, stride, dil,
+             hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
+             int(lrelu), float(alpha), int(accumulate), hip.stream())
+    return out
+
+
+def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in_hw: Tuple[int, int],
+               gx: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """gx (+)= conv_transpose(gy, weight); gy must already carry the activation derivative."""
+    B, cout, oh, ow = gy.shape
+    cout_w, cin, k, _ = weight.shape
+    assert cout == cout_w
+    H, W = in_hw
+    if gx is None:
+        gx = torch.empty(B, cin, H, W, device=gy.device, dtype=torch.float32)
+        accumulate = False
+    if BACKEND == "miopen":
+        v = torch.nn.grad.conv2d_input((B, cin, H, W), weight.detach(), gy, stride=stride,
+                                       padding=((k - 1) * dil) // 2, dilation=dil)
+        if accumulate:
+            gx += v
+        else:
+            gx.copy_(v)
+        return gx
+    if stride == 1 and cout >= 2:
+        wp = packed_weights(weight, True)
+        hip.call("irr_conv2d_fwd_f32", hip.ptr(gy), hip.ptr(wp), None, None, hip.ptr(gx), B, cout, oh, ow, cin, H, W,
+                 k, 1, dil, hip.bs(gy), hip.bs(gx), 0, 0, 1.0, int(accumulate), hip.stream())
+    else:
+        tmp = gx if not accumulate else torch.empty(B, cin, H, W, device=gy.device, dtype=torch.float32)
+        wc = weight.detach().contiguous()
+        hip.call("irr_conv2d_dgrad_strided_f32", hip.ptr(gy), hip.ptr(wc), hip.ptr(tmp), B, cin, H, W, cout, oh, ow,
+                 k, stride, dil, hip.bs(gy), hip.bs(tmp), hip.stream())
+        if accumulate:
+            gx += tmp
+    return gx
+
+
+def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil: int,
+               gw: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gw += d/dW; gw (Cout,Cin,k,k) is created zeroed when not given."""
+    cout, cin, k, _ = weight_shape
+    B, _, H, W = x.shape
+    _, _, oh, ow = gy.shape
+    if gw is None:
+        gw = torch.zeros(cout, cin, k, k, device=x.device, dtype=torch.float32)
+    if BACKEND == "miopen":
+        gw += torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), gy, stride=stride,
+                                          padding=((k - 1) * dil) // 2, dilation=dil)
+        return gw
+    assert gw.is_contiguous()
+    hip.call("irr_conv2d_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), B, cin, H, W, cout, oh, ow, k, stride, dil,
+             hip.bs(x), hip.bs(gy), hip.stream())
+    return gw
+
+
+def lrelu_bwd_bias(gy: torch.Tensor, y: Optional[torch.Tensor], lrelu: bool, gpre: Optional[torch.Tensor],
+                   gbias: Optional[torch.Tensor]) -> None:
+    """gpre = gy * LeakyReLU'(y) (y = the activated output); gbias += sum over (b, h, w) of gpre."""
+    B, C, H, W = gy.shape
+    hip.call("irr_lrelu_bwd_bias_f32", hip.ptr(gy), hip.ptr(y) if lrelu else None, hip.ptr(gpre), hip.ptr(gbias),
+             B, C, H * W, hip.bs(gy), hip.bs(y) if lrelu else 0, hip.bs(gpre) if gpre is not None else 0,
+             int(lrelu), hip.stream())
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd: one conv() block
+# ----------------------------------------------------------------------------------------------
+class _ConvBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride: int, dil: int, lrelu: bool, res, alpha: float):
+        if not x.is_cuda:
+            raise RuntimeError("irr_amd conv runs on the HIP device only (no CPU fallback)")
+        x = x if _planes_dense(x) else x.contiguous()
+        if res is not None and not _planes_dense(res):
+            res = res.contiguous()
+        if res is None and alpha == 1.0:
+            y = conv_forward(x, weight, bias, stride, dil, lrelu)
+            act = y
+        else:
+            # keep the activated conv output for the LeakyReLU derivative
+            act = conv_forward(x, weight, bias, stride, dil, lrelu)
+            y = act * alpha if res is None else torch.add(res, act, alpha=alpha)
+        ctx.cfg = (stride, dil, lrelu, alpha, res is not None)
+        ctx.save_for_backward(x, weight, act if lrelu else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, act = ctx.saved_tensors
+        stride, dil, lrelu, alpha, has_res = ctx.cfg
+        gy = gy if _planes_dense(gy) else gy.contiguous()
+        gres = gy if (has_res and ctx.needs_input_grad[6]) else None
+        g = gy if alpha == 1.0 else gy * alpha
+        cout = weight.shape[0]
+        gb = torch.zeros(cout, device=gy.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if lrelu or gb is not None:
+            gpre = torch.empty_like(g) if lrelu else None
+            lrelu_bwd_bias(g, act, lrelu, gpre, gb)
+            if lrelu:
+                g = gpre
+        gx = conv_dgrad(g, weight, stride, dil, x.shape[2:]) if ctx.needs_input_grad[0] else None
+        gw = conv_wgrad(x, g, weight.shape, stride, dil) if ctx.needs_input_grad[1] else None
+        return gx, gw, gb, None, None, None, gres, None
+
+
+def _planes_dense(t: torch.Tensor) -> bool:
+    b, c, h, w = t.shape
+    sb, sc, sh, sw = t.stride()
+    return (sw == 1 or w == 1) and (sh == w or h == 1) and (sc == h * w or c == 1)
+
+
+def conv_block(x, weight, bias, stride: int = 1, dil: int = 1, lrelu: bool = True, res=None, alpha: float = 1.0):
+    """[res +] alpha * LeakyReLU?(conv2d(x, weight, bias, stride, 'same' padding, dil))."""
+    return _ConvBlock.apply(x, weight, bias, int(stride), int(dil), bool(lrelu), res, float(alpha))

@@ -1,0 +1,267 @@
+// fp32 MFMA direct convolution for the IRR-PWC conv() blocks (models/pwc_modules.py:8-19,
+// models/irr_modules.py:7-18): k in {1,3}, stride in {1,2}, dilation d, "same" padding, bias, LeakyReLU(0.1),
+// with the epilogue variants the decoders need (residual add, scaling, accumulate-into-output).
+//
+// Formulation (per wave, no LDS, no barriers):  D[co][px] += W[co][k] * X[k][px],  k = (ci, tap)
+//   * v_mfma_f32_32x32x2_f32: rows i = 32 output channels, cols j = 32 output pixels, 2 k-values per
+//     instruction = two consecutive input channels of one tap (lanes 0-31 -> ci=2cp, lanes 32-63 -> ci=2cp+1).
+//   * pixels are a LINEAR index over (b, oy, ox); a lane owns one pixel per 32-pixel sub-tile and keeps
+//     its 9 tap offsets (+ validity) for the whole K loop, so tiles may wrap rows and samples freely and the
+//     X operand is one coalesced global_load_dword per (sub-tile, tap, channel pair) straight into the MFMA
+//     source VGPR -- the activations are NCHW, i.e. already "K-major, pixel-contiguous", which is exactly
+//     the B-fragment layout; an LDS round trip would buy nothing at the fp32 MFMA rate (64 cyc / instr).
+//   * weights come from a packed [cp][tap][half][CoP] array (irr_conv_pack_weights_f32) so the A fragment
+//     is one coalesced 256 B load per (tap, pair, co-tile); all waves of a CU share it through L1/L2.
+//   * a wave owns MT co-tiles x NT pixel sub-tiles (MT*NT*16 accumulator VGPRs); one block = 4 independent
+//     waves; grid.x walks the pixel range, grid.y the co-tile groups.
+//   * epilogue writes D rows as dense 128 B pixel runs per output channel (NCHW), fusing bias, LeakyReLU,
+//     residual/scale and the "+=" used for DenseNet gradient accumulation.
+// The same kernel computes the stride-1 data gradient when fed transposed+flipped packed weights.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  const float* res;
+  float* y;
+  int B, Cin, H, W, Cout, OH, OW;
+  int stride, dil, pad;
+  int CoP;               // padded Cout (multiple of 32)
+  long x_bs, y_bs, res_bs;
+  int lrelu, accumulate;
+  float alpha;
+};
+
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
+}
+
+template <int MT, int NT, int KS>
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
+  constexpr int KK = KS * KS;
+  constexpr int D = (KK == 9) ? 3 : 1;          // prefetch distance in k-steps (ring slots)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, half = lane >> 5;
+  const long ohw = (long)a.OH * a.OW;
+  const long hw = (long)a.H * a.W;
+  const long total = (long)a.B * ohw;
+  const long pbase = ((long)blockIdx.x * 4 + wave) * (NT * 32);
+  if (pbase >= total) return;
+  const int cog = blockIdx.y;
+
+  uint32_t voff[NT][KK];
+  bool valid[NT][KK];
+  uint32_t ooff[NT], roff[NT];
+  bool pvalid[NT];
+#pragma unroll
+  for (int s = 0; s < NT; ++s) {
+    const long p = pbase + s * 32 + j;
+    pvalid[s] = p < total;
+    const long pp = pvalid[s] ? p : total - 1;
+    const int b = (int)(pp / ohw);
+    const int r = (int)(pp - (long)b * ohw);
+    const int oy = r / a.OW, ox = r - oy * a.OW;
+    ooff[s] = (uint32_t)((long)b * a.y_bs + r);
+    roff[s] = (uint32_t)((long)b * a.res_bs + r);
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      const int ty = t / KS, tx = t - ty * KS;
+      const int iy = oy * a.stride - a.pad + ty * a.dil;
+      const int ix = ox * a.stride - a.pad + tx * a.dil;
+      const bool ok = pvalid[s] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
+      voff[s][t] = (uint32_t)(((long)b * a.x_bs + (long)cy * a.W + cx + (long)half * hw) * 4);
+      valid[s][t] = ok;
+    }
+  }
+  const uint32_t aoff = (uint32_t)((half * a.CoP + cog * MT * 32 + j) * 4);
+  const uint32_t cop_bytes2 = (uint32_t)a.CoP * 8u;       // two k-rows per tap
+  const uint32_t wstep = (uint32_t)KK * cop_bytes2;       // packed-weight bytes per channel pair
+  const uint32_t xstep = (uint32_t)(hw * 8);              // activation bytes per channel pair
+  const int ncp = (a.Cin + 1) >> 1;
+  // odd Cin: the last pair is (Cin-2, Cin-1) with a zero weight row for Cin-2 (see pack_weights_kernel),
+  // so every activation read stays inside the tensor.
+  const uint32_t x_last = (uint32_t)((long)(a.Cin - 2) * hw * 4);
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, (short)0, (int)0xffffffffu, 0x00020000);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][s][r] = 0.f;
+
+  float ra[D][MT], rb[D][NT];      // operand ring, statically indexed
+
+  // issue the loads of k-step (cp, tap) into ring slot `slot`
+  auto issue = [&](int slot, int cp, int tap) {
+    const int cpc = min(cp, ncp - 1);                       // past-the-end prefetches re-read the last pair
+    const uint32_t xs = (cpc == ncp - 1 && (a.Cin & 1)) ? x_last : (uint32_t)cpc * xstep;
+    const uint32_t ws = (uint32_t)cpc * wstep + (uint32_t)tap * cop_bytes2;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ra[slot][m] = buf_load(wr, aoff + m * 128, ws);
+#pragma unroll
+    for (int s = 0; s < NT; ++s) rb[slot][s] = buf_load(xr, voff[s][tap], xs);
+  };
+
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(d, d / KK, d % KK);
+
+  for (int cp = 0; cp < ncp; ++cp) {
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) {
+      const int slot = tap % D;
+      float av[MT], bv[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) av[m] = ra[slot][m];
+#pragma unroll
+      for (int s = 0; s < NT; ++s) bv[s] = valid[s][tap] ? rb[slot][s] : 0.f;
+      const int ntap = tap + D;
+      __builtin_amdgcn_sched_barrier(0);      // keep the software pipeline: consume slot -> refill slot -> MFMAs
+      issue(slot, ntap >= KK ? cp + 1 : cp, ntap >= KK ? ntap - KK : ntap);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int s = 0; s < NT; ++s)
+          acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[s], acc[m][s], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*half, j = lane&31 ----
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = (cog * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co >= a.Cout) continue;
+      const float bsv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+      for (int s = 0; s < NT; ++s) {
+        if (!pvalid[s]) continue;
+        float v = acc[m][s][r] + bsv;
+        if (a.lrelu) v = irr_lrelu(v);
+        float* dst = a.y + ooff[s] + (long)co * ohw;
+        if (a.res) v = a.res[roff[s] + (long)co * ohw] + a.alpha * v;
+        else v *= a.alpha;
+        if (a.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+  }
+}
+
+// wp[((cp*KK + tap)*2 + half)*CoP + co]
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int KK,
+                                    int CoP, int transpose, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int co = (int)(i % CoP);
+  long r = i / CoP;
+  const int half = (int)(r & 1);
+  r >>= 1;
+  const int tap = (int)(r % KK);
+  const int cp = (int)(r / KK);
+  int ci = 2 * cp + half;
+  bool zero_row = false;
+  if ((Cin & 1) && cp == (Cin >> 1)) {        // odd tail: lanes read channels (Cin-2, Cin-1); Cin-2 was already consumed
+    ci = Cin - 2 + half;
+    zero_row = (half == 0);
+  }
+  float v = 0.f;
+  if (!transpose) {
+    if (!zero_row && ci < Cin && co < Cout) v = w[((long)co * Cin + ci) * KK + tap];
+  } else {
+    // logical conv': Cin' = Cout(orig), Cout' = Cin(orig): here (Cin, Cout) are ALREADY the swapped sizes;
+    // w is the original (Cout_orig = Cin, Cin_orig = Cout) tensor: w[ci][co][KK-1-tap]
+    if (!zero_row && ci < Cin && co < Cout) v = w[((long)ci * Cout + co) * KK + (KK - 1 - tap)];
+  }
+  wp[i] = v;
+}
+
+template <int MT, int NT, int KS>
+int launch(const ConvArgs& a, hipStream_t st) {
+  const long total = (long)a.B * a.OH * a.OW;
+  const int cot = a.CoP / 32;
+  dim3 grid(irr_cdiv(total, 4L * NT * 32), irr_cdiv(cot, MT), 1);
+  hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KS>), grid, dim3(256), 0, st, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+template <int KS>
+int dispatch(const ConvArgs& a, hipStream_t st) {
+  const int cot = a.CoP / 32;
+  const long total = (long)a.B * a.OH * a.OW;
+  const long ptiles = (total + 31) / 32;
+  // small problems: favour many waves over register blocking
+  if (ptiles * cot < 4096) {
+    if (cot >= 2 && ptiles * ((cot + 1) / 2) >= 1024) return launch<2, 1, KS>(a, st);
+    return launch<1, 1, KS>(a, st);
+  }
+  if (cot == 1) return launch<1, 4, KS>(a, st);
+  if (cot == 2) return launch<2, 4, KS>(a, st);
+  if (cot == 3) return launch<3, 2, KS>(a, st);
+  return launch<4, 2, KS>(a, st);
+}
+
+}  // namespace
+
+extern "C" long irr_conv_packed_weight_elems(int Cin, int Cout, int k) {
+  const long CoP = (Cout + 31) / 32 * 32;
+  return (long)((Cin + 1) / 2) * k * k * 2 * CoP;
+}
+
+extern "C" int irr_conv_pack_weights_f32(const float* w, float* wp, int Cin, int Cout, int k, int transpose,
+                                         void* stream) {
+  if (!w || !wp || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3)) return IRR_EINVAL;
+  const int CoP = (Cout + 31) / 32 * 32;
+  const long n = irr_conv_packed_weight_elems(Cin, Cout, k);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, Cin, Cout,
+                     k * k, CoP, transpose, n);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, const float* res, float* y, int B,
+                                  int Cin, int H, int W, int Cout, int OH, int OW, int k, int stride, int dil,
+                                  long x_bs, long y_bs, long res_bs, int lrelu, float alpha, int accumulate,
+                                  void* stream) {
+  if (!x || !wp || !y || B <= 0 || Cin < 2 || Cout <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return IRR_EINVAL;
+  if ((k != 1 && k != 3) || stride < 1 || dil < 1) return IRR_EINVAL;
+  const int pad = ((k - 1) * dil) / 2;
+  if (OH != (H + 2 * pad - dil * (k - 1) - 1) / stride + 1 || OW != (W + 2 * pad - dil * (k - 1) - 1) / stride + 1)
+    return IRR_EINVAL;
+  ConvArgs a;
+  a.wp = wp; a.bias = bias;
+  a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW;
+  a.stride = stride; a.dil = dil; a.pad = pad;
+  a.CoP = (Cout + 31) / 32 * 32;
+  a.x_bs = x_bs; a.y_bs = y_bs; a.res_bs = res_bs;
+  a.lrelu = lrelu; a.accumulate = accumulate; a.alpha = alpha;
+  // 32-bit byte offsets inside the kernel: split the batch so every offset stays below 4 GiB
+  const long lim = (1L << 30) - (long)(Cin + 2) * H * W - 1;       // elements
+  long per = x_bs > 0 ? lim / (x_bs > y_bs ? (x_bs > res_bs ? x_bs : res_bs) : (y_bs > res_bs ? y_bs : res_bs)) : B;
+  if (per < 1) return IRR_EINVAL;
+  if (per > B) per = B;
+  for (int b0 = 0; b0 < B; b0 += (int)per) {
+    const int nb = (B - b0) < per ? (B - b0) : (int)per;
+    a.B = nb;
+    a.x = x + (long)b0 * x_bs;
+    a.y = y + (long)b0 * y_bs;
+    a.res = res ? res + (long)b0 * res_bs : nullptr;
+    const int rc = (k == 3) ? dispatch<3>(a, (hipStream_t)stream) : dispatch<1>(a, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
