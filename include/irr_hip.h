@@ -127,6 +127,28 @@ int irr_conv2d_dgrad_strided_f32(const float* gy, const float* w, float* gx,
                                  int B, int Cin, int H, int W, int Cout, int OH, int OW,
                                  int k, int stride, int dil, long gy_bs, long gx_bs, void* stream);
 
+/* ---- bilateral refinement tail -------------------------------------------------------------------
+ * RefineFlow / RefineOcc tail (models/irr_modules.py:92-104, 130-139):
+ *   wgt_t = softmax_t(-f[b,t,y,x]^2), t = dy*3+dx ;
+ *   out[b,c,y,x] = scale_c * sum_t wgt_t * v[b,c,clamp(y+dy-1),clamp(x+dx-1)]      (ReplicationPad2d(1) + Unfold(3x3))
+ * scale_c = scale0 for c == 0, scale1 otherwise: folds the to_global rescale applied right after RefineFlow
+ * (models/IRR_PWC.py:137-138).  f has 9 channels, v/out have C (2 for flow, 1 for occlusion).
+ */
+int irr_refine_tail_fwd_f32(const float* f, const float* v, float* out, int B, int C, int H, int W,
+                            long f_bs, long v_bs, long out_bs, float scale0, float scale1, void* stream);
+/* gf (9 channels, nullable) is overwritten; gv (nullable) is zeroed inside and scatter-added. */
+int irr_refine_tail_bwd_f32(const float* f, const float* v, const float* gout, float* gf, float* gv,
+                            int B, int C, int H, int W, long f_bs, long v_bs, long gout_bs, long gf_bs, long gv_bs,
+                            float scale0, float scale1, void* stream);
+
+/* ---- nearest x2 upsampling ------------------------------------------------------------------------
+ * upsample_factor2 (models/irr_modules.py:21-27) for H, W multiples of 64 (the bilinear fallback never fires).
+ */
+int irr_upsample_nearest2x_fwd_f32(const float* x, float* out, int B, int C, int H, int W,
+                                   long x_bs, long out_bs, void* stream);
+int irr_upsample_nearest2x_bwd_f32(const float* gout, float* gx, int B, int C, int H, int W,
+                                   long gout_bs, long gx_bs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,14 @@
 """irr_amd -- MI355X-native IRR-PWC forward/backward path (drop-in for visinf/irr's models/IRR_PWC.py).
 
 Only what the hot path needs lives here: ``csrc/`` (HIP kernels + the C ABI of include/irr_hip.h),
-``hip.py`` (ctypes binding), ``functional.py`` (autograd operators) and the host-side mirror of the
-reference's module surface.
+``hip.py`` (ctypes binding), ``functional.py`` / ``conv.py`` (autograd operators) and the host-side mirror
+of the reference's module surface (``irr_pwc.PWCNet``, ``modules``, ``losses``, ``correlation.Correlation``).
 """
 __version__ = "0.1.0"
+
+from .irr_pwc import PWCNet  # noqa: E402,F401
+from .correlation import Correlation  # noqa: E402,F401
+from .functional import compute_cost_volume  # noqa: E402,F401
+from .losses import MultiScaleEPE_PWC_Bi_Occ_upsample  # noqa: E402,F401
+
+IRR_PWC = PWCNet          # models/__init__.py:35 rebinds the module name to the class

@@ -155,3 +155,67 @@ def upsample2d_as(inputs, target_as, mode="bilinear"):
     if mode != "bilinear":
         raise ValueError("only bilinear is implemented")
     return resize_bilinear_ac(inputs, target_as.shape[2], target_as.shape[3])
+
+
+# ----------------------------------------------------------------------------------------------
+# bilateral refinement tail
+# ----------------------------------------------------------------------------------------------
+class _RefineTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, v, scale0: float, scale1: float):
+        _need_cuda(feat, v)
+        feat, v = feat.contiguous(), v.contiguous()
+        B, C, H, W = v.shape
+        if feat.shape != (B, 9, H, W):
+            raise ValueError(f"refine tail expects 9 kernel channels, got {tuple(feat.shape)}")
+        out = torch.empty_like(v)
+        hip.call("irr_refine_tail_fwd_f32", hip.ptr(feat), hip.ptr(v), hip.ptr(out), B, C, H, W,
+                 hip.bs(feat), hip.bs(v), hip.bs(out), scale0, scale1, hip.stream())
+        ctx.scales = (scale0, scale1)
+        ctx.save_for_backward(feat, v)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        feat, v = ctx.saved_tensors
+        gout = gout.contiguous()
+        B, C, H, W = v.shape
+        gf = torch.empty_like(feat) if ctx.needs_input_grad[0] else None
+        gv = torch.empty_like(v) if ctx.needs_input_grad[1] else None
+        hip.call("irr_refine_tail_bwd_f32", hip.ptr(feat), hip.ptr(v), hip.ptr(gout), hip.ptr(gf), hip.ptr(gv),
+                 B, C, H, W, hip.bs(feat), hip.bs(v), hip.bs(gout), hip.bs(gf) if gf is not None else 0,
+                 hip.bs(gv) if gv is not None else 0, ctx.scales[0], ctx.scales[1], hip.stream())
+        return gf, gv, None, None
+
+
+def refine_tail(feat, v, scale=(1.0, 1.0)):
+    """scale_c * sum_t softmax_t(-feat^2) * replicate-padded 3x3 neighbourhood of v (models/irr_modules.py:92-104)."""
+    return _RefineTail.apply(feat, v, float(scale[0]), float(scale[1]))
+
+
+# ----------------------------------------------------------------------------------------------
+# nearest x2
+# ----------------------------------------------------------------------------------------------
+class _Nearest2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty(B, C, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+        hip.call("irr_upsample_nearest2x_fwd_f32", hip.ptr(x), hip.ptr(out), B, C, H, W, hip.bs(x), hip.bs(out), hip.stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        gout = gout.contiguous()
+        B, C, OH, OW = gout.shape
+        gx = torch.empty(B, C, OH // 2, OW // 2, device=gout.device, dtype=torch.float32)
+        hip.call("irr_upsample_nearest2x_bwd_f32", hip.ptr(gout), hip.ptr(gx), B, C, OH // 2, OW // 2,
+                 hip.bs(gout), hip.bs(gx), hip.stream())
+        return gx
+
+
+def upsample_nearest2x(x):
+    """F.interpolate(x, scale_factor=2, mode='nearest') (models/irr_modules.py:22)."""
+    return _Nearest2x.apply(x)

@@ -1,0 +1,157 @@
+"""IRR-PWC on MI355X -- drop-in for the reference's ``models.IRR_PWC`` (= models/IRR_PWC.py ``PWCNet``).
+
+Same constructor (``PWCNet(args, div_flow=0.05)``), same ``forward(input_dict) -> dict`` contract
+(train: ``{'flow': 7 lists, 'occ': 7 lists}``; eval: full-resolution ``{'flow', 'occ'}``), same 124
+``state_dict`` keys and the same attributes (``_div_flow, search_range, num_chs, output_level, num_levels,
+corr_params``).  What differs is the execution plan:
+
+* both flow directions are processed as ONE batch of 2B samples (``[x1; x2]`` against ``[x2; x1]``): the
+  decoders share their weights across directions (models/IRR_PWC.py:32-46), so this halves the number of
+  launches and doubles the pixel count every MFMA conv tile sees; results are identical because every
+  operator is per-sample;
+* the reference's ``rescale_flow`` aliasing (models/pwc_modules.py:70-82, observable at
+  models/IRR_PWC.py:128-138) is written out explicitly, alias-free: G = S*flow_cont is what the image
+  warp and RefineFlow see, the level's ``flow_cont`` output is S*G, and the refined flow is scaled once;
+* every tensor operation is a kernel of libirr_hip.so (cost volume, warp+mask, bilinear / nearest
+  resize, MFMA convs, bilateral refinement tail).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from .modules import (ContextNetwork, FeatureExtractor, FlowEstimatorDense, OccContextNetwork, OccEstimatorDense,
+                      OccUpsampleNetwork, RefineFlow, RefineOcc, WarpingLayer, conv, initialize_msra)
+
+
+def _swap_halves(t: torch.Tensor) -> torch.Tensor:
+    b = t.shape[0] // 2
+    return torch.cat([t[b:], t[:b]], dim=0)
+
+
+class PWCNet(nn.Module):
+    def __init__(self, args, div_flow=0.05, mask_threshold: float = 1.0):
+        super().__init__()
+        self.args = args
+        self._div_flow = div_flow
+        self.search_range = 4
+        self.num_chs = [3, 16, 32, 64, 96, 128, 196]
+        self.output_level = 4
+        self.num_levels = 7
+        self.leakyRELU = nn.LeakyReLU(0.1, inplace=True)
+
+        self.feature_pyramid_extractor = FeatureExtractor(self.num_chs)
+        self.warping_layer = WarpingLayer(mask_threshold)
+
+        self.dim_corr = (self.search_range * 2 + 1) ** 2
+        self.num_ch_in_flo = self.dim_corr + 32 + 2
+        self.num_ch_in_occ = self.dim_corr + 32 + 1
+
+        self.flow_estimators = FlowEstimatorDense(self.num_ch_in_flo)
+        self.context_networks = ContextNetwork(self.num_ch_in_flo + 448 + 2)
+        self.occ_estimators = OccEstimatorDense(self.num_ch_in_occ)
+        self.occ_context_networks = OccContextNetwork(self.num_ch_in_occ + 448 + 1)
+        self.occ_shuffle_upsample = OccUpsampleNetwork(11, 1)
+
+        self.conv_1x1 = nn.ModuleList([conv(196, 32, kernel_size=1, stride=1, dilation=1),
+                                       conv(128, 32, kernel_size=1, stride=1, dilation=1),
+                                       conv(96, 32, kernel_size=1, stride=1, dilation=1),
+                                       conv(64, 32, kernel_size=1, stride=1, dilation=1)])
+        self.conv_1x1_1 = conv(16, 3, kernel_size=1, stride=1, dilation=1)
+
+        self.refine_flow = RefineFlow(2 + 1 + 32)
+        self.refine_occ = RefineOcc(1 + 32 + 32)
+        self.corr_params = {"pad_size": self.search_range, "kernel_size": 1, "max_disp": self.search_range,
+                            "stride1": 1, "stride2": 1, "corr_multiply": 1}
+        initialize_msra(self.modules())
+
+    # the validity-mask threshold of WarpingLayer: 1.0 = reference as-is, 0.9999 = robust parity mode
+    @property
+    def mask_threshold(self) -> float:
+        return self.warping_layer.mask_threshold
+
+    @mask_threshold.setter
+    def mask_threshold(self, v: float) -> None:
+        self.warping_layer.mask_threshold = float(v)
+
+    def forward(self, input_dict):
+        x1_raw, x2_raw = input_dict['input1'], input_dict['input2']
+        B, _, H, W = x1_raw.shape
+        if H % 64 or W % 64:
+            raise ValueError("IRR-PWC needs height and width that are multiples of 64")
+        div = self._div_flow
+        dev = x1_raw.device
+
+        raw = torch.cat([x1_raw, x2_raw], dim=0)                 # [x1; x2]   (2B)
+        raw_o = _swap_halves(raw)                                # [x2; x1]
+        pyr = self.feature_pyramid_extractor(raw) + [raw]        # coarsest first; both images in one pass
+
+        def warp(x, fl):
+            return self.warping_layer(x, fl, H, W, div)
+
+        h0, w0 = pyr[0].shape[2:]
+        flow = torch.zeros(2 * B, 2, h0, w0, device=dev)          # [flow_f; flow_b]
+        occ = torch.zeros(2 * B, 1, h0, w0, device=dev)           # [occ_f ; occ_b ]
+        flows, occs = [], []
+
+        for l, x in enumerate(pyr):
+            h, w = x.shape[2:]
+            xo = _swap_halves(x)                                  # the other image's features
+            if l <= self.output_level:
+                if l == 0:
+                    xo_warp = xo
+                else:
+                    flow = Fn.resize_bilinear_ac(flow, h, w)
+                    occ = Fn.resize_bilinear_ac(occ, h, w)
+                    xo_warp = warp(xo, flow)
+                corr = Fn.cost_volume(x, xo_warp, lrelu=True)     # cost volume + LeakyReLU fused
+
+                x_1by1 = self.conv_1x1[l](x) if l != self.output_level else x
+
+                s_loc = (float(w / W / div), float(h / H / div))      # to_local  (pwc_modules.py:72-73)
+                s_glb = (float(W * div / w), float(H * div / h))      # to_global (pwc_modules.py:75-76)
+                t_loc = flow.new_tensor(s_loc).view(1, 2, 1, 1)
+                t_glb = flow.new_tensor(s_glb).view(1, 2, 1, 1)
+                flow = flow * t_loc
+
+                x_intm, flow_res = self.flow_estimators(torch.cat([corr, x_1by1, flow], dim=1))
+                flow_est = flow + flow_res
+                flow_cont = self.context_networks(torch.cat([x_intm, flow_est], dim=1), res=flow_est)
+
+                x_intm_o, occ_res = self.occ_estimators(torch.cat([corr, x_1by1, occ], dim=1))
+                occ_est = occ + occ_res
+                occ_cont = self.occ_context_networks(torch.cat([x_intm_o, occ_est], dim=1), res=occ_est)
+
+                # refinement (models/IRR_PWC.py:126-138, alias-free)
+                img = Fn.resize_bilinear_ac(raw, h, w)
+                img_o = _swap_halves(img)
+                G = flow_cont * t_glb
+                img_o_warp = warp(img_o, G)
+                flow = self.refine_flow(G.detach(), img - img_o_warp, x_1by1, scale=s_glb)   # incl. to_global
+                flow_cont = G * t_glb
+
+                x_1by1_o_warp = warp(_swap_halves(x_1by1), flow)
+                occ = self.refine_occ(occ_cont.detach(), x_1by1, x_1by1 - x_1by1_o_warp)
+
+                flows.append([flow_cont[:B], flow_cont[B:], flow[:B], flow[B:]])
+                occs.append([occ_cont[:B], occ_cont[B:], occ[:B], occ[B:]])
+            else:
+                flow = Fn.resize_bilinear_ac(flow, h, w)
+                flows.append([flow[:B], flow[B:]])
+                xo_warp = warp(xo, flow)
+                flow_o_warp = warp(_swap_halves(flow), flow)
+                if l != self.num_levels - 1:
+                    # conv_1x1_1 on x and on the warped other image: one launch over the 4B batch
+                    both = self.conv_1x1_1(torch.cat([x, xo_warp], dim=0))
+                    x_in, xo_w_in = both[:2 * B], both[2 * B:]
+                else:
+                    x_in, xo_w_in = x, xo_warp
+                occ = self.occ_shuffle_upsample(occ, torch.cat([x_in, xo_w_in, flow, flow_o_warp], dim=1))
+                occs.append([occ[:B], occ[B:]])
+
+        if self.training:
+            return {'flow': flows, 'occ': occs}
+        out_flow = Fn.resize_bilinear_ac(flow[:B], H, W, alpha=1.0 / div)
+        out_occ = Fn.resize_bilinear_ac(occ[:B], H, W)
+        return {'flow': out_flow, 'occ': out_occ}

@@ -1,0 +1,69 @@
+"""One optimisation step of IRR-PWC -- the build's counterpart of the reference's
+``TrainingEpoch._step`` (runtime.py:131-194) + ``ModelAndLoss.forward`` (configuration.py:45-62) with
+Adam(lr=1e-4, weight_decay=4e-4) (scripts/IRR-PWC_flyingChairsOcc.sh:29-31):
+
+    zero_grad -> forward -> loss -> NaN assert -> backward -> [grad all-reduce] -> optimizer.step
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+
+class ModelAndLoss(nn.Module):
+    """configuration.py:20-62: chains model -> loss, owns the ``_model.*`` state_dict namespace."""
+
+    def __init__(self, args, model, training_loss, evaluation_loss=None):
+        super().__init__()
+        self._model = model
+        self._training_loss = training_loss
+        self._evaluation_loss = evaluation_loss if evaluation_loss is not None else training_loss
+
+    @property
+    def model(self):
+        return self._model
+
+    @property
+    def training_loss(self):
+        return self._training_loss
+
+    def forward(self, example_dict):
+        output_dict = self._model(example_dict)
+        loss = self._training_loss if self.training else self._evaluation_loss
+        return loss(output_dict, example_dict), output_dict
+
+
+class TrainStep:
+    """Holds model+loss+optimizer and runs reference-equivalent steps on device-resident batches."""
+
+    def __init__(self, model_and_loss: ModelAndLoss, optimizer: torch.optim.Optimizer, training_key: str = "total_loss",
+                 grad_sync=None, check_nan: bool = True):
+        self.model_and_loss = model_and_loss
+        self.optimizer = optimizer
+        self.training_key = training_key
+        self.grad_sync = grad_sync              # callable() run between backward and optimizer.step (data parallel)
+        self.check_nan = check_nan
+
+    def __call__(self, example_dict: Dict[str, torch.Tensor]):
+        for key, t in example_dict.items():      # runtime.py:158-162
+            if "input" in key:
+                t.requires_grad_(True)
+            elif "target" in key:
+                t.requires_grad_(False)
+        self.optimizer.zero_grad()
+        loss_dict, output_dict = self.model_and_loss(example_dict)
+        training_loss = loss_dict[self.training_key]
+        if self.check_nan:                        # runtime.py:182-183 (device->host sync, as in the reference)
+            assert not math.isnan(training_loss.item()), "training_loss is NaN"
+        training_loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync()
+        self.optimizer.step()
+        return loss_dict, output_dict, example_dict["input1"].shape[0]
+
+
+def make_adam(params, lr: float = 1e-4, weight_decay: float = 4e-4) -> torch.optim.Optimizer:
+    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)
