@@ -36,31 +36,25 @@ def out_hw(h: int, w: int, k: int, stride: int, dil: int) -> Tuple[int, int]:
 # ----------------------------------------------------------------------------------------------
 # packed-weight cache: weights are re-packed only when the parameter changed (optimizer step)
 # ----------------------------------------------------------------------------------------------
-_PACK_CACHE = {}
-
-
 def packed_weights(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
+    """Packed copy of ``weight`` for irr_conv2d_fwd_f32, cached ON the tensor object (so it dies with the
+    parameter and can never be confused with another tensor that later reuses the same address) and
+    refreshed whenever the parameter's storage or version counter changes (optimizer step, load_state_dict)."""
+    cache = weight.__dict__.setdefault("_irr_packed", {})
     w = weight.detach()
-    key = (w.data_ptr(), bool(transpose))
-    ver = w._version
-    hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == ver and hit[2] == tuple(w.shape):
+    tag = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = cache.get(bool(transpose))
+    if hit is not None and hit[0] == tag:
         return hit[1]
     cout, cin, k, _ = w.shape
-    if transpose:
-        lcin, lcout = cout, cin
-    else:
-        lcin, lcout = cin, cout
+    lcin, lcout = (cout, cin) if transpose else (cin, cout)
     n = hip.lib().irr_conv_packed_weight_elems(lcin, lcout, k)
-    wp = hit[1] if (hit is not None and hit[1].numel() == n) else torch.empty(n, device=w.device, dtype=torch.float32)
+    wp = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == w.device) else \
+        torch.empty(n, device=w.device, dtype=torch.float32)
     wc = w.contiguous()
     hip.call("irr_conv_pack_weights_f32", hip.ptr(wc), hip.ptr(wp), lcin, lcout, k, int(transpose), hip.stream())
-    _PACK_CACHE[key] = (ver, wp, tuple(w.shape))
+    cache[bool(transpose)] = (tag, wp)
     return wp
-
-
-def clear_pack_cache() -> None:
-    _PACK_CACHE.clear()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -176,6 +170,7 @@ class _ConvBlock(torch.autograd.Function):
         ctx.cfg = (stride, dil, lrelu, alpha, res is not None)
         ctx.save_for_backward(x, weight, act if lrelu else None)
         ctx.has_bias = bias is not None
+        ctx.weight_obj = weight            # the Parameter object that carries the packed-weight cache
         return y
 
     @staticmethod
@@ -192,7 +187,7 @@ class _ConvBlock(torch.autograd.Function):
             lrelu_bwd_bias(g, act, lrelu, gpre, gb)
             if lrelu:
                 g = gpre
-        gx = conv_dgrad(g, weight, stride, dil, x.shape[2:]) if ctx.needs_input_grad[0] else None
+        gx = conv_dgrad(g, ctx.weight_obj, stride, dil, x.shape[2:]) if ctx.needs_input_grad[0] else None
         gw = conv_wgrad(x, g, weight.shape, stride, dil) if ctx.needs_input_grad[1] else None
         return gx, gw, gb, None, None, None, gres, None
 
