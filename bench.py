@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- IRR-PWC train-step throughput on MI355X (BASELINE.json metric: image-pairs/sec fwd+bwd).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one synthetic batch: zero_grad -> PWCNet forward (train mode) ->
+MultiScaleEPE_PWC_Bi_Occ_upsample -> NaN check -> backward -> [RCCL gradient all-reduce] -> Adam step,
+i.e. the reference's TrainingEpoch._step (runtime.py:131-194) with inputs already resident in HBM.
+Workload = BASELINE configs[2] (384x448, 32 pairs per GPU, FlyingChairsOcc-shaped synthetic tensors,
+weak scaling: every rank gets its own 32 pairs).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+CONV_GFLOP_PER_PAIR = {(384, 448): 1088.4, (448, 1024): 2902.5}   # 3x forward conv FLOPs
+
+
+def synthetic_batch(batch, height, width, seed, device):
+    """inputs U[0,1), targets 5*N(0,1) px, occlusion Bernoulli(0.2); CPU generator, then copied."""
+    g = torch.Generator().manual_seed(seed)
+    b = {"input1": torch.rand(batch, 3, height, width, generator=g),
+         "input2": torch.rand(batch, 3, height, width, generator=g),
+         "target1": 5 * torch.randn(batch, 2, height, width, generator=g),
+         "target2": 5 * torch.randn(batch, 2, height, width, generator=g),
+         "target_occ1": (torch.rand(batch, 1, height, width, generator=g) < 0.2).float(),
+         "target_occ2": (torch.rand(batch, 1, height, width, generator=g) < 0.2).float()}
+    return {k: v.to(device) for k, v in b.items()}
+
+
+def cpu_baseline(height, width, budget_s=20.0):
+    """The oracle's train step (CPU restatement of the reference path, kind="port") timed on the host cores of
+    the GPU box, bounded sample: B=2 pairs per step, 1 warm-up + as many timed steps as fit in the budget."""
+    from oracle import irr_pwc_oracle as O
+    threads = torch.get_num_threads()
+    B = 2
+    P = O.make_trainable(O.synthetic_params(0))
+    opt = O.make_adam(P)
+    batch = O.synthetic_batch(B, height, width, 1234)
+    O.train_step(P, opt, batch)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        O.train_step(P, opt, batch)
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 8:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return {"value": B / dt, "unit": "image-pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{n} timed steps (+1 warm-up) of the oracle train step (fwd+loss+bwd+Adam), batch {B}, "
+                      f"{height}x{width}, {threads} torch threads on the GPU host"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU")
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--width", type=int, default=448)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import irr_amd
+    from irr_amd import conv as C
+    from irr_amd import ddp
+    from irr_amd.train import ModelAndLoss, TrainStep
+    from irr_amd.optim import FusedAdam
+
+    args = types.SimpleNamespace(batch_size=a.batch, model_div_flow=0.05)
+    torch.manual_seed(0)                                     # same MSRA init on every rank
+    model = irr_amd.PWCNet(args).to(device).train()
+    ddp.broadcast_params(model)
+    loss = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(args, reduce_fn=ddp.reduce_losses() if world > 1 else None).train()
+    mal = ModelAndLoss(args, model, loss).train()
+    arena = ddp.GradArena(model.named_parameters())
+    opt = FusedAdam(model, arena, lr=1e-4, weight_decay=4e-4)
+    step = TrainStep(mal, opt, grad_sync=arena.sync)
+    batch = synthetic_batch(a.batch, a.height, a.width, 1234 + rank, device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(batch)
+    timer = None
+    if not a.no_kernel_timer:
+        timer = C.KernelTimer()
+        C.TIMER = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ld, _, _ = step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    C.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    pairs = a.batch * world * a.steps
+    value = pairs / dt
+
+    roof = None
+    if timer is not None:
+        summ = timer.summary()
+        if summ:
+            var, st = max(summ.items(), key=lambda kv: kv[1]["seconds"])
+            ach = st["flops"] / st["seconds"] / 1e12
+            tot_f = sum(s["flops"] for s in summ.values())
+            tot_s = sum(s["seconds"] for s in summ.values())
+            roof = {"bound": "mfma", "kernel": f"conv_fwd_kernel<{var // 100},{(var // 10) % 10},{var % 10}>",
+                    "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": st["calls"], "avg_launch_us": round(st["seconds"] / st["calls"] * 1e6, 2),
+                    "flop_per_launch": st["flops"] / st["calls"],
+                    "all_conv_fwd_dgrad": {"achieved": round(tot_f / tot_s / 1e12, 2), "seconds_per_step": round(tot_s / a.steps, 5),
+                                           "flops_per_step": tot_f / a.steps}}
+    if rank == 0:
+        gf = CONV_GFLOP_PER_PAIR.get((a.height, a.width))
+        out = {"metric": "image-pairs/sec fwd+bwd IRR-PWC 384x448 bs32", "value": round(value, 3), "unit": "image-pairs/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"BASELINE configs[2]: IRR_PWC train step (fwd + MultiScaleEPE_PWC_Bi_Occ_upsample + "
+                                      f"bwd + Adam), FlyingChairsOcc-shaped synthetic {a.height}x{a.width}, {a.batch} pairs per GPU",
+                          "pairs_per_gpu": a.batch, "global_batch": a.batch * world, "height": a.height, "width": a.width,
+                          "parallelism": f"dp{world}", "weights": "MSRA init, torch.manual_seed(0)"},
+               "loss": {k: float(v.detach()) for k, v in ld.items()},
+               "step_mfma_frac": round(value / world * gf * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4) if gf else None,
+               "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.height, a.width)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,6 +109,10 @@ int irr_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, const
                        long x_bs, long y_bs, long res_bs,
                        int lrelu, float alpha, int accumulate, void* stream);
 
+/* Which template instantiation irr_conv2d_fwd_f32 launches for this problem, as MT*100 + NT*10 + k
+ * (conv_fwd_kernel<MT,NT,k>); used to label bench.py's roofline line and to find the kernel in rocprof output. */
+int irr_conv2d_fwd_variant(int B, int Cout, int OH, int OW, int k);
+
 /* dW[co][ci][tap] (+)= sum_{b,y,x} gy[b,co,y,x] * x[b,ci,y*stride+(ty-pad), x*stride+(tx-pad)]
  * gw is the plain (Cout,Cin,k,k) tensor and is ACCUMULATED into with atomics (caller zeroes it). */
 int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw,
@@ -148,6 +152,16 @@ int irr_upsample_nearest2x_fwd_f32(const float* x, float* out, int B, int C, int
                                    long x_bs, long out_bs, void* stream);
 int irr_upsample_nearest2x_bwd_f32(const float* gout, float* gx, int B, int C, int H, int W,
                                    long gout_bs, long gx_bs, void* stream);
+
+/* ---- fused Adam over one flat arena ------------------------------------------------------------------
+ * torch.optim.Adam semantics (runtime.py:189; lr 1e-4, weight_decay 4e-4 as L2-in-gradient,
+ * scripts/IRR-PWC_flyingChairsOcc.sh:29-31) over n contiguous fp32 elements (16-byte aligned pointers):
+ *   g = grad*grad_scale + wd*p ; m = lerp(m, g, 1-b1) ; v = b2*v + (1-b2)*g*g ;
+ *   p -= (lr/bias_corr1) * m / (sqrt(v)/sqrt(bias_corr2) + eps)          bias_corr_i = 1 - beta_i^t
+ */
+int irr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay,
+                      float bias_corr1, float bias_corr2, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,36 @@ from . import hip
 BACKEND = os.environ.get("IRR_CONV_BACKEND", "hip")
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing of the MFMA conv kernel (bench.py's ``roofline`` object).
+    Events are recorded on the launch stream right around the C-ABI call; nothing synchronises until
+    ``summary()``.  Keyed by template instantiation (``conv_fwd_kernel<MT,NT,k>``)."""
+
+    def __init__(self):
+        self.records = []          # (variant code, flops, start event, stop event)
+
+    def wrap(self, variant: int, flops: float, launch):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        launch()
+        e.record()
+        self.records.append((variant, flops, s, e))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for variant, flops, s, e in self.records:
+            a = agg.setdefault(variant, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += s.elapsed_time(e) * 1e-3
+        self.records.clear()
+        return {v: {"calls": a[0], "flops": a[1], "seconds": a[2]} for v, a in agg.items()}
+
+
+TIMER: Optional[KernelTimer] = None
+
+
 def set_backend(name: str) -> None:
     global BACKEND
     if name not in ("hip", "miopen"):
@@ -36,13 +66,17 @@ def out_hw(h: int, w: int, k: int, stride: int, dil: int) -> Tuple[int, int]:
 # ----------------------------------------------------------------------------------------------
 # packed-weight cache: weights are re-packed only when the parameter changed (optimizer step)
 # ----------------------------------------------------------------------------------------------
+# bumped by anything that rewrites parameters outside autograd's version counters (FusedAdam.step)
+WEIGHT_EPOCH = [0]
+
+
 def packed_weights(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
     """Packed copy of ``weight`` for irr_conv2d_fwd_f32, cached ON the tensor object (so it dies with the
     parameter and can never be confused with another tensor that later reuses the same address) and
     refreshed whenever the parameter's storage or version counter changes (optimizer step, load_state_dict)."""
     cache = weight.__dict__.setdefault("_irr_packed", {})
     w = weight.detach()
-    tag = (w.data_ptr(), w._version, tuple(w.shape))
+    tag = (w.data_ptr(), w._version, tuple(w.shape), WEIGHT_EPOCH[0])
     hit = cache.get(bool(transpose))
     if hit is not None and hit[0] == tag:
         return hit[1]
@@ -83,10 +117,15 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
             out.copy_(v)
         return out
     wp = packed_weights(weight, False)
-    hip.call("irr_conv2d_fwd_f32", hip.ptr(x), hip.ptr(wp), hip.ptr(bias.detach() if bias is not None else None),
-             hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, oh, ow, k, stride, dil,
-             hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
-             int(lrelu), float(alpha), int(accumulate), hip.stream())
+    args = ("irr_conv2d_fwd_f32", hip.ptr(x), hip.ptr(wp), hip.ptr(bias.detach() if bias is not None else None),
+            hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, oh, ow, k, stride, dil,
+            hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
+            int(lrelu), float(alpha), int(accumulate), hip.stream())
+    if TIMER is None:
+        hip.call(*args)
+    else:
+        TIMER.wrap(hip.lib().irr_conv2d_fwd_variant(B, cout, oh, ow, k), 2.0 * B * oh * ow * cout * cin * k * k,
+                   lambda: hip.call(*args))
     return out
 
 
@@ -110,8 +149,13 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         return gx
     if stride == 1 and cout >= 2:
         wp = packed_weights(weight, True)
-        hip.call("irr_conv2d_fwd_f32", hip.ptr(gy), hip.ptr(wp), None, None, hip.ptr(gx), B, cout, oh, ow, cin, H, W,
-                 k, 1, dil, hip.bs(gy), hip.bs(gx), 0, 0, 1.0, int(accumulate), hip.stream())
+        args = ("irr_conv2d_fwd_f32", hip.ptr(gy), hip.ptr(wp), None, None, hip.ptr(gx), B, cout, oh, ow, cin, H, W,
+                k, 1, dil, hip.bs(gy), hip.bs(gx), 0, 0, 1.0, int(accumulate), hip.stream())
+        if TIMER is None:
+            hip.call(*args)
+        else:
+            TIMER.wrap(hip.lib().irr_conv2d_fwd_variant(B, cin, H, W, k), 2.0 * B * H * W * cout * cin * k * k,
+                       lambda: hip.call(*args))
     else:
         tmp = gx if not accumulate else torch.empty(B, cin, H, W, device=gy.device, dtype=torch.float32)
         wc = weight.detach().contiguous()

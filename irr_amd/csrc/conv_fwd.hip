@@ -199,23 +199,40 @@ int launch(const ConvArgs& a, hipStream_t st) {
   return e == hipSuccess ? 0 : (int)e;
 }
 
+// (MT, NT) tiling choice, shared by the launcher and by irr_conv2d_fwd_variant (bench / profile labelling)
+static void pick_variant(int cot, long total, int* mt, int* nt) {
+  const long ptiles = (total + 31) / 32;
+  if (ptiles * cot < 4096) {            // small problems: favour many waves over register blocking
+    if (cot >= 2 && ptiles * ((cot + 1) / 2) >= 1024) { *mt = 2; *nt = 1; return; }
+    *mt = 1; *nt = 1; return;
+  }
+  if (cot == 1) { *mt = 1; *nt = 4; return; }
+  if (cot == 2) { *mt = 2; *nt = 4; return; }
+  if (cot == 3) { *mt = 3; *nt = 2; return; }
+  *mt = 4; *nt = 2;
+}
+
 template <int KS>
 int dispatch(const ConvArgs& a, hipStream_t st) {
-  const int cot = a.CoP / 32;
-  const long total = (long)a.B * a.OH * a.OW;
-  const long ptiles = (total + 31) / 32;
-  // small problems: favour many waves over register blocking
-  if (ptiles * cot < 4096) {
-    if (cot >= 2 && ptiles * ((cot + 1) / 2) >= 1024) return launch<2, 1, KS>(a, st);
-    return launch<1, 1, KS>(a, st);
+  int mt, nt;
+  pick_variant(a.CoP / 32, (long)a.B * a.OH * a.OW, &mt, &nt);
+  switch (mt * 10 + nt) {
+    case 11: return launch<1, 1, KS>(a, st);
+    case 21: return launch<2, 1, KS>(a, st);
+    case 14: return launch<1, 4, KS>(a, st);
+    case 24: return launch<2, 4, KS>(a, st);
+    case 32: return launch<3, 2, KS>(a, st);
+    default: return launch<4, 2, KS>(a, st);
   }
-  if (cot == 1) return launch<1, 4, KS>(a, st);
-  if (cot == 2) return launch<2, 4, KS>(a, st);
-  if (cot == 3) return launch<3, 2, KS>(a, st);
-  return launch<4, 2, KS>(a, st);
 }
 
 }  // namespace
+
+extern "C" int irr_conv2d_fwd_variant(int B, int Cout, int OH, int OW, int k) {
+  int mt, nt;
+  pick_variant((Cout + 31) / 32, (long)B * OH * OW, &mt, &nt);
+  return mt * 100 + nt * 10 + k;
+}
 
 extern "C" long irr_conv_packed_weight_elems(int Cin, int Cout, int k) {
   const long CoP = (Cout + 31) / 32 * 32;
