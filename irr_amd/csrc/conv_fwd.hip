@@ -166,6 +166,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
                                     int CoP, int transpose, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (i >= n - 4 * 32) { wp[i] = 0.f; return; }       // tail slack
   const int co = (int)(i % CoP);
   long r = i / CoP;
   const int half = (int)(r & 1);
@@ -236,7 +237,9 @@ extern "C" int irr_conv2d_fwd_variant(int B, int Cout, int OH, int OW, int k) {
 
 extern "C" long irr_conv_packed_weight_elems(int Cin, int Cout, int k) {
   const long CoP = (Cout + 31) / 32 * 32;
-  return (long)((Cin + 1) / 2) * k * k * 2 * CoP;
+  // + slack: a wave that owns MT co-tiles may read up to 3 tiles past CoP in the LAST row (rows past Cout are
+  // discarded in the epilogue, but the addresses must stay inside the allocation)
+  return (long)((Cin + 1) / 2) * k * k * 2 * CoP + 4 * 32;
 }
 
 extern "C" int irr_conv_pack_weights_f32(const float* w, float* wp, int Cin, int Cout, int k, int transpose,
