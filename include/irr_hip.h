@@ -113,9 +113,11 @@ int irr_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, const
  * (conv_fwd_kernel<MT,NT,k>); used to label bench.py's roofline line and to find the kernel in rocprof output. */
 int irr_conv2d_fwd_variant(int B, int Cout, int OH, int OW, int k);
 
-/* dW[co][ci][tap] (+)= sum_{b,y,x} gy[b,co,y,x] * x[b,ci,y*stride+(ty-pad), x*stride+(tx-pad)]
- * gw is the plain (Cout,Cin,k,k) tensor and is ACCUMULATED into with atomics (caller zeroes it). */
-int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw,
+/* dW[co][ci][tap] += sum_{b,y,x} gy[b,co,y,x] * x[b,ci,y*stride+(ty-pad), x*stride+(tx-pad)]
+ * gw is the plain (Cout,Cin,k,k) tensor and is ACCUMULATED into (caller zeroes it when it wants "=").
+ * ws: caller-owned scratch of Cout*Cin*k*k floats (split-K partials land there with coalesced atomics in
+ * [co][tap][ci] order and are then added to gw). */
+int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws,
                          int B, int Cin, int H, int W, int Cout, int OH, int OW,
                          int k, int stride, int dil, long x_bs, long gy_bs, void* stream);
 

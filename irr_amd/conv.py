@@ -179,7 +179,8 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
                                           padding=((k - 1) * dil) // 2, dilation=dil)
         return gw
     assert gw.is_contiguous()
-    hip.call("irr_conv2d_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), B, cin, H, W, cout, oh, ow, k, stride, dil,
+    ws = torch.empty(cout * cin * k * k, device=x.device, dtype=torch.float32)
+    hip.call("irr_conv2d_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), B, cin, H, W, cout, oh, ow, k, stride, dil,
              hip.bs(x), hip.bs(gy), hip.stream())
     return gw
 

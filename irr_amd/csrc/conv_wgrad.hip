@@ -7,9 +7,12 @@
 // channel row), written as [channel][pixel] with an odd row pitch (33), and read back with lanes along the
 // channel axis (stride 33 words -> conflict-free ds_read_b32).  One 32-pixel stage feeds 16 MFMA k-steps.
 //
-// Work split: a block owns MTB co-tiles x NTB ci-tiles (one wave per (co-tile, ci-tile) pair, all 9 taps:
-// 9 accumulator tiles = 144 VGPRs) and a contiguous slice of the pixel range (split-K); partial results are
-// added to dW with fp32 atomics (dW is shared by every pyramid level and both flow directions anyway).
+// Work split: a block owns MTB co-tiles x ONE ci-tile and a contiguous slice of the pixel range (split-K).
+// Wave (m, ty) accumulates co-tile m against the three taps of kernel row ty (3 accumulator tiles = 48
+// VGPRs), so a block has 3*MTB waves that share one staged x tile (9 tap-shifted copies of 32 channels) and
+// MTB gy tiles.  The next stage is prefetched into VGPRs (one full stage in flight per block), its loads
+// interleaved with the MFMAs of the current stage.  Split-K partials are added with COALESCED fp32 atomics
+// into a [co][tap][ci] workspace (lanes = ci are contiguous) and then folded into dW[co][ci][tap].
 #include "common.h"
 
 namespace {
@@ -22,28 +25,28 @@ constexpr int PITCH = KP + 1;
 struct WgArgs {
   const float* x;
   const float* gy;
-  float* gw;
+  float* gw;                    // workspace, [Cout][KK][Cin]
   int B, Cin, H, W, Cout, OH, OW;
   int stride, dil, pad;
   long x_bs, gy_bs;
   int chunks_per_block;
 };
 
-template <int MTB, int NTB, int KS>
-__global__ __launch_bounds__(MTB* NTB * 64, 2) void conv_wgrad_kernel(const WgArgs a) {
+template <int MTB, int KS>
+__global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a) {
   constexpr int KK = KS * KS;
-  constexpr int NW = MTB * NTB;
-  constexpr int NT = NW * 64;
-  constexpr int AROWS = MTB * 32, BROWS = NTB * 32;
-  __shared__ float As[AROWS][PITCH];
-  __shared__ float Bs[KK][BROWS][PITCH];
+  constexpr int NW = MTB * KS;                 // waves: (co-tile m, kernel row ty)
+  constexpr int AROWS = MTB * 32, BROWS = KK * 32, ROWS = AROWS + BROWS;
+  constexpr int RGN = 2 * NW;                  // row groups: every half-wave stages one row per round
+  constexpr int NR = (ROWS + RGN - 1) / RGN;   // staged values per lane per stage
+  __shared__ float S[ROWS][PITCH];             // rows [0,AROWS): gy tiles; then tap-major x tiles
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / NTB, wn = wave - wm * NTB;
+  const int wm = wave / KS, ty_w = wave - wm * KS;
   const int j = lane & 31, half = lane >> 5;
-  const int co0 = blockIdx.z * AROWS, ci0 = blockIdx.y * BROWS;
+  const int co0 = blockIdx.z * AROWS, ci0 = blockIdx.y * 32;
   const long ohw = (long)a.OH * a.OW;
   const long hw = (long)a.H * a.W;
   const long total = (long)a.B * ohw;
@@ -51,86 +54,139 @@ __global__ __launch_bounds__(MTB* NTB * 64, 2) void conv_wgrad_kernel(const WgAr
   const long c_begin = (long)blockIdx.x * a.chunks_per_block;
   const long c_end = min(nchunks, c_begin + a.chunks_per_block);
 
-  f32x16 acc[KK];
+  f32x16 acc[KS];
 #pragma unroll
-  for (int t = 0; t < KK; ++t)
+  for (int t = 0; t < KS; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // staging role of this thread: pixel column `px` of the stage, rows rg, rg+RG, ...
+  // staging role: pixel column px of the stage, rows rg, rg+RGN, ...
   const int px = tid & (KP - 1);
-  const int rg = tid / KP;
-  constexpr int RG = NT / KP;
+  const int rg = tid >> 5;
 
-  for (long c = c_begin; c < c_end; ++c) {
+  float stg[NR];
+  // per-stage pixel decode of this lane's staging column
+  const float* gb = nullptr;
+  const float* xb = nullptr;
+  int iy0 = 0, ix0 = 0;
+  bool pv = false;
+  auto decode = [&](long c) {
     const long p = c * KP + px;
-    const bool pv = p < total;
+    pv = p < total;
     const long pp = pv ? p : total - 1;
     const int b = (int)(pp / ohw);
     const int r = (int)(pp - (long)b * ohw);
     const int oy = r / a.OW, ox = r - oy * a.OW;
-    __syncthreads();                         // previous stage fully consumed
-    {
-      const float* g = a.gy + (long)b * a.gy_bs + r;
-#pragma unroll 4
-      for (int row = rg; row < AROWS; row += RG) {
-        const int co = co0 + row;
-        As[row][px] = (pv && co < a.Cout) ? g[(long)co * ohw] : 0.f;
-      }
+    gb = a.gy + (long)b * a.gy_bs + r;
+    xb = a.x + (long)b * a.x_bs;
+    iy0 = oy * a.stride - a.pad;
+    ix0 = ox * a.stride - a.pad;
+  };
+  // issue the global load of staged value i (row rg + i*RGN of the next stage)
+  auto issue1 = [&](int i) {
+    const int row = rg + i * RGN;
+    float v = 0.f;
+    if (row < AROWS) {
+      const int co = co0 + row;
+      const bool ok = pv && co < a.Cout;
+      const float t = gb[(long)(ok ? co : 0) * ohw];
+      v = ok ? t : 0.f;
+    } else if (row < ROWS) {
+      const int q = row - AROWS;
+      const int tap = q >> 5, ci = ci0 + (q & 31);
+      const int ty = (KS == 3) ? (tap * 11) >> 5 : 0;       // tap / 3 for tap in [0, 9)
+      const int tx = tap - ty * KS;
+      const int iy = iy0 + ty * a.dil, ix = ix0 + tx * a.dil;
+      const bool ok = pv && ci < a.Cin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float t = xb[ok ? ((long)ci * hw + (long)iy * a.W + ix) : 0];
+      v = ok ? t : 0.f;
     }
+    stg[i] = v;
+  };
+
+  if (c_begin < c_end) {
+    decode(c_begin);
 #pragma unroll
-    for (int t = 0; t < KK; ++t) {
-      const int ty = t / KS, tx = t - ty * KS;
-      const int iy = oy * a.stride - a.pad + ty * a.dil;
-      const int ix = ox * a.stride - a.pad + tx * a.dil;
-      const bool ok = pv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const float* xs = a.x + (long)b * a.x_bs + (long)(ok ? iy : 0) * a.W + (ok ? ix : 0);
-#pragma unroll 4
-      for (int row = rg; row < BROWS; row += RG) {
-        const int ci = ci0 + row;
-        Bs[t][row][px] = (ok && ci < a.Cin) ? xs[(long)ci * hw] : 0.f;
-      }
+    for (int i = 0; i < NR; ++i) issue1(i);
+  }
+  constexpr int KSTEPS = KP / 2;
+  constexpr int PER = (NR + KSTEPS - 1) / KSTEPS;      // prefetch loads interleaved per k-step
+  for (long c = c_begin; c < c_end; ++c) {
+    __syncthreads();                           // previous stage fully consumed
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int row = rg + i * RGN;
+      if (row < ROWS) S[row][px] = stg[i];
     }
     __syncthreads();
-    const float* arow = &As[wm * 32 + j][half];
-#pragma unroll 4
-    for (int k = 0; k < KP / 2; ++k) {
-      const float av = arow[2 * k];
+    const bool more = c + 1 < c_end;           // block-uniform
+    if (more) decode(c + 1);
+    const float* arow = &S[wm * 32 + j][half];
+    const float* brow = &S[AROWS + (ty_w * KS) * 32 + j][half];
 #pragma unroll
-      for (int t = 0; t < KK; ++t) {
-        const float bv = Bs[t][wn * 32 + j][2 * k + half];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+    for (int k = 0; k < KSTEPS; ++k) {
+      const float av = arow[2 * k];
+      float bv[KS];
+#pragma unroll
+      for (int t = 0; t < KS; ++t) bv[t] = brow[t * 32 * PITCH + 2 * k];
+      if (more) {                              // next stage's loads ride along with the MFMAs
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+          if (k * PER + u < NR) issue1(k * PER + u);
       }
+#pragma unroll
+      for (int t = 0; t < KS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
     }
   }
 
   // D[i][jj]: i = co_local = (r&3) + 8*(r>>2) + 4*half, jj = ci_local = lane&31
-  const int ci = ci0 + wn * 32 + j;
+  const int ci = ci0 + j;
   if (ci < a.Cin) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (co >= a.Cout) continue;
-      float* dst = a.gw + ((long)co * a.Cin + ci) * KK;
+      // workspace layout [co][tap][ci]: lanes (ci) are contiguous -> one cache line per half-wave atomic
+      float* dst = a.gw + ((long)co * KK + ty_w * KS) * a.Cin + ci;
 #pragma unroll
-      for (int t = 0; t < KK; ++t) unsafeAtomicAdd(dst + t, acc[t][r]);
+      for (int t = 0; t < KS; ++t) unsafeAtomicAdd(dst + (long)t * a.Cin, acc[t][r]);
     }
   }
 }
 
-template <int MTB, int NTB, int KS>
+static int cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int MTB, int KS>
 int launch(WgArgs a, hipStream_t st) {
   const long total = (long)a.B * a.OH * a.OW;
   const long nchunks = (total + KP - 1) / KP;
-  const int gy_ = irr_cdiv(a.Cin, NTB * 32), gz_ = irr_cdiv(a.Cout, MTB * 32);
-  // aim for ~4 blocks per CU overall, at least 4 stages per block
-  long want = (1024 + (long)gy_ * gz_ - 1) / ((long)gy_ * gz_);
-  if (want < 1) want = 1;
-  long cpb = (nchunks + want - 1) / want;
-  if (cpb < 4) cpb = 4;
+  const int gy_ = irr_cdiv(a.Cin, 32), gz_ = irr_cdiv(a.Cout, MTB * 32);
+  // split-K so that the grid is (just under) a whole number of residency rounds: equal-sized blocks in
+  // ROUNDS full waves of the chip, no ragged tail; few rounds keep the atomic epilogue small.
+  static int occ = 0;
+  if (!occ) {
+    int o = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, conv_wgrad_kernel<MTB, KS>, MTB * KS * 64, 0) != hipSuccess || o < 1) o = 1;
+    occ = o;
+  }
+  const long slots = (long)occ * cu_count();
+  constexpr int ROUNDS = 2;
+  long xs = (slots * ROUNDS) / ((long)gy_ * gz_);
+  if (xs < 1) xs = 1;
+  long cpb = (nchunks + xs - 1) / xs;
+  if (cpb < 8) cpb = 8;
   a.chunks_per_block = (int)cpb;
   dim3 grid(irr_cdiv(nchunks, cpb), gy_, gz_);
-  hipLaunchKernelGGL((conv_wgrad_kernel<MTB, NTB, KS>), grid, dim3(MTB * NTB * 64), 0, st, a);
+  hipLaunchKernelGGL((conv_wgrad_kernel<MTB, KS>), grid, dim3(MTB * KS * 64), 0, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -138,10 +194,22 @@ int launch(WgArgs a, hipStream_t st) {
 template <int KS>
 int dispatch(const WgArgs& a, hipStream_t st) {
   const int cot = (a.Cout + 31) / 32;
-  if (cot == 1) return launch<1, 4, KS>(a, st);
-  if (cot == 2) return launch<2, 2, KS>(a, st);
-  if (cot == 3) return launch<3, 1, KS>(a, st);
-  return launch<4, 1, KS>(a, st);
+  if (cot == 1) return launch<1, KS>(a, st);
+  if (cot == 2) return launch<2, KS>(a, st);
+  if (cot == 3) return launch<3, KS>(a, st);
+  return launch<4, KS>(a, st);
+}
+
+// gw[co][ci][tap] += ws[co][tap][ci]
+__global__ __launch_bounds__(256) void wgrad_unpack_kernel(const float* __restrict__ ws, float* __restrict__ gw, int Cin,
+                                                          int KK, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int tap = (int)(i % KK);
+  const long r = i / KK;
+  const int ci = (int)(r % Cin);
+  const long co = r / Cin;
+  gw[i] += ws[(co * KK + tap) * Cin + ci];
 }
 
 // gpre = gy * lrelu'(y) ; gbias[c] += sum_p gpre
@@ -204,16 +272,23 @@ __global__ __launch_bounds__(256) void dgrad_strided_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, int B, int Cin, int H, int W, int Cout,
-                                    int OH, int OW, int k, int stride, int dil, long x_bs, long gy_bs, void* stream) {
-  if (!x || !gy || !gw || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return IRR_EINVAL;
+extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, int B, int Cin, int H, int W,
+                                    int Cout, int OH, int OW, int k, int stride, int dil, long x_bs, long gy_bs,
+                                    void* stream) {
+  if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return IRR_EINVAL;
   if ((k != 1 && k != 3) || stride < 1 || dil < 1) return IRR_EINVAL;
   WgArgs a;
-  a.x = x; a.gy = gy; a.gw = gw;
+  const long n = (long)Cout * Cin * k * k;
+  IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, (hipStream_t)stream));
+  a.x = x; a.gy = gy; a.gw = ws;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW;
   a.stride = stride; a.dil = dil; a.pad = ((k - 1) * dil) / 2;
   a.x_bs = x_bs; a.gy_bs = gy_bs; a.chunks_per_block = 0;
-  return (k == 3) ? dispatch<3>(a, (hipStream_t)stream) : dispatch<1>(a, (hipStream_t)stream);
+  const int rc = (k == 3) ? dispatch<3>(a, (hipStream_t)stream) : dispatch<1>(a, (hipStream_t)stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ws, gw, Cin, k * k, n);
+  IRR_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int irr_lrelu_bwd_bias_f32(const float* gy, const float* y, float* gpre, float* gbias, int B, int C, int HW,
