@@ -23,6 +23,8 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
           "-Wno-unused-function"]
 # per-file extras.  warp.hip reproduces ATen's fp32 rounding sequence: no contraction there.
+if os.environ.get("IRR_WG_ABL"):
+    COMMON = COMMON + ["-DWG_ABL=" + os.environ["IRR_WG_ABL"]]
 EXTRA = {"warp.hip": ["-ffp-contract=off"], "resize.hip": ["-ffp-contract=off"]}
 
 

@@ -15,6 +15,10 @@
 // into a [co][tap][ci] workspace (lanes = ci are contiguous) and then folded into dW[co][ci][tap].
 #include "common.h"
 
+#ifndef WG_ABL
+#define WG_ABL 0      // ablation builds only (tools/): 1 = no global loads, 2 = + no LDS writes, 3 = + no barriers
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -32,13 +36,29 @@ struct WgArgs {
   int chunks_per_block;
 };
 
+__device__ __forceinline__ float wg_buf_load(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
+}
+
+constexpr uint32_t OOB = 0xfffffffcu;          // voffset beyond num_records: the buffer load returns 0, no fault
+
 template <int MTB, int KS>
 __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a) {
   constexpr int KK = KS * KS;
   constexpr int NW = MTB * KS;                 // waves: (co-tile m, kernel row ty)
   constexpr int AROWS = MTB * 32, BROWS = KK * 32, ROWS = AROWS + BROWS;
-  constexpr int RGN = 2 * NW;                  // row groups: every half-wave stages one row per round
-  constexpr int NR = (ROWS + RGN - 1) / RGN;   // staged values per lane per stage
+  // Staging roles are per wave: NWB waves stage the x tile, NWA the gy tile (a lone wave does both).  A
+  // half-wave (32 lanes = the 32 pixels of a stage) loads one channel row per instruction.  Every x stager
+  // owns CPB input channels x all taps, so the tap geometry (9 voffsets) is computed once per stage; the
+  // channel enters through the scalar soffset; taps that fall outside the image get an out-of-range voffset
+  // and the buffer load's hardware bounds check returns 0 -- no per-load VALU work at all.
+  constexpr int NWB = (NW == 1) ? 1 : (NW >= 12) ? 8 : (NW >= 6) ? 4 : (NW >= 4) ? 2 : (NW == 3) ? 2 : 1;
+  constexpr int NWA = (NW == 1) ? 1 : NW - NWB;
+  constexpr int NB = 2 * NWB, NA = 2 * NWA;    // half-waves per role
+  constexpr int CPB = 32 / NB;                 // input channels per x-staging half-wave
+  constexpr int NRB = KK * CPB;                // staged values per lane (x stagers)
+  constexpr int NRA = (AROWS + NA - 1) / NA;   // staged values per lane (gy stagers)
+  constexpr int NR = (NW == 1) ? NRB + NRA : (NRB > NRA ? NRB : NRA);
   __shared__ float S[ROWS][PITCH];             // rows [0,AROWS): gy tiles; then tap-major x tiles
 
   const int tid = threadIdx.x;
@@ -60,48 +80,71 @@ __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // staging role: pixel column px of the stage, rows rg, rg+RGN, ...
-  const int px = tid & (KP - 1);
-  const int rg = tid >> 5;
+  const bool do_b = (NW == 1) || (wave < NWB);            // wave-uniform roles
+  const bool do_a = (NW == 1) || (wave >= NWB);
+  const int wb = wave;                                     // x-stager wave index
+  const int wa = (NW == 1) ? 0 : wave - NWB;               // gy-stager wave index
+  const int px = lane & 31;
+
+  // extents of the two views (bytes) for the hardware bounds check
+  const uint32_t x_bytes = (uint32_t)min((long)0xfffffffcL, ((long)(a.B - 1) * a.x_bs + (long)a.Cin * hw) * 4);
+  const uint32_t g_bytes = (uint32_t)min((long)0xfffffffcL, ((long)(a.B - 1) * a.gy_bs + (long)a.Cout * ohw) * 4);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)a.gy, (short)0, (int)g_bytes, 0x00020000);
+  const uint32_t xs0 = (uint32_t)((long)(ci0 + 2 * wb) * hw * 4);     // soffset of this wave's first channel pair
+  const uint32_t xsc = (uint32_t)((long)NB * hw * 4);                 // soffset step between owned channels
+  const uint32_t gs0 = (uint32_t)((long)(co0 + 2 * wa) * ohw * 4);
+  const uint32_t gsc = (uint32_t)((long)NA * ohw * 4);
 
   float stg[NR];
-  // per-stage pixel decode of this lane's staging column
-  const float* gb = nullptr;
-  const float* xb = nullptr;
-  int iy0 = 0, ix0 = 0;
-  bool pv = false;
+  uint32_t xv[KK];                              // per-tap voffset of this lane's pixel (+ half-wave channel)
+  uint32_t gv = OOB;
   auto decode = [&](long c) {
     const long p = c * KP + px;
-    pv = p < total;
+    const bool pv = p < total;
     const long pp = pv ? p : total - 1;
     const int b = (int)(pp / ohw);
     const int r = (int)(pp - (long)b * ohw);
-    const int oy = r / a.OW, ox = r - oy * a.OW;
-    gb = a.gy + (long)b * a.gy_bs + r;
-    xb = a.x + (long)b * a.x_bs;
-    iy0 = oy * a.stride - a.pad;
-    ix0 = ox * a.stride - a.pad;
-  };
-  // issue the global load of staged value i (row rg + i*RGN of the next stage)
-  auto issue1 = [&](int i) {
-    const int row = rg + i * RGN;
-    float v = 0.f;
-    if (row < AROWS) {
-      const int co = co0 + row;
-      const bool ok = pv && co < a.Cout;
-      const float t = gb[(long)(ok ? co : 0) * ohw];
-      v = ok ? t : 0.f;
-    } else if (row < ROWS) {
-      const int q = row - AROWS;
-      const int tap = q >> 5, ci = ci0 + (q & 31);
-      const int ty = (KS == 3) ? (tap * 11) >> 5 : 0;       // tap / 3 for tap in [0, 9)
-      const int tx = tap - ty * KS;
-      const int iy = iy0 + ty * a.dil, ix = ix0 + tx * a.dil;
-      const bool ok = pv && ci < a.Cin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const float t = xb[ok ? ((long)ci * hw + (long)iy * a.W + ix) : 0];
-      v = ok ? t : 0.f;
+    if (do_a) gv = pv ? (uint32_t)(((long)b * a.gy_bs + r + (long)half * ohw) * 4) : OOB;
+    if (do_b) {
+      const int oy = r / a.OW, ox = r - oy * a.OW;
+      const long base = (long)b * a.x_bs + (long)half * hw;
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const int ty = t / KS, tx = t - ty * KS;
+        const int iy = oy * a.stride - a.pad + ty * a.dil, ix = ox * a.stride - a.pad + tx * a.dil;
+        const bool ok = pv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        xv[t] = ok ? (uint32_t)((base + (long)iy * a.W + ix) * 4) : OOB;
+      }
     }
-    stg[i] = v;
+  };
+  // issue the global load of staged value i
+  auto issue1 = [&](int i) {
+    if (WG_ABL >= 1) { stg[i] = 1.f; return; }
+    if (do_b && i < NRB) {
+      const int t = i / CPB, cc = i - t * CPB;                 // compile-time after unrolling
+      stg[i] = wg_buf_load(xr, xv[t], xs0 + cc * xsc);
+    }
+    if (do_a && i >= ((NW == 1) ? NRB : 0) && i < ((NW == 1) ? NRB : 0) + NRA) {
+      const int ia = i - ((NW == 1) ? NRB : 0);
+      if (2 * wa + ia * NA < AROWS) stg[i] = wg_buf_load(gr, gv, gs0 + ia * gsc);
+    }
+  };
+  auto store_stage = [&]() {
+    if (do_b) {
+#pragma unroll
+      for (int i = 0; i < NRB; ++i) {
+        const int t = i / CPB, cc = i - t * CPB;
+        S[AROWS + t * 32 + 2 * wb + half + cc * NB][px] = stg[i];
+      }
+    }
+    if (do_a) {
+#pragma unroll
+      for (int ia = 0; ia < NRA; ++ia) {
+        const int row = 2 * wa + half + ia * NA;
+        if (2 * wa + ia * NA < AROWS) S[row][px] = stg[((NW == 1) ? NRB : 0) + ia];
+      }
+    }
   };
 
   if (c_begin < c_end) {
@@ -112,13 +155,9 @@ __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a
   constexpr int KSTEPS = KP / 2;
   constexpr int PER = (NR + KSTEPS - 1) / KSTEPS;      // prefetch loads interleaved per k-step
   for (long c = c_begin; c < c_end; ++c) {
-    __syncthreads();                           // previous stage fully consumed
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int row = rg + i * RGN;
-      if (row < ROWS) S[row][px] = stg[i];
-    }
-    __syncthreads();
+    if (WG_ABL < 3) __syncthreads();           // previous stage fully consumed
+    if (WG_ABL < 2 || c == c_begin) store_stage();
+    if (WG_ABL < 3) __syncthreads();
     const bool more = c + 1 < c_end;           // block-uniform
     if (more) decode(c + 1);
     const float* arow = &S[wm * 32 + j][half];
@@ -284,8 +323,19 @@ extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW;
   a.stride = stride; a.dil = dil; a.pad = ((k - 1) * dil) / 2;
   a.x_bs = x_bs; a.gy_bs = gy_bs; a.chunks_per_block = 0;
-  const int rc = (k == 3) ? dispatch<3>(a, (hipStream_t)stream) : dispatch<1>(a, (hipStream_t)stream);
-  if (rc) return rc;
+  // 32-bit byte offsets inside the kernel: split the batch so both views stay below 4 GiB
+  const long lim = (1L << 30) - 64;                                  // elements
+  const long bsmax = x_bs > gy_bs ? x_bs : gy_bs;
+  long per = bsmax > 0 ? (lim - (long)(Cin > Cout ? Cin : Cout) * H * W) / bsmax : B;
+  if (per < 1) return IRR_EINVAL;
+  if (per > B) per = B;
+  for (int b0 = 0; b0 < B; b0 += (int)per) {
+    a.B = (B - b0) < per ? (B - b0) : (int)per;
+    a.x = x + (long)b0 * x_bs;
+    a.gy = gy + (long)b0 * gy_bs;
+    const int rc = (k == 3) ? dispatch<3>(a, (hipStream_t)stream) : dispatch<1>(a, (hipStream_t)stream);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ws, gw, Cin, k * k, n);
   IRR_LAUNCH_CHECK();
   return 0;
