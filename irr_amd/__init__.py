@@ -11,4 +11,6 @@ from .correlation import Correlation  # noqa: E402,F401
 from .functional import compute_cost_volume  # noqa: E402,F401
 from .losses import MultiScaleEPE_PWC_Bi_Occ_upsample  # noqa: E402,F401
 
+from . import ddp, optim, train  # noqa: E402,F401
+
 IRR_PWC = PWCNet          # models/__init__.py:35 rebinds the module name to the class

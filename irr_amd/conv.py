@@ -147,6 +147,11 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         else:
             gx.copy_(v)
         return gx
+    if stride == 1 and cout == 1:
+        # the MFMA kernel consumes input channels in pairs: give the single-channel gradient a zero partner
+        gy = torch.cat([gy, torch.zeros_like(gy)], dim=1)
+        weight = torch.cat([weight.detach(), torch.zeros_like(weight.detach())], dim=0)
+        cout = 2
     if stride == 1 and cout >= 2:
         wp = packed_weights(weight, True)
         args = ("irr_conv2d_fwd_f32", hip.ptr(gy), hip.ptr(wp), None, None, hip.ptr(gx), B, cout, oh, ow, cin, H, W,
