@@ -41,7 +41,10 @@ def cpu_baseline(height, width, budget_s=20.0):
     """The oracle's train step (CPU restatement of the reference path, kind="port") timed on the host cores of
     the GPU box, bounded sample: B=2 pairs per step, 1 warm-up + as many timed steps as fit in the budget."""
     from oracle import irr_pwc_oracle as O
-    threads = torch.get_num_threads()
+    # 16 threads is the fastest setting for this graph on the GPU host (EPYC 9575F, 128 cores visible):
+    # probed 8/16/32/64/128 threads -> 0.52/0.59/0.46/0.22/0.07 pairs/s (tools/cpu_threads_probe.py)
+    threads = min(16, os.cpu_count() or 16)
+    torch.set_num_threads(threads)
     B = 2
     P = O.make_trainable(O.synthetic_params(0))
     opt = O.make_adam(P)
@@ -52,12 +55,12 @@ def cpu_baseline(height, width, budget_s=20.0):
     while True:
         O.train_step(P, opt, batch)
         n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 8:
+        if time.perf_counter() - t0 > budget_s or n >= 4:
             break
     dt = (time.perf_counter() - t0) / n
     return {"value": B / dt, "unit": "image-pairs/s", "cores": threads, "kind": "port",
             "sample": f"{n} timed steps (+1 warm-up) of the oracle train step (fwd+loss+bwd+Adam), batch {B}, "
-                      f"{height}x{width}, {threads} torch threads on the GPU host"}
+                      f"{height}x{width}, {threads} torch threads on the GPU host (best of 8/16/32/64/128 threads)"}
 
 
 def main():

@@ -121,6 +121,16 @@ int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws,
                          int B, int Cin, int H, int W, int Cout, int OH, int OW,
                          int k, int stride, int dil, long x_bs, long gy_bs, void* stream);
 
+/* ---- tiny-Cout heads (Cout <= 4, stride 1): direct VALU kernels, same contracts as the MFMA entry points -------
+ * conv_last 563->2 / 562->1, context tails 32->2 / 32->1, OccUpsampleNetwork.out_convs 32->1
+ * (models/pwc_modules.py:161,198,221,239; models/irr_modules.py:44).  w is the plain (Cout,Cin,k,k) tensor. */
+int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const float* bias, const float* res, float* y,
+                               int B, int Cin, int H, int W, int Cout, int k, int dil,
+                               long x_bs, long y_bs, long res_bs, int lrelu, float alpha, int accumulate, void* stream);
+int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, float* gw, float* ws,
+                                 int B, int Cin, int H, int W, int Cout, int k, int dil,
+                                 long x_bs, long gy_bs, void* stream);
+
 /* gpre = gy * (y>0 ? 1 : 0.1) (if lrelu) ; gbias[co] += sum gpre (gbias nullable, accumulated).
  * gpre may alias gy. */
 int irr_lrelu_bwd_bias_f32(const float* gy, const float* y, float* gpre, float* gbias,

@@ -116,6 +116,12 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
         else:
             out.copy_(v)
         return out
+    if cout <= 4 and stride == 1:
+        wc = weight.detach().contiguous()
+        hip.call("irr_conv2d_smallco_fwd_f32", hip.ptr(x), hip.ptr(wc), hip.ptr(bias.detach() if bias is not None else None),
+                 hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, k, dil, hip.bs(x), hip.bs(out),
+                 hip.bs(res) if res is not None else 0, int(lrelu), float(alpha), int(accumulate), hip.stream())
+        return out
     wp = packed_weights(weight, False)
     args = ("irr_conv2d_fwd_f32", hip.ptr(x), hip.ptr(wp), hip.ptr(bias.detach() if bias is not None else None),
             hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, oh, ow, k, stride, dil,
@@ -161,6 +167,13 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         else:
             TIMER.wrap(hip.lib().irr_conv2d_fwd_variant(B, cin, H, W, k), 2.0 * B * H * W * cout * cin * k * k,
                        lambda: hip.call(*args))
+    elif stride == 2 and k == 3 and dil == 1 and H == 2 * oh and W == 2 * ow and cout >= 2:
+        # transposed stride-2 conv == stride-1 conv (flipped weights) of the zero-interleaved gradient
+        z = torch.zeros(B, cout, H, W, device=gy.device, dtype=torch.float32)
+        z[:, :, ::2, ::2] = gy
+        wp = packed_weights(weight, True)
+        hip.call("irr_conv2d_fwd_f32", hip.ptr(z), hip.ptr(wp), None, None, hip.ptr(gx), B, cout, H, W, cin, H, W,
+                 k, 1, 1, hip.bs(z), hip.bs(gx), 0, 0, 1.0, int(accumulate), hip.stream())
     else:
         tmp = gx if not accumulate else torch.empty(B, cin, H, W, device=gy.device, dtype=torch.float32)
         wc = weight.detach().contiguous()
@@ -185,6 +198,10 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
         return gw
     assert gw.is_contiguous()
     ws = torch.empty(cout * cin * k * k, device=x.device, dtype=torch.float32)
+    if cout <= 4 and stride == 1:
+        hip.call("irr_conv2d_smallco_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), B, cin, H, W, cout, k, dil,
+                 hip.bs(x), hip.bs(gy), hip.stream())
+        return gw
     hip.call("irr_conv2d_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), B, cin, H, W, cout, oh, ow, k, stride, dil,
              hip.bs(x), hip.bs(gy), hip.stream())
     return gw

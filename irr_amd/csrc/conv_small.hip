@@ -1,0 +1,187 @@
+// Direct (VALU) kernels for the tiny-Cout heads of IRR-PWC: conv_last 563->2 / 562->1, context tails 32->2 / 32->1,
+// OccUpsampleNetwork.out_convs 32->1 (models/pwc_modules.py:161,198,221,239; models/irr_modules.py:44).
+// A 32-wide MFMA tile would spend 94-97 % of its rows on padding for these layers (SURVEY.md Appendix A,
+// observation (v)); here every lane owns one output pixel (coalesced along x), weights are wave-uniform scalar
+// loads, and the 3x3 neighbourhood reads hit L1.  Same epilogue contract as irr_conv2d_fwd_f32.
+#include "common.h"
+
+namespace {
+
+template <int NC, int KS>
+__global__ __launch_bounds__(256) void conv_smallco_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, const float* __restrict__ res,
+                                                              float* __restrict__ y, int B, int Cin, int H, int W,
+                                                              int dil, long x_bs, long y_bs, long res_bs, int lrelu,
+                                                              float alpha, int accumulate) {
+  constexpr int KK = KS * KS;
+  const long hw = (long)H * W;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= hw) return;
+  const int b = blockIdx.y;
+  const int oy = (int)(p / W), ox = (int)(p - (long)oy * W);
+  const int pad = ((KS - 1) * dil) / 2;
+  int off[KK];
+  bool ok[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) {
+    const int iy = oy - pad + (t / KS) * dil, ix = ox - pad + (t % KS) * dil;
+    ok[t] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    off[t] = ok[t] ? iy * W + ix : 0;
+  }
+  float acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+  const float* xb = x + (long)b * x_bs;
+  for (int ci = 0; ci < Cin; ++ci) {
+    const float* xc = xb + (long)ci * hw;
+    float v[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      const float l = xc[off[t]];
+      v[t] = ok[t] ? l : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float* wc = w + ((long)c * Cin + ci) * KK;      // wave-uniform -> scalar loads
+#pragma unroll
+      for (int t = 0; t < KK; ++t) acc[c] = fmaf(wc[t], v[t], acc[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    float v = acc[c] + (bias ? bias[c] : 0.f);
+    if (lrelu) v = irr_lrelu(v);
+    float* dst = y + (long)b * y_bs + (long)c * hw + p;
+    if (res) v = res[(long)b * res_bs + (long)c * hw + p] + alpha * v;
+    else v *= alpha;
+    if (accumulate) v += *dst;
+    *dst = v;
+  }
+}
+
+// ws[co][tap][ci] += sum over this block's pixels of gy[co][p] * x[ci][p + off(tap)]
+template <int NC, int KS>
+__global__ __launch_bounds__(256) void conv_smallco_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                float* __restrict__ ws, int B, int Cin, int H, int W,
+                                                                int dil, long x_bs, long gy_bs, int pix_per_block) {
+  constexpr int KK = KS * KS;
+  const long hw = (long)H * W;
+  const int ci = blockIdx.y, b = blockIdx.z;
+  const long p0 = (long)blockIdx.x * pix_per_block;
+  const long p1 = min(hw, p0 + pix_per_block);
+  const int pad = ((KS - 1) * dil) / 2;
+  const float* xc = x + (long)b * x_bs + (long)ci * hw;
+  const float* gb = gy + (long)b * gy_bs;
+  float acc[NC][KK];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[c][t] = 0.f;
+  for (long p = p0 + threadIdx.x; p < p1; p += 256) {
+    const int oy = (int)(p / W), ox = (int)(p - (long)oy * W);
+    float g[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) g[c] = gb[(long)c * hw + p];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      const int iy = oy - pad + (t / KS) * dil, ix = ox - pad + (t % KS) * dil;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const float l = xc[ok ? (long)iy * W + ix : 0];
+      const float v = ok ? l : 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c][t] = fmaf(g[c], v, acc[c][t]);
+    }
+  }
+  __shared__ float red[4][NC * KK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      float s = acc[c][t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+      if (lane == 0) red[wv][c * KK + t] = s;
+    }
+  __syncthreads();
+  if (threadIdx.x < NC * KK) {
+    const int c = threadIdx.x / KK, t = threadIdx.x - c * KK;
+    const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    unsafeAtomicAdd(ws + ((long)c * KK + t) * Cin + ci, s);
+  }
+}
+
+__global__ __launch_bounds__(256) void smallco_unpack_kernel(const float* __restrict__ ws, float* __restrict__ gw, int Cin,
+                                                            int KK, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int tap = (int)(i % KK);
+  const long r = i / KK;
+  const int ci = (int)(r % Cin);
+  const long co = r / Cin;
+  gw[i] += ws[(co * KK + tap) * Cin + ci];
+}
+
+template <int KS>
+int fwd_dispatch(int NC, dim3 grid, hipStream_t st, const float* x, const float* w, const float* bias, const float* res,
+                 float* y, int B, int Cin, int H, int W, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
+                 float alpha, int accumulate) {
+#define IRR_SMALL_FWD(N)                                                                                              \
+  hipLaunchKernelGGL((conv_smallco_fwd_kernel<N, KS>), grid, dim3(256), 0, st, x, w, bias, res, y, B, Cin, H, W, dil, \
+                     x_bs, y_bs, res_bs, lrelu, alpha, accumulate)
+  switch (NC) {
+    case 1: IRR_SMALL_FWD(1); break;
+    case 2: IRR_SMALL_FWD(2); break;
+    case 3: IRR_SMALL_FWD(3); break;
+    case 4: IRR_SMALL_FWD(4); break;
+    default: return IRR_EINVAL;
+  }
+#undef IRR_SMALL_FWD
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace
+
+extern "C" int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const float* bias, const float* res, float* y,
+                                          int B, int Cin, int H, int W, int Cout, int k, int dil, long x_bs, long y_bs,
+                                          long res_bs, int lrelu, float alpha, int accumulate, void* stream) {
+  if (!x || !w || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 1 || Cout > 4 || B > 65535) return IRR_EINVAL;
+  if ((k != 1 && k != 3) || dil < 1) return IRR_EINVAL;
+  dim3 grid(irr_cdiv((long)H * W, 256), B, 1);
+  return k == 3 ? fwd_dispatch<3>(Cout, grid, (hipStream_t)stream, x, w, bias, res, y, B, Cin, H, W, dil, x_bs, y_bs, res_bs,
+                                  lrelu, alpha, accumulate)
+                : fwd_dispatch<1>(Cout, grid, (hipStream_t)stream, x, w, bias, res, y, B, Cin, H, W, dil, x_bs, y_bs, res_bs,
+                                  lrelu, alpha, accumulate);
+}
+
+extern "C" int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, int B, int Cin, int H,
+                                            int W, int Cout, int k, int dil, long x_bs, long gy_bs, void* stream) {
+  if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 1 || Cout > 4) return IRR_EINVAL;
+  if ((k != 1 && k != 3) || dil < 1 || B > 65535 || Cin > 65535) return IRR_EINVAL;
+  const long n = (long)Cout * Cin * k * k;
+  hipStream_t st = (hipStream_t)stream;
+  IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, st));
+  const long hw = (long)H * W;
+  // enough blocks to fill the chip, at least 4 pixels per thread
+  long chunks = (2048 + (long)Cin * B - 1) / ((long)Cin * B);
+  if (chunks < 1) chunks = 1;
+  long ppb = (hw + chunks - 1) / chunks;
+  if (ppb < 1024) ppb = 1024;
+  dim3 grid(irr_cdiv(hw, ppb), Cin, B);
+#define IRR_SMALL_WG(N, K)                                                                                        \
+  hipLaunchKernelGGL((conv_smallco_wgrad_kernel<N, K>), grid, dim3(256), 0, st, x, gy, ws, B, Cin, H, W, dil, x_bs, \
+                     gy_bs, (int)ppb)
+  if (k == 3) {
+    switch (Cout) { case 1: IRR_SMALL_WG(1, 3); break; case 2: IRR_SMALL_WG(2, 3); break;
+                    case 3: IRR_SMALL_WG(3, 3); break; default: IRR_SMALL_WG(4, 3); break; }
+  } else {
+    switch (Cout) { case 1: IRR_SMALL_WG(1, 1); break; case 2: IRR_SMALL_WG(2, 1); break;
+                    case 3: IRR_SMALL_WG(3, 1); break; default: IRR_SMALL_WG(4, 1); break; }
+  }
+#undef IRR_SMALL_WG
+  IRR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(smallco_unpack_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, st, ws, gw, Cin, k * k, n);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
