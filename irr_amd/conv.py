@@ -268,3 +268,94 @@ def _planes_dense(t: torch.Tensor) -> bool:
 def conv_block(x, weight, bias, stride: int = 1, dil: int = 1, lrelu: bool = True, res=None, alpha: float = 1.0):
     """[res +] alpha * LeakyReLU?(conv2d(x, weight, bias, stride, 'same' padding, dil))."""
     return _ConvBlock.apply(x, weight, bias, int(stride), int(dil), bool(lrelu), res, float(alpha))
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd: the whole DenseNet estimator (FlowEstimatorDense / OccEstimatorDense) as ONE node
+# ----------------------------------------------------------------------------------------------
+class _DenseEstimatorFn(torch.autograd.Function):
+    """conv1..conv5 (+LeakyReLU, outputs PREPENDED) and conv_last of models/pwc_modules.py:153-170 / 190-207
+    on ONE preallocated NCHW buffer: every conv reads a channel suffix and writes the slice in front of it,
+    so there is no torch.cat; the backward walks the same buffer layout with a gradient buffer G in which
+    data-gradients are accumulated in place (``accumulate`` epilogue of the MFMA kernel).
+
+    Buffer layout (channels): [c5 32 | c4 64 | c3 96 | c2 128 | c1 128 | x Cin0 | est E]   (est only if base given)
+    Returns (buf, out): out = conv_last(x5) (+ base when given; then also stored in the est slot so the
+    context network can consume ``buf`` directly as cat([x5, est]), models/IRR_PWC.py:113-114)."""
+
+    GROW = (128, 128, 96, 64, 32)
+
+    @staticmethod
+    def forward(ctx, x, base, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        B, cin0, H, W = x.shape
+        E = ws[5].shape[0]
+        ctot = 448 + cin0
+        has_base = base is not None
+        buf = torch.empty(B, ctot + (E if has_base else 0), H, W, device=x.device, dtype=torch.float32)
+        buf[:, 448:ctot].copy_(x)
+        off = 448
+        for i in range(5):
+            co = _DenseEstimatorFn.GROW[i]
+            conv_forward(buf[:, off:ctot], ws[i], bs[i], 1, 1, True, out=buf[:, off - co:off])
+            off -= co
+        if has_base:
+            base_c = base if _planes_dense(base) else base.contiguous()
+            out = conv_forward(buf[:, :ctot], ws[5], bs[5], 1, 1, False, res=base_c, alpha=1.0)
+            buf[:, ctot:].copy_(out)
+        else:
+            out = conv_forward(buf[:, :ctot], ws[5], bs[5], 1, 1, False)
+        ctx.save_for_backward(buf, *ws)
+        ctx.cfg = (cin0, E, has_base)
+        return buf, out
+
+    @staticmethod
+    def backward(ctx, g_buf, g_out):
+        buf = ctx.saved_tensors[0]
+        ws = ctx.saved_tensors[1:]
+        cin0, E, has_base = ctx.cfg
+        B, _, H, W = buf.shape
+        ctot = 448 + cin0
+        dev = buf.device
+        # G: gradient w.r.t. every channel of buf.  g_buf is produced exclusively for this node (the context
+        # network's first conv), so it is updated in place.
+        if g_buf is None:
+            G = torch.zeros_like(buf)
+        else:
+            G = g_buf if (g_buf.is_contiguous() and g_buf.shape == buf.shape) else g_buf.contiguous()
+        g_est = None
+        if g_out is not None:
+            g_est = g_out if _planes_dense(g_out) else g_out.contiguous()
+        if has_base:
+            g_est = G[:, ctot:] + g_est if g_est is not None else G[:, ctot:].clone()
+        grads_w = [None] * 6
+        grads_b = [None] * 6
+        if g_est is not None:
+            gb = torch.zeros(E, device=dev, dtype=torch.float32)
+            lrelu_bwd_bias(g_est, None, False, None, gb)
+            grads_b[5] = gb
+            grads_w[5] = conv_wgrad(buf[:, :ctot], g_est, ws[5].shape, 1, 1)
+            conv_dgrad(g_est, ws[5], 1, 1, (H, W), gx=G[:, :ctot], accumulate=True)
+        off = 0
+        for i in range(4, -1, -1):
+            co = _DenseEstimatorFn.GROW[i]
+            gslice = G[:, off:off + co]
+            gb = torch.zeros(co, device=dev, dtype=torch.float32)
+            lrelu_bwd_bias(gslice, buf[:, off:off + co], True, gslice, gb)      # in place: G slice becomes d/d(pre-activation)
+            grads_b[i] = gb
+            grads_w[i] = conv_wgrad(buf[:, off + co:ctot], gslice, ws[i].shape, 1, 1)
+            conv_dgrad(gslice, ws[i], 1, 1, (H, W), gx=G[:, off + co:ctot], accumulate=True)
+            off += co
+        gx = G[:, 448:ctot] if ctx.needs_input_grad[0] else None
+        gbase = g_est if (has_base and ctx.needs_input_grad[1]) else None
+        out = [gx, gbase]
+        for i in range(6):
+            out += [grads_w[i], grads_b[i]]
+        return tuple(out)
+
+
+def dense_estimator(x, base, weights_and_biases):
+    """(buf, out) -- see _DenseEstimatorFn.  weights_and_biases = [w1, b1, ..., w5, b5, w_last, b_last]."""
+    if not x.is_cuda:
+        raise RuntimeError("irr_amd conv runs on the HIP device only (no CPU fallback)")
+    return _DenseEstimatorFn.apply(x, base, *weights_and_biases)

@@ -115,13 +115,12 @@ class PWCNet(nn.Module):
                 t_glb = flow.new_tensor(s_glb).view(1, 2, 1, 1)
                 flow = flow * t_loc
 
-                x_intm, flow_res = self.flow_estimators(torch.cat([corr, x_1by1, flow], dim=1))
-                flow_est = flow + flow_res
-                flow_cont = self.context_networks(torch.cat([x_intm, flow_est], dim=1), res=flow_est)
+                # estimator + "est = flow + res" + cat([x_intm, est]) in one cat-free node (conv.dense_estimator)
+                ctx_in, flow_est = self.flow_estimators.forward_residual(torch.cat([corr, x_1by1, flow], dim=1), flow)
+                flow_cont = self.context_networks(ctx_in, res=flow_est)
 
-                x_intm_o, occ_res = self.occ_estimators(torch.cat([corr, x_1by1, occ], dim=1))
-                occ_est = occ + occ_res
-                occ_cont = self.occ_context_networks(torch.cat([x_intm_o, occ_est], dim=1), res=occ_est)
+                ctx_in_o, occ_est = self.occ_estimators.forward_residual(torch.cat([corr, x_1by1, occ], dim=1), occ)
+                occ_cont = self.occ_context_networks(ctx_in_o, res=occ_est)
 
                 # refinement (models/IRR_PWC.py:126-138, alias-free)
                 img = Fn.resize_bilinear_ac(raw, h, w)

@@ -113,10 +113,21 @@ class _DenseEstimator(nn.Module):
         self.conv5 = conv(ch_in + 416, 32)
         self.conv_last = conv(ch_in + 448, ch_out, isReLU=False)
 
+    def _wb(self):
+        out = []
+        for layer in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.conv_last):
+            out += [layer.weight, layer.bias]
+        return out
+
     def forward(self, x):
-        for layer in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
-            x = torch.cat([layer(x), x], dim=1)          # new features are PREPENDED
-        return x, self.conv_last(x)
+        """(x5, x_out) as in the reference; the five convs write into one buffer (new features PREPENDED)."""
+        buf, out = C.dense_estimator(x, None, self._wb())
+        return buf, out
+
+    def forward_residual(self, x, base):
+        """Model fast path: returns (cat([x5, est]), est) with est = base + conv_last(x5), i.e. the input of
+        the context network (models/IRR_PWC.py:110-114) without building it by concatenation."""
+        return C.dense_estimator(x, base, self._wb())
 
 
 class FlowEstimatorDense(_DenseEstimator):
