@@ -14,6 +14,7 @@
 // interleaved with the MFMAs of the current stage.  Split-K partials are added with COALESCED fp32 atomics
 // into a [co][tap][ci] workspace (lanes = ci are contiguous) and then folded into dW[co][ci][tap].
 #include "common.h"
+#include <stdlib.h>
 
 #ifndef WG_ABL
 #define WG_ABL 0      // ablation builds only (tools/): 1 = no global loads, 2 = + no LDS writes, 3 = + no barriers
@@ -40,7 +41,11 @@ __device__ __forceinline__ float wg_buf_load(__amdgpu_buffer_rsrc_t rs, uint32_t
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
 }
 
-constexpr uint32_t OOB = 0xfffffffcu;          // voffset beyond num_records: the buffer load returns 0, no fault
+// Out-of-range marker for a voffset.  The hardware bounds check of a raw buffer load covers voffset (+imm) but
+// NOT soffset, so channel/row offsets are added into the voffset (one v_add_u32 per load) and the marker is
+// chosen so that marker + any in-view offset (< 2 GiB, enforced by the launcher) still exceeds num_records
+// without wrapping: such lanes read 0 and touch no memory.
+constexpr uint32_t OOB = 0x80000000u;
 
 template <int MTB, int KS>
 __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a) {
@@ -87,8 +92,8 @@ __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a
   const int px = lane & 31;
 
   // extents of the two views (bytes) for the hardware bounds check
-  const uint32_t x_bytes = (uint32_t)min((long)0xfffffffcL, ((long)(a.B - 1) * a.x_bs + (long)a.Cin * hw) * 4);
-  const uint32_t g_bytes = (uint32_t)min((long)0xfffffffcL, ((long)(a.B - 1) * a.gy_bs + (long)a.Cout * ohw) * 4);
+  const uint32_t x_bytes = (uint32_t)min((long)0x7ffffffcL, ((long)(a.B - 1) * a.x_bs + (long)a.Cin * hw) * 4);
+  const uint32_t g_bytes = (uint32_t)min((long)0x7ffffffcL, ((long)(a.B - 1) * a.gy_bs + (long)a.Cout * ohw) * 4);
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)a.gy, (short)0, (int)g_bytes, 0x00020000);
   const uint32_t xs0 = (uint32_t)((long)(ci0 + 2 * wb) * hw * 4);     // soffset of this wave's first channel pair
@@ -123,11 +128,11 @@ __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a
     if (WG_ABL >= 1) { stg[i] = 1.f; return; }
     if (do_b && i < NRB) {
       const int t = i / CPB, cc = i - t * CPB;                 // compile-time after unrolling
-      stg[i] = wg_buf_load(xr, xv[t], xs0 + cc * xsc);
+      stg[i] = wg_buf_load(xr, xv[t] + xs0 + cc * xsc, 0);
     }
     if (do_a && i >= ((NW == 1) ? NRB : 0) && i < ((NW == 1) ? NRB : 0) + NRA) {
       const int ia = i - ((NW == 1) ? NRB : 0);
-      if (2 * wa + ia * NA < AROWS) stg[i] = wg_buf_load(gr, gv, gs0 + ia * gsc);
+      if (2 * wa + ia * NA < AROWS) stg[i] = wg_buf_load(gr, gv + gs0 + ia * gsc, 0);
     }
   };
   auto store_stage = [&]() {
@@ -193,6 +198,167 @@ __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Halo-tile variant for the common case k=3, stride=1, dilation=1 (every DenseNet / refinement / occlusion-
+// upsampler conv; only the dilated context-network layers take the tap-copy kernel above).
+// A stage is a 2-D patch of TR rows x 30 output columns; x is staged ONCE with a one-pixel halo
+// ((TR+2) rows x 32 columns per channel -- exactly one half-wave load per halo row) and the nine taps read
+// shifted positions of the same LDS tile, so the staged volume per MFMA drops ~3x versus nine tap copies.
+// ---------------------------------------------------------------------------------------------------------
+template <int MTB, int TR>
+__global__ __launch_bounds__(MTB * 3 * 64) void conv_wgrad_halo_kernel(const WgArgs a) {
+  constexpr int KS = 3, KK = 9;
+  constexpr int NW = MTB * KS;
+  constexpr int TC = 30;                         // output columns per tile (+2 halo = 32 = one half-wave)
+  constexpr int AROWS = MTB * 32;
+  constexpr int AP = TR * 32 + 1, BP = (TR + 2) * 32 + 1;     // odd pitches: conflict-free channel-strided reads
+  constexpr int NWB = (NW >= 12) ? 4 : (NW >= 9) ? 4 : (NW >= 6) ? 2 : 2;
+  constexpr int NWA = NW - NWB;
+  constexpr int NB = 2 * NWB, NA = 2 * NWA;
+  constexpr int CPB = 32 / NB;                   // channels per x-staging half-wave
+  constexpr int NRB = CPB * (TR + 2);
+  constexpr int ALOADS = AROWS * TR;             // half-wave loads of the gy tile
+  constexpr int NRA = (ALOADS + NA - 1) / NA;
+  constexpr int NR = NRB > NRA ? NRB : NRA;
+  __shared__ float SA[AROWS][AP];
+  __shared__ float SB[32][BP];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / KS, ty_w = wave - wm * KS;
+  const int j = lane & 31, half = lane >> 5;
+  const int co0 = blockIdx.z * AROWS, ci0 = blockIdx.y * 32;
+  const long hw = (long)a.H * a.W;
+  const int tiles_x = (a.W + TC - 1) / TC, tiles_y = (a.H + TR - 1) / TR;
+  const long ntiles = (long)a.B * tiles_y * tiles_x;
+  const long c_begin = (long)blockIdx.x * a.chunks_per_block;
+  const long c_end = min(ntiles, c_begin + a.chunks_per_block);
+
+  f32x16 acc[KS];
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const bool do_b = wave < NWB;
+  const int wb = wave, wa = wave - NWB;
+  const int hl = lane & 31;                      // column inside the half-wave
+
+  const uint32_t x_bytes = (uint32_t)min((long)0x7ffffffcL, ((long)(a.B - 1) * a.x_bs + (long)a.Cin * hw) * 4);
+  const uint32_t g_bytes = (uint32_t)min((long)0x7ffffffcL, ((long)(a.B - 1) * a.gy_bs + (long)a.Cout * hw) * 4);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)a.gy, (short)0, (int)g_bytes, 0x00020000);
+  const uint32_t xs0 = (uint32_t)((long)(ci0 + 2 * wb) * hw * 4);
+  const uint32_t xsc = (uint32_t)((long)NB * hw * 4);
+
+  float stg[NR];
+  uint32_t xv[TR + 2];                           // x stagers: voffset of halo row hr at this lane's halo column
+  uint32_t gv[TR];                               // gy stagers: voffset of tile row r at this lane's column
+  auto decode = [&](long c) {
+    const int tx_ = (int)(c % tiles_x);
+    const long r1 = c / tiles_x;
+    const int ty_ = (int)(r1 % tiles_y);
+    const int b = (int)(r1 / tiles_y);
+    const int y0 = ty_ * TR, x0 = tx_ * TC;
+    if (do_b) {
+      const int x = x0 - 1 + hl;
+      const bool xok = x >= 0 && x < a.W;
+      const long base = (long)b * a.x_bs + (long)half * hw + x;
+#pragma unroll
+      for (int hr = 0; hr < TR + 2; ++hr) {
+        const int y = y0 - 1 + hr;
+        xv[hr] = (xok && y >= 0 && y < a.H) ? (uint32_t)((base + (long)y * a.W) * 4) : OOB;
+      }
+    } else {
+      const int x = x0 + hl;
+      const bool xok = hl < TC && x < a.W;
+      const long base = (long)b * a.gy_bs + x;
+#pragma unroll
+      for (int r = 0; r < TR; ++r) {
+        const int y = y0 + r;
+        gv[r] = (xok && y < a.H) ? (uint32_t)((base + (long)y * a.W) * 4) : OOB;
+      }
+    }
+  };
+  auto issue1 = [&](int i) {
+    if (WG_ABL >= 1) { stg[i] = 1.f; return; }
+    if (do_b) {
+      if (i < NRB) {
+        const int cc = i / (TR + 2), hr = i - cc * (TR + 2);
+        stg[i] = wg_buf_load(xr, xv[hr] + xs0 + cc * xsc, 0);
+      }
+    } else if (i < NRA) {
+      // half-wave load id q = (2*wa + half) + i*NA  ->  (row = q / TR, r = q % TR)
+      const int q = 2 * wa + half + i * NA;
+      const int row = q / TR, r = q - row * TR;
+      const uint32_t v = (TR == 2) ? (r ? gv[1] : gv[0]) : (r == 0 ? gv[0] : r == 1 ? gv[1] : r == 2 ? gv[TR > 2 ? 2 : 0] : gv[TR > 3 ? 3 : 0]);
+      const uint32_t vo = (q < ALOADS && co0 + row < a.Cout) ? v + (uint32_t)((long)(co0 + row) * hw * 4) : OOB;
+      stg[i] = wg_buf_load(gr, vo, 0);
+    }
+  };
+  auto store_stage = [&]() {
+    if (do_b) {
+#pragma unroll
+      for (int i = 0; i < NRB; ++i) {
+        const int cc = i / (TR + 2), hr = i - cc * (TR + 2);
+        SB[2 * wb + half + cc * NB][hr * 32 + hl] = stg[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NRA; ++i) {
+        const int q = 2 * wa + half + i * NA;
+        const int row = q / TR, r = q - row * TR;
+        if (q < ALOADS) SA[row][r * 32 + hl] = stg[i];
+      }
+    }
+  };
+
+  if (c_begin < c_end) {
+    decode(c_begin);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) issue1(i);
+  }
+  constexpr int KSTEPS = TR * (TC / 2);
+  constexpr int PER = (NR + KSTEPS - 1) / KSTEPS;
+  for (long c = c_begin; c < c_end; ++c) {
+    if (WG_ABL < 3) __syncthreads();
+    if (WG_ABL < 2 || c == c_begin) store_stage();
+    if (WG_ABL < 3) __syncthreads();
+    const bool more = c + 1 < c_end;
+    if (more) decode(c + 1);
+    const float* arow = &SA[wm * 32 + j][half];
+    const float* brow = &SB[j][ty_w * 32 + half];
+#pragma unroll
+    for (int k = 0; k < KSTEPS; ++k) {
+      const int r = k / (TC / 2), cpair = k - r * (TC / 2);
+      const float av = arow[r * 32 + 2 * cpair];
+      float bv[KS];
+#pragma unroll
+      for (int t = 0; t < KS; ++t) bv[t] = brow[r * 32 + 2 * cpair + t];
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+          if (k * PER + u < NR) issue1(k * PER + u);
+      }
+#pragma unroll
+      for (int t = 0; t < KS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+    }
+  }
+
+  const int ci = ci0 + j;
+  if (ci < a.Cin) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co >= a.Cout) continue;
+      float* dst = a.gw + ((long)co * KK + ty_w * KS) * a.Cin + ci;
+#pragma unroll
+      for (int t = 0; t < KS; ++t) unsafeAtomicAdd(dst + (long)t * a.Cin, acc[t][r]);
+    }
+  }
+}
+
 static int cu_count() {
   static int n = 0;
   if (!n) {
@@ -228,6 +394,38 @@ int launch(WgArgs a, hipStream_t st) {
   hipLaunchKernelGGL((conv_wgrad_kernel<MTB, KS>), grid, dim3(MTB * KS * 64), 0, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
+}
+
+template <int MTB, int TR>
+int launch_halo(WgArgs a, hipStream_t st) {
+  const int tiles_x = (a.W + 29) / 30, tiles_y = (a.H + TR - 1) / TR;
+  const long ntiles = (long)a.B * tiles_y * tiles_x;
+  const int gy_ = irr_cdiv(a.Cin, 32), gz_ = irr_cdiv(a.Cout, MTB * 32);
+  static int occ = 0;
+  if (!occ) {
+    int o = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, conv_wgrad_halo_kernel<MTB, TR>, MTB * 3 * 64, 0) != hipSuccess || o < 1) o = 1;
+    occ = o;
+  }
+  const long slots = (long)occ * cu_count();
+  constexpr int ROUNDS = 2;
+  long xs = (slots * ROUNDS) / ((long)gy_ * gz_);
+  if (xs < 1) xs = 1;
+  long cpb = (ntiles + xs - 1) / xs;
+  if (cpb < 4) cpb = 4;
+  a.chunks_per_block = (int)cpb;
+  dim3 grid(irr_cdiv(ntiles, cpb), gy_, gz_);
+  hipLaunchKernelGGL((conv_wgrad_halo_kernel<MTB, TR>), grid, dim3(MTB * 3 * 64), 0, st, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+static int dispatch_halo(const WgArgs& a, hipStream_t st) {
+  const int cot = (a.Cout + 31) / 32;
+  if (cot == 1) return launch_halo<1, 2>(a, st);
+  if (cot == 2) return launch_halo<2, 2>(a, st);
+  if (cot == 3) return launch_halo<3, 2>(a, st);
+  return launch_halo<4, 2>(a, st);
 }
 
 template <int KS>
@@ -324,7 +522,7 @@ extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
   a.stride = stride; a.dil = dil; a.pad = ((k - 1) * dil) / 2;
   a.x_bs = x_bs; a.gy_bs = gy_bs; a.chunks_per_block = 0;
   // 32-bit byte offsets inside the kernel: split the batch so both views stay below 4 GiB
-  const long lim = (1L << 30) - 64;                                  // elements
+  const long lim = (1L << 29) - 64;                                  // elements: both views stay below 2 GiB (see OOB)
   const long bsmax = x_bs > gy_bs ? x_bs : gy_bs;
   long per = bsmax > 0 ? (lim - (long)(Cin > Cout ? Cin : Cout) * H * W) / bsmax : B;
   if (per < 1) return IRR_EINVAL;
@@ -333,7 +531,9 @@ extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
     a.B = (B - b0) < per ? (B - b0) : (int)per;
     a.x = x + (long)b0 * x_bs;
     a.gy = gy + (long)b0 * gy_bs;
-    const int rc = (k == 3) ? dispatch<3>(a, (hipStream_t)stream) : dispatch<1>(a, (hipStream_t)stream);
+    const bool halo = (k == 3 && stride == 1 && dil == 1 && W >= 56 && !getenv("IRR_WGRAD_NO_HALO"));
+    const int rc = halo ? dispatch_halo(a, (hipStream_t)stream)
+                        : (k == 3) ? dispatch<3>(a, (hipStream_t)stream) : dispatch<1>(a, (hipStream_t)stream);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ws, gw, Cin, k * k, n);

@@ -26,6 +26,9 @@ CASES = [
     (16, 3, 1, 1, 1, True, 1, 48, 56),
     (11, 32, 3, 1, 1, True, 1, 48, 56),
     (32, 32, 3, 1, 1, False, 3, 33, 47),      # ragged: pixel count not a multiple of the tile
+    (40, 128, 3, 1, 1, True, 2, 10, 64),      # halo-tile wgrad: partial last column tile + padded channels
+    (64, 64, 3, 1, 1, True, 1, 7, 90),        # halo-tile wgrad: odd row count
+    (35, 96, 3, 1, 1, True, 1, 12, 58),
 ]
 
 
