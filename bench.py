@@ -145,6 +145,17 @@ def main():
                     "flop_per_launch": st["flops"] / st["calls"],
                     "all_conv_fwd_dgrad": {"achieved": round(tot_f / tot_s / 1e12, 2), "seconds_per_step": round(tot_s / a.steps, 5),
                                            "flops_per_step": tot_f / a.steps}}
+    if rank == 0 and roof is not None:
+        # HBM bytes per launch of that kernel from the committed PMC passes (profiles/r1_hbm_traffic.txt:
+        # separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH x2 gfx950 correction); not re-measured here.
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            k = roof["kernel"].replace(",", ", ")
+            if k in tr and (a.height, a.width, a.batch) == (384, 448, 32):
+                roof["traffic"] = round((tr[k]["fetch_MB_per_launch_corrected"] + tr[k]["write_MB_per_launch"]) * 1e6)
+                roof["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 PMC passes, bytes per launch)"
+        except Exception:
+            pass
     if rank == 0:
         gf = CONV_GFLOP_PER_PAIR.get((a.height, a.width))
         out = {"metric": "image-pairs/sec fwd+bwd IRR-PWC 384x448 bs32", "value": round(value, 3), "unit": "image-pairs/s",

@@ -1,0 +1,35 @@
+"""HBM traffic per kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
+usage: rocpd_traffic.py fetch.db write.db > profiles/<name>.txt
+Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  On gfx950 FETCH_SIZE under-reports wide coalesced
+reads by exactly 2x (MI355X_MICROARCH.md, HBM section) -> the corrected column doubles it; WRITE_SIZE is left
+as reported (uncalibrated per the guide)."""
+import re
+import sqlite3
+import sys
+
+
+def agg(path, counter):
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, dispatch_id, sum(counter_value), max(duration) from pmc_events "
+                      "where counter_name=? group by name, dispatch_id", (counter,)).fetchall()
+    out = {}
+    for name, _d, v, dur in rows:
+        short = re.sub(r"\(anonymous namespace\)::|void ", "", name)
+        short = re.sub(r"\(.*\)$", "", short)[:60]
+        a = out.setdefault(short, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += v
+        a[2] += dur
+    return out
+
+
+f = agg(sys.argv[1], "FETCH_SIZE")
+w = agg(sys.argv[2], "WRITE_SIZE")
+print(f"{'kernel':60s} {'launches':>8s} {'avg_us':>9s} {'fetch_MB/launch(x2 corr)':>26s} {'write_MB/launch':>16s} {'GB/s (corr)':>12s}")
+for k in sorted(f, key=lambda k: -f[k][2])[:30]:
+    n = f[k][0]
+    fe = f[k][1] / n * 1024 * 2 / 1e6
+    wn = max(w.get(k, [1])[0], 1)
+    wr = w.get(k, [1, 0.0, 0.0])[1] / wn * 1024 / 1e6
+    us = f[k][2] / n / 1e3
+    print(f"{k:60s} {n:8d} {us:9.1f} {fe:26.2f} {wr:16.2f} {(fe + wr) / us * 1e-3 * 1e3:12.1f}")
