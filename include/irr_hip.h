@@ -101,13 +101,17 @@ int irr_conv_pack_weights_f32(const float* w, float* wp, int Cin, int Cout, int 
  *   y = res ? res + alpha*v : alpha*v      (res nullable; OccUpsampleNetwork residual adds,
  *                                           models/irr_modules.py:51-54, and flow + flow_res, models/IRR_PWC.py:110-114)
  *   accumulate != 0: y += previous y        (data-gradient accumulation into DenseNet gradient buffers).
+ *   mask (nullable): finally y *= LeakyReLU'(mask[b,co,p]) for co < nmask -- lets a data-gradient launch hand the
+ *   NEXT layer its pre-activation gradient directly (mask = that layer's saved activation), so no separate
+ *   LeakyReLU-backward pass over the tensor is needed.
  * Cin >= 2.  The batch is split internally so that all in-kernel byte offsets stay below 4 GiB.
  */
 int irr_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, const float* res, float* y,
                        int B, int Cin, int H, int W, int Cout, int OH, int OW,
                        int k, int stride, int dil,
                        long x_bs, long y_bs, long res_bs,
-                       int lrelu, float alpha, int accumulate, void* stream);
+                       int lrelu, float alpha, int accumulate,
+                       const float* mask, long mask_bs, int nmask, void* stream);
 
 /* Which template instantiation irr_conv2d_fwd_f32 launches for this problem, as MT*100 + NT*10 + k
  * (conv_fwd_kernel<MT,NT,k>); used to label bench.py's roofline line and to find the kernel in rocprof output. */
@@ -116,8 +120,9 @@ int irr_conv2d_fwd_variant(int B, int Cout, int OH, int OW, int k);
 /* dW[co][ci][tap] += sum_{b,y,x} gy[b,co,y,x] * x[b,ci,y*stride+(ty-pad), x*stride+(tx-pad)]
  * gw is the plain (Cout,Cin,k,k) tensor and is ACCUMULATED into (caller zeroes it when it wants "=").
  * ws: caller-owned scratch of Cout*Cin*k*k floats (split-K partials land there with coalesced atomics in
- * [co][tap][ci] order and are then added to gw). */
-int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws,
+ * [co][tap][ci] order and are then added to gw).
+ * gbias (nullable): gbias[co] += sum_{b,y,x} gy[b,co,y,x] (the bias gradient, taken from the staged gy tiles). */
+int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias,
                          int B, int Cin, int H, int W, int Cout, int OH, int OW,
                          int k, int stride, int dil, long x_bs, long gy_bs, void* stream);
 
@@ -127,7 +132,7 @@ int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws,
 int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const float* bias, const float* res, float* y,
                                int B, int Cin, int H, int W, int Cout, int k, int dil,
                                long x_bs, long y_bs, long res_bs, int lrelu, float alpha, int accumulate, void* stream);
-int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, float* gw, float* ws,
+int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias,
                                  int B, int Cin, int H, int W, int Cout, int k, int dil,
                                  long x_bs, long gy_bs, void* stream);
 

@@ -25,6 +25,10 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-a
 # per-file extras.  warp.hip reproduces ATen's fp32 rounding sequence: no contraction there.
 if os.environ.get("IRR_WG_ABL"):
     COMMON = COMMON + ["-DWG_ABL=" + os.environ["IRR_WG_ABL"]]
+if os.environ.get("IRR_WG_ISSUE"):
+    COMMON = COMMON + ["-DWG_ISSUE_MODE=" + os.environ["IRR_WG_ISSUE"]]
+if os.environ.get("IRR_CONV_D"):
+    COMMON = COMMON + ["-DCONV_PREFETCH_D=" + os.environ["IRR_CONV_D"]]
 EXTRA = {"warp.hip": ["-ffp-contract=off"], "resize.hip": ["-ffp-contract=off"]}
 
 

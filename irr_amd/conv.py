@@ -98,6 +98,7 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                  lrelu: bool, out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                  alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
     """out = [res +] alpha * act(conv(x, weight) + bias)   (accumulate: out += ...)."""
+    # (the LeakyReLU'-mask epilogue of the kernel is only used by conv_dgrad)
     B, cin, H, W = x.shape
     cout, cin_w, k, _ = weight.shape
     assert cin == cin_w, (x.shape, weight.shape)
@@ -126,7 +127,7 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     args = ("irr_conv2d_fwd_f32", hip.ptr(x), hip.ptr(wp), hip.ptr(bias.detach() if bias is not None else None),
             hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, oh, ow, k, stride, dil,
             hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
-            int(lrelu), float(alpha), int(accumulate), hip.stream())
+            int(lrelu), float(alpha), int(accumulate), None, 0, 0, hip.stream())
     if TIMER is None:
         hip.call(*args)
     else:
@@ -136,8 +137,11 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
 
 
 def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in_hw: Tuple[int, int],
-               gx: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
-    """gx (+)= conv_transpose(gy, weight); gy must already carry the activation derivative."""
+               gx: Optional[torch.Tensor] = None, accumulate: bool = False,
+               mask: Optional[torch.Tensor] = None, nmask: int = 0) -> torch.Tensor:
+    """gx (+)= conv_transpose(gy, weight); gy must already carry the activation derivative.
+    mask/nmask: afterwards gx[:, :nmask] *= LeakyReLU'(mask[:, :nmask]) in the same launch (mask = the saved
+    activation that produced this conv's input), i.e. gx comes out as a PRE-activation gradient."""
     B, cout, oh, ow = gy.shape
     cout_w, cin, k, _ = weight.shape
     assert cout == cout_w
@@ -152,7 +156,10 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
             gx += v
         else:
             gx.copy_(v)
+        if mask is not None and nmask > 0:
+            gx[:, :nmask] *= torch.where(mask[:, :nmask] > 0, 1.0, 0.1)
         return gx
+    margs = (hip.ptr(mask), hip.bs(mask), int(nmask)) if (mask is not None and nmask > 0) else (None, 0, 0)
     if stride == 1 and cout == 1:
         # the MFMA kernel consumes input channels in pairs: give the single-channel gradient a zero partner
         gy = torch.cat([gy, torch.zeros_like(gy)], dim=1)
@@ -161,7 +168,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
     if stride == 1 and cout >= 2:
         wp = packed_weights(weight, True)
         args = ("irr_conv2d_fwd_f32", hip.ptr(gy), hip.ptr(wp), None, None, hip.ptr(gx), B, cout, oh, ow, cin, H, W,
-                k, 1, dil, hip.bs(gy), hip.bs(gx), 0, 0, 1.0, int(accumulate), hip.stream())
+                k, 1, dil, hip.bs(gy), hip.bs(gx), 0, 0, 1.0, int(accumulate), *margs, hip.stream())
         if TIMER is None:
             hip.call(*args)
         else:
@@ -173,7 +180,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         z[:, :, ::2, ::2] = gy
         wp = packed_weights(weight, True)
         hip.call("irr_conv2d_fwd_f32", hip.ptr(z), hip.ptr(wp), None, None, hip.ptr(gx), B, cout, H, W, cin, H, W,
-                 k, 1, 1, hip.bs(z), hip.bs(gx), 0, 0, 1.0, int(accumulate), hip.stream())
+                 k, 1, 1, hip.bs(z), hip.bs(gx), 0, 0, 1.0, int(accumulate), *margs, hip.stream())
     else:
         tmp = gx if not accumulate else torch.empty(B, cin, H, W, device=gy.device, dtype=torch.float32)
         wc = weight.detach().contiguous()
@@ -181,12 +188,15 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                  k, stride, dil, hip.bs(gy), hip.bs(tmp), hip.stream())
         if accumulate:
             gx += tmp
+        if mask is not None and nmask > 0:
+            gx[:, :nmask] *= torch.where(mask[:, :nmask] > 0, 1.0, 0.1)
     return gx
 
 
 def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil: int,
-               gw: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """gw += d/dW; gw (Cout,Cin,k,k) is created zeroed when not given."""
+               gw: Optional[torch.Tensor] = None, gbias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gw += d/dW; gw (Cout,Cin,k,k) is created zeroed when not given.  gbias (optional, (Cout,)) += sum of gy over
+    (b, h, w): the bias gradient comes out of the same launch (the gy tiles are staged there anyway)."""
     cout, cin, k, _ = weight_shape
     B, _, H, W = x.shape
     _, _, oh, ow = gy.shape
@@ -195,14 +205,16 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
     if BACKEND == "miopen":
         gw += torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), gy, stride=stride,
                                           padding=((k - 1) * dil) // 2, dilation=dil)
+        if gbias is not None:
+            gbias += gy.sum(dim=(0, 2, 3))
         return gw
     assert gw.is_contiguous()
     ws = torch.empty(cout * cin * k * k, device=x.device, dtype=torch.float32)
     if cout <= 4 and stride == 1:
-        hip.call("irr_conv2d_smallco_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), B, cin, H, W, cout, k, dil,
+        hip.call("irr_conv2d_smallco_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), B, cin, H, W, cout, k, dil,
                  hip.bs(x), hip.bs(gy), hip.stream())
         return gw
-    hip.call("irr_conv2d_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), B, cin, H, W, cout, oh, ow, k, stride, dil,
+    hip.call("irr_conv2d_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), B, cin, H, W, cout, oh, ow, k, stride, dil,
              hip.bs(x), hip.bs(gy), hip.stream())
     return gw
 
@@ -249,13 +261,15 @@ class _ConvBlock(torch.autograd.Function):
         g = gy if alpha == 1.0 else gy * alpha
         cout = weight.shape[0]
         gb = torch.zeros(cout, device=gy.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        if lrelu or gb is not None:
+        want_w = ctx.needs_input_grad[1]
+        bias_in_wgrad = gb is not None and want_w and not lrelu      # no elementwise pass needed at all
+        if lrelu or (gb is not None and not bias_in_wgrad):
             gpre = torch.empty_like(g) if lrelu else None
-            lrelu_bwd_bias(g, act, lrelu, gpre, gb)
+            lrelu_bwd_bias(g, act, lrelu, gpre, gb)                  # mask and bias gradient in one HBM pass
             if lrelu:
                 g = gpre
         gx = conv_dgrad(g, ctx.weight_obj, stride, dil, x.shape[2:]) if ctx.needs_input_grad[0] else None
-        gw = conv_wgrad(x, g, weight.shape, stride, dil) if ctx.needs_input_grad[1] else None
+        gw = conv_wgrad(x, g, weight.shape, stride, dil, gbias=gb if bias_in_wgrad else None) if want_w else None
         return gx, gw, gb, None, None, None, gres, None
 
 
@@ -330,21 +344,26 @@ class _DenseEstimatorFn(torch.autograd.Function):
             g_est = G[:, ctot:] + g_est if g_est is not None else G[:, ctot:].clone()
         grads_w = [None] * 6
         grads_b = [None] * 6
+        # Walk conv_last, conv5 .. conv1.  Each data-gradient launch accumulates into the channel suffix of G
+        # and, in the same epilogue, multiplies the slice of the NEXT layer to be processed (the first
+        # GROW[i-1] channels of that suffix, which has just received its last contribution) by LeakyReLU' of the
+        # saved activations -- so every G slice is already a pre-activation gradient when its turn comes, and
+        # the bias gradients come out of the wgrad launches: no separate elementwise pass over G.
         if g_est is not None:
-            gb = torch.zeros(E, device=dev, dtype=torch.float32)
-            lrelu_bwd_bias(g_est, None, False, None, gb)
-            grads_b[5] = gb
-            grads_w[5] = conv_wgrad(buf[:, :ctot], g_est, ws[5].shape, 1, 1)
-            conv_dgrad(g_est, ws[5], 1, 1, (H, W), gx=G[:, :ctot], accumulate=True)
+            grads_b[5] = torch.zeros(E, device=dev, dtype=torch.float32)
+            grads_w[5] = conv_wgrad(buf[:, :ctot], g_est, ws[5].shape, 1, 1, gbias=grads_b[5])
+            conv_dgrad(g_est, ws[5], 1, 1, (H, W), gx=G[:, :ctot], accumulate=True, mask=buf[:, :ctot], nmask=32)
+        else:
+            lrelu_bwd_bias(G[:, :32], buf[:, :32], True, G[:, :32], None)
         off = 0
         for i in range(4, -1, -1):
             co = _DenseEstimatorFn.GROW[i]
-            gslice = G[:, off:off + co]
-            gb = torch.zeros(co, device=dev, dtype=torch.float32)
-            lrelu_bwd_bias(gslice, buf[:, off:off + co], True, gslice, gb)      # in place: G slice becomes d/d(pre-activation)
-            grads_b[i] = gb
-            grads_w[i] = conv_wgrad(buf[:, off + co:ctot], gslice, ws[i].shape, 1, 1)
-            conv_dgrad(gslice, ws[i], 1, 1, (H, W), gx=G[:, off + co:ctot], accumulate=True)
+            gslice = G[:, off:off + co]                       # already d/d(pre-activation)
+            grads_b[i] = torch.zeros(co, device=dev, dtype=torch.float32)
+            grads_w[i] = conv_wgrad(buf[:, off + co:ctot], gslice, ws[i].shape, 1, 1, gbias=grads_b[i])
+            nm = _DenseEstimatorFn.GROW[i - 1] if i > 0 else 0
+            conv_dgrad(gslice, ws[i], 1, 1, (H, W), gx=G[:, off + co:ctot], accumulate=True,
+                       mask=buf[:, off + co:ctot] if nm else None, nmask=nm)
             off += co
         gx = G[:, 448:ctot] if ctx.needs_input_grad[0] else None
         gbase = g_est if (has_base and ctx.needs_input_grad[1]) else None

@@ -19,6 +19,10 @@
 // The same kernel computes the stride-1 data gradient when fed transposed+flipped packed weights.
 #include "common.h"
 
+#ifndef CONV_PREFETCH_D
+#define CONV_PREFETCH_D 3   // must divide 9
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -35,6 +39,9 @@ struct ConvArgs {
   long x_bs, y_bs, res_bs;
   int lrelu, accumulate;
   float alpha;
+  const float* mask;     // optional: after everything else, y *= LeakyReLU'(mask[b,co,p]) for co < nmask
+  long mask_bs;
+  int nmask;
 };
 
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
@@ -44,7 +51,7 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, uint32_t vo
 template <int MT, int NT, int KS>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
   constexpr int KK = KS * KS;
-  constexpr int D = (KK == 9) ? 3 : 1;          // prefetch distance in k-steps (ring slots)
+  constexpr int D = (KK == 9) ? CONV_PREFETCH_D : 1;          // prefetch distance in k-steps (ring slots)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, half = lane >> 5;
@@ -57,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
 
   uint32_t voff[NT][KK];
   bool valid[NT][KK];
-  uint32_t ooff[NT], roff[NT];
+  uint32_t ooff[NT], roff[NT], moff[NT];
   bool pvalid[NT];
 #pragma unroll
   for (int s = 0; s < NT; ++s) {
@@ -69,6 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
     const int oy = r / a.OW, ox = r - oy * a.OW;
     ooff[s] = (uint32_t)((long)b * a.y_bs + r);
     roff[s] = (uint32_t)((long)b * a.res_bs + r);
+    moff[s] = (uint32_t)((long)b * a.mask_bs + r);
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
       const int ty = t / KS, tx = t - ty * KS;
@@ -155,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
         if (a.res) v = a.res[roff[s] + (long)co * ohw] + a.alpha * v;
         else v *= a.alpha;
         if (a.accumulate) v += *dst;
+        if (a.mask && co < a.nmask) v *= irr_lrelu_grad(a.mask[moff[s] + (long)co * ohw]);
         *dst = v;
       }
     }
@@ -256,7 +265,7 @@ extern "C" int irr_conv_pack_weights_f32(const float* w, float* wp, int Cin, int
 extern "C" int irr_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, const float* res, float* y, int B,
                                   int Cin, int H, int W, int Cout, int OH, int OW, int k, int stride, int dil,
                                   long x_bs, long y_bs, long res_bs, int lrelu, float alpha, int accumulate,
-                                  void* stream) {
+                                  const float* mask, long mask_bs, int nmask, void* stream) {
   if (!x || !wp || !y || B <= 0 || Cin < 2 || Cout <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return IRR_EINVAL;
   if ((k != 1 && k != 3) || stride < 1 || dil < 1) return IRR_EINVAL;
   const int pad = ((k - 1) * dil) / 2;
@@ -269,9 +278,11 @@ extern "C" int irr_conv2d_fwd_f32(const float* x, const float* wp, const float* 
   a.CoP = (Cout + 31) / 32 * 32;
   a.x_bs = x_bs; a.y_bs = y_bs; a.res_bs = res_bs;
   a.lrelu = lrelu; a.accumulate = accumulate; a.alpha = alpha;
+  a.mask_bs = mask_bs; a.nmask = nmask;
   // 32-bit byte offsets inside the kernel: split the batch so every offset stays below 4 GiB
   const long lim = (1L << 30) - (long)(Cin + 2) * H * W - 1;       // elements
   long per = x_bs > 0 ? lim / (x_bs > y_bs ? (x_bs > res_bs ? x_bs : res_bs) : (y_bs > res_bs ? y_bs : res_bs)) : B;
+  if (mask && mask_bs > 0 && lim / mask_bs < per) per = lim / mask_bs;
   if (per < 1) return IRR_EINVAL;
   if (per > B) per = B;
   for (int b0 = 0; b0 < B; b0 += (int)per) {
@@ -280,6 +291,7 @@ extern "C" int irr_conv2d_fwd_f32(const float* x, const float* wp, const float* 
     a.x = x + (long)b0 * x_bs;
     a.y = y + (long)b0 * y_bs;
     a.res = res ? res + (long)b0 * res_bs : nullptr;
+    a.mask = mask ? mask + (long)b0 * mask_bs : nullptr;
     const int rc = (k == 3) ? dispatch<3>(a, (hipStream_t)stream) : dispatch<1>(a, (hipStream_t)stream);
     if (rc) return rc;
   }

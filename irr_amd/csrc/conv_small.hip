@@ -62,8 +62,9 @@ __global__ __launch_bounds__(256) void conv_smallco_fwd_kernel(const float* __re
 // ws[co][tap][ci] += sum over this block's pixels of gy[co][p] * x[ci][p + off(tap)]
 template <int NC, int KS>
 __global__ __launch_bounds__(256) void conv_smallco_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                                float* __restrict__ ws, int B, int Cin, int H, int W,
-                                                                int dil, long x_bs, long gy_bs, int pix_per_block) {
+                                                                float* __restrict__ ws, float* __restrict__ gbias, int B,
+                                                                int Cin, int H, int W, int dil, long x_bs, long gy_bs,
+                                                                int pix_per_block) {
   constexpr int KK = KS * KS;
   const long hw = (long)H * W;
   const int ci = blockIdx.y, b = blockIdx.z;
@@ -73,15 +74,21 @@ __global__ __launch_bounds__(256) void conv_smallco_wgrad_kernel(const float* __
   const float* xc = x + (long)b * x_bs + (long)ci * hw;
   const float* gb = gy + (long)b * gy_bs;
   float acc[NC][KK];
+  float bsum[NC];
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
+  for (int c = 0; c < NC; ++c) {
+    bsum[c] = 0.f;
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[c][t] = 0.f;
+  }
   for (long p = p0 + threadIdx.x; p < p1; p += 256) {
     const int oy = (int)(p / W), ox = (int)(p - (long)oy * W);
     float g[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) g[c] = gb[(long)c * hw + p];
+    for (int c = 0; c < NC; ++c) {
+      g[c] = gb[(long)c * hw + p];
+      bsum[c] += g[c];
+    }
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
       const int iy = oy - pad + (t / KS) * dil, ix = ox - pad + (t % KS) * dil;
@@ -94,6 +101,15 @@ __global__ __launch_bounds__(256) void conv_smallco_wgrad_kernel(const float* __
   }
   __shared__ float red[4][NC * KK];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (gbias && ci == 0) {                      // the ci == 0 blocks also carry the bias gradient
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float sb = bsum[c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sb += __shfl_down(sb, o, 64);
+      if (lane == 0) unsafeAtomicAdd(gbias + c, sb);
+    }
+  }
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -155,8 +171,9 @@ extern "C" int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const 
                                   lrelu, alpha, accumulate);
 }
 
-extern "C" int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, int B, int Cin, int H,
-                                            int W, int Cout, int k, int dil, long x_bs, long gy_bs, void* stream) {
+extern "C" int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, int B,
+                                            int Cin, int H, int W, int Cout, int k, int dil, long x_bs, long gy_bs,
+                                            void* stream) {
   if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 1 || Cout > 4) return IRR_EINVAL;
   if ((k != 1 && k != 3) || dil < 1 || B > 65535 || Cin > 65535) return IRR_EINVAL;
   const long n = (long)Cout * Cin * k * k;
@@ -170,8 +187,8 @@ extern "C" int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, flo
   if (ppb < 1024) ppb = 1024;
   dim3 grid(irr_cdiv(hw, ppb), Cin, B);
 #define IRR_SMALL_WG(N, K)                                                                                        \
-  hipLaunchKernelGGL((conv_smallco_wgrad_kernel<N, K>), grid, dim3(256), 0, st, x, gy, ws, B, Cin, H, W, dil, x_bs, \
-                     gy_bs, (int)ppb)
+  hipLaunchKernelGGL((conv_smallco_wgrad_kernel<N, K>), grid, dim3(256), 0, st, x, gy, ws, gbias, B, Cin, H, W, dil, \
+                     x_bs, gy_bs, (int)ppb)
   if (k == 3) {
     switch (Cout) { case 1: IRR_SMALL_WG(1, 3); break; case 2: IRR_SMALL_WG(2, 3); break;
                     case 3: IRR_SMALL_WG(3, 3); break; default: IRR_SMALL_WG(4, 3); break; }

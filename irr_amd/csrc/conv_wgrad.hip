@@ -16,6 +16,9 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef WG_ISSUE_MODE
+#define WG_ISSUE_MODE 0   // 0: next-stage loads interleaved with the k-steps, 1: all issued before the k-loop
+#endif
 #ifndef WG_ABL
 #define WG_ABL 0      // ablation builds only (tools/): 1 = no global loads, 2 = + no LDS writes, 3 = + no barriers
 #endif
@@ -31,6 +34,7 @@ struct WgArgs {
   const float* x;
   const float* gy;
   float* gw;                    // workspace, [Cout][KK][Cin]
+  float* gbias;                 // optional: gbias[co] += sum of gy over pixels (taken from the staged gy tiles)
   int B, Cin, H, W, Cout, OH, OW;
   int stride, dil, pad;
   long x_bs, gy_bs;
@@ -102,6 +106,10 @@ __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a
   const uint32_t gsc = (uint32_t)((long)NA * ohw * 4);
 
   float stg[NR];
+  const bool want_bias = do_a && a.gbias != nullptr && blockIdx.y == 0;   // one ci-tile column sums the gy tiles
+  float bsum[NRA];
+#pragma unroll
+  for (int ia = 0; ia < NRA; ++ia) bsum[ia] = 0.f;
   uint32_t xv[KK];                              // per-tap voffset of this lane's pixel (+ half-wave channel)
   uint32_t gv = OOB;
   auto decode = [&](long c) {
@@ -147,7 +155,10 @@ __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a
 #pragma unroll
       for (int ia = 0; ia < NRA; ++ia) {
         const int row = 2 * wa + half + ia * NA;
-        if (2 * wa + ia * NA < AROWS) S[row][px] = stg[((NW == 1) ? NRB : 0) + ia];
+        if (2 * wa + ia * NA < AROWS) {
+          S[row][px] = stg[((NW == 1) ? NRB : 0) + ia];
+          if (want_bias) bsum[ia] += stg[((NW == 1) ? NRB : 0) + ia];
+        }
       }
     }
   };
@@ -180,6 +191,17 @@ __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a
       }
 #pragma unroll
       for (int t = 0; t < KS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+    }
+  }
+
+  if (want_bias) {
+#pragma unroll
+    for (int ia = 0; ia < NRA; ++ia) {
+      float v = bsum[ia];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);          // reduce over the 32 pixels of the half-wave
+      const int co = co0 + 2 * wa + half + ia * NA;
+      if (px == 0 && 2 * wa + ia * NA < AROWS && co < a.Cout) unsafeAtomicAdd(a.gbias + co, v);
     }
   }
 
@@ -253,6 +275,10 @@ __global__ __launch_bounds__(MTB * 3 * 64) void conv_wgrad_halo_kernel(const WgA
   const uint32_t xsc = (uint32_t)((long)NB * hw * 4);
 
   float stg[NR];
+  const bool want_bias = !do_b && a.gbias != nullptr && blockIdx.y == 0;
+  float bsum[NRA];
+#pragma unroll
+  for (int i = 0; i < NRA; ++i) bsum[i] = 0.f;
   uint32_t xv[TR + 2];                           // x stagers: voffset of halo row hr at this lane's halo column
   uint32_t gv[TR];                               // gy stagers: voffset of tile row r at this lane's column
   auto decode = [&](long c) {
@@ -309,7 +335,10 @@ __global__ __launch_bounds__(MTB * 3 * 64) void conv_wgrad_halo_kernel(const WgA
       for (int i = 0; i < NRA; ++i) {
         const int q = 2 * wa + half + i * NA;
         const int row = q / TR, r = q - row * TR;
-        if (q < ALOADS) SA[row][r * 32 + hl] = stg[i];
+        if (q < ALOADS) {
+          SA[row][r * 32 + hl] = stg[i];
+          if (want_bias) bsum[i] += stg[i];
+        }
       }
     }
   };
@@ -327,6 +356,12 @@ __global__ __launch_bounds__(MTB * 3 * 64) void conv_wgrad_halo_kernel(const WgA
     if (WG_ABL < 3) __syncthreads();
     const bool more = c + 1 < c_end;
     if (more) decode(c + 1);
+#if WG_ISSUE_MODE == 1
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) issue1(i);
+    }
+#endif
     const float* arow = &SA[wm * 32 + j][half];
     const float* brow = &SB[j][ty_w * 32 + half];
 #pragma unroll
@@ -336,13 +371,32 @@ __global__ __launch_bounds__(MTB * 3 * 64) void conv_wgrad_halo_kernel(const WgA
       float bv[KS];
 #pragma unroll
       for (int t = 0; t < KS; ++t) bv[t] = brow[r * 32 + 2 * cpair + t];
+#if WG_ISSUE_MODE == 0
       if (more) {
 #pragma unroll
         for (int u = 0; u < PER; ++u)
           if (k * PER + u < NR) issue1(k * PER + u);
       }
+#elif WG_ISSUE_MODE == 2
+      if (more) {                              // evenly spread over the whole stage
+#pragma unroll
+        for (int i = (k * NR) / KSTEPS; i < ((k + 1) * NR) / KSTEPS; ++i) issue1(i);
+      }
+#endif
 #pragma unroll
       for (int t = 0; t < KS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+    }
+  }
+
+  if (want_bias) {
+#pragma unroll
+    for (int i = 0; i < NRA; ++i) {
+      float v = bsum[i];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      const int q = 2 * wa + half + i * NA;
+      const int co = co0 + q / TR;
+      if (hl == 0 && q < ALOADS && co < a.Cout) unsafeAtomicAdd(a.gbias + co, v);
     }
   }
 
@@ -509,7 +563,8 @@ __global__ __launch_bounds__(256) void dgrad_strided_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, int B, int Cin, int H, int W,
+extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, int B, int Cin, int H,
+                                    int W,
                                     int Cout, int OH, int OW, int k, int stride, int dil, long x_bs, long gy_bs,
                                     void* stream) {
   if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return IRR_EINVAL;
@@ -517,7 +572,7 @@ extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
   WgArgs a;
   const long n = (long)Cout * Cin * k * k;
   IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, (hipStream_t)stream));
-  a.x = x; a.gy = gy; a.gw = ws;
+  a.x = x; a.gy = gy; a.gw = ws; a.gbias = gbias;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW;
   a.stride = stride; a.dil = dil; a.pad = ((k - 1) * dil) / 2;
   a.x_bs = x_bs; a.gy_bs = gy_bs; a.chunks_per_block = 0;
