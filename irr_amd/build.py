@@ -29,6 +29,10 @@ if os.environ.get("IRR_WG_ISSUE"):
     COMMON = COMMON + ["-DWG_ISSUE_MODE=" + os.environ["IRR_WG_ISSUE"]]
 if os.environ.get("IRR_CONV_D"):
     COMMON = COMMON + ["-DCONV_PREFETCH_D=" + os.environ["IRR_CONV_D"]]
+if os.environ.get("IRR_CONV_ABL"):
+    COMMON = COMMON + ["-DCONV_ABL=" + os.environ["IRR_CONV_ABL"]]
+if os.environ.get("IRR_CONV_ORDER"):
+    COMMON = COMMON + ["-DCONV_ORDER=" + os.environ["IRR_CONV_ORDER"]]
 EXTRA = {"warp.hip": ["-ffp-contract=off"], "resize.hip": ["-ffp-contract=off"]}
 
 

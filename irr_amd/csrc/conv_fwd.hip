@@ -19,6 +19,12 @@
 // The same kernel computes the stride-1 data gradient when fed transposed+flipped packed weights.
 #include "common.h"
 
+#ifndef CONV_ORDER
+#define CONV_ORDER 0        // 0: auto (see REFILL_AFTER), 1: always refill after the MFMAs, 2: always before
+#endif
+#ifndef CONV_ABL
+#define CONV_ABL 0          // ablation builds only: 1 = no activation loads, 2 = no activation and no weight loads
+#endif
 #ifndef CONV_PREFETCH_D
 #define CONV_PREFETCH_D 3   // must divide 9
 #endif
@@ -51,6 +57,9 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, uint32_t vo
 template <int MT, int NT, int KS>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
   constexpr int KK = KS * KS;
+  // ring refill placement: with >= 2 co-tiles the MFMAs of a step are issued first and the refill loads ride
+  // in their shadow (measured +8 % on the 565->128 level-4 conv); single co-tile variants keep load-first.
+  constexpr bool REFILL_AFTER = (CONV_ORDER == 1) || (CONV_ORDER == 0 && MT >= 2);
   constexpr int D = (KK == 9) ? CONV_PREFETCH_D : 1;          // prefetch distance in k-steps (ring slots)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -116,9 +125,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
     const uint32_t xs = (cpc == ncp - 1 && (a.Cin & 1)) ? x_last : (uint32_t)cpc * xstep;
     const uint32_t ws = (uint32_t)cpc * wstep + (uint32_t)tap * cop_bytes2;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) ra[slot][m] = buf_load(wr, aoff + m * 128, ws);
+    for (int m = 0; m < MT; ++m) ra[slot][m] = (CONV_ABL >= 2) ? 0.5f + m : buf_load(wr, aoff + m * 128, ws);
 #pragma unroll
-    for (int s = 0; s < NT; ++s) rb[slot][s] = buf_load(xr, voff[s][tap], xs);
+    for (int s = 0; s < NT; ++s) rb[slot][s] = (CONV_ABL >= 1) ? 0.25f + s : buf_load(xr, voff[s][tap], xs);
   };
 
 #pragma unroll
@@ -135,14 +144,20 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
       for (int s = 0; s < NT; ++s) bv[s] = valid[s][tap] ? rb[slot][s] : 0.f;
       const int ntap = tap + D;
       __builtin_amdgcn_sched_barrier(0);      // keep the software pipeline: consume slot -> refill slot -> MFMAs
-      issue(slot, ntap >= KK ? cp + 1 : cp, ntap >= KK ? ntap - KK : ntap);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!REFILL_AFTER) {
+        issue(slot, ntap >= KK ? cp + 1 : cp, ntap >= KK ? ntap - KK : ntap);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int s = 0; s < NT; ++s)
           acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[s], acc[m][s], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (REFILL_AFTER) {
+        issue(slot, ntap >= KK ? cp + 1 : cp, ntap >= KK ? ntap - KK : ntap);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
