@@ -16,9 +16,6 @@
 #include "common.h"
 #include <stdlib.h>
 
-#ifndef WG_ISSUE_MODE
-#define WG_ISSUE_MODE 0   // 0: next-stage loads interleaved with the k-steps, 1: all issued before the k-loop
-#endif
 #ifndef WG_ABL
 #define WG_ABL 0      // ablation builds only (tools/): 1 = no global loads, 2 = + no LDS writes, 3 = + no barriers
 #endif
@@ -184,13 +181,17 @@ __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a
       float bv[KS];
 #pragma unroll
       for (int t = 0; t < KS; ++t) bv[t] = brow[t * 32 * PITCH + 2 * k];
-      if (more) {                              // next stage's loads ride along with the MFMAs
+      // next stage's loads are threaded between the MFMAs of the k-step (an in-order wave that has to wait
+      // for a slot in the memory pipeline then delays one MFMA, not three)
 #pragma unroll
-        for (int u = 0; u < PER; ++u)
-          if (k * PER + u < NR) issue1(k * PER + u);
+      for (int t = 0; t < KS; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+        if (more) {
+#pragma unroll
+          for (int u = t; u < PER; u += KS)
+            if (k * PER + u < NR) issue1(k * PER + u);
+        }
       }
-#pragma unroll
-      for (int t = 0; t < KS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
     }
   }
 
@@ -356,12 +357,6 @@ __global__ __launch_bounds__(MTB * 3 * 64) void conv_wgrad_halo_kernel(const WgA
     if (WG_ABL < 3) __syncthreads();
     const bool more = c + 1 < c_end;
     if (more) decode(c + 1);
-#if WG_ISSUE_MODE == 1
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < NR; ++i) issue1(i);
-    }
-#endif
     const float* arow = &SA[wm * 32 + j][half];
     const float* brow = &SB[j][ty_w * 32 + half];
 #pragma unroll
@@ -371,20 +366,15 @@ __global__ __launch_bounds__(MTB * 3 * 64) void conv_wgrad_halo_kernel(const WgA
       float bv[KS];
 #pragma unroll
       for (int t = 0; t < KS; ++t) bv[t] = brow[r * 32 + 2 * cpair + t];
-#if WG_ISSUE_MODE == 0
-      if (more) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u)
-          if (k * PER + u < NR) issue1(k * PER + u);
+      for (int t = 0; t < KS; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+        if (more) {                            // next stage's loads threaded between the MFMAs
+#pragma unroll
+          for (int u = t; u < PER; u += KS)
+            if (k * PER + u < NR) issue1(k * PER + u);
+        }
       }
-#elif WG_ISSUE_MODE == 2
-      if (more) {                              // evenly spread over the whole stage
-#pragma unroll
-        for (int i = (k * NR) / KSTEPS; i < ((k + 1) * NR) / KSTEPS; ++i) issue1(i);
-      }
-#endif
-#pragma unroll
-      for (int t = 0; t < KS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
     }
   }
 
