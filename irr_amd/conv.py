@@ -378,3 +378,90 @@ def dense_estimator(x, base, weights_and_biases):
     if not x.is_cuda:
         raise RuntimeError("irr_amd conv runs on the HIP device only (no CPU fallback)")
     return _DenseEstimatorFn.apply(x, base, *weights_and_biases)
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd: a sequential chain of conv() blocks as ONE node
+# ----------------------------------------------------------------------------------------------
+class _ConvChainFn(torch.autograd.Function):
+    """y = [res +] conv_n(... conv_1(x)) for the purely sequential sub-networks (ContextNetwork /
+    OccContextNetwork, models/pwc_modules.py:210-243; the 7-conv stacks of RefineFlow / RefineOcc,
+    models/irr_modules.py:71-79,115-123; the (stride-2, stride-1) pairs of FeatureExtractor,
+    models/pwc_modules.py:91-96).
+
+    Backward walks the chain with no elementwise pass over the activations: the data-gradient launch of
+    layer i multiplies its result by LeakyReLU'(a_{i-1}) in its epilogue, so it directly yields the
+    pre-activation gradient layer i-1 needs, and every bias gradient comes out of the wgrad launch."""
+
+    @staticmethod
+    def forward(ctx, x, res, cfg, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        x = x if _planes_dense(x) else x.contiguous()
+        acts = []
+        cur = x
+        n = len(ws)
+        for i in range(n):
+            stride, dil, lrelu = cfg[i]
+            last = i == n - 1
+            if last and res is not None:
+                res_c = res if _planes_dense(res) else res.contiguous()
+                if lrelu:
+                    a = conv_forward(cur, ws[i], bs[i], stride, dil, True)      # keep the activation for its mask
+                    acts.append(a)
+                    cur = torch.add(res_c, a)
+                else:
+                    cur = conv_forward(cur, ws[i], bs[i], stride, dil, False, res=res_c)
+                    acts.append(None)
+            else:
+                cur = conv_forward(cur, ws[i], bs[i], stride, dil, lrelu)
+                acts.append(cur)
+        ctx.cfg = cfg
+        ctx.has_res = res is not None
+        ctx.weight_objs = ws
+        ctx.save_for_backward(x, *[a for a in acts[:-1]], *( [acts[-1]] if cfg[-1][2] else [] ))
+        return cur
+
+    @staticmethod
+    def backward(ctx, gy):
+        cfg = ctx.cfg
+        n = len(cfg)
+        saved = ctx.saved_tensors
+        x = saved[0]
+        acts = list(saved[1:n])                               # a_0 .. a_{n-2}
+        a_last = saved[n] if cfg[-1][2] else None
+        ws = ctx.weight_objs
+        gy = gy if _planes_dense(gy) else gy.contiguous()
+        gres = gy if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        dev = gy.device
+        g = gy
+        if cfg[-1][2]:                                        # activation on the chain output: one pass on a small tensor
+            gpre = torch.empty_like(gy)
+            lrelu_bwd_bias(gy, a_last, True, gpre, None)
+            g = gpre
+        grads = [None] * (2 * n)
+        for i in range(n - 1, -1, -1):
+            stride, dil, _ = cfg[i]
+            inp = acts[i - 1] if i > 0 else x
+            gb = torch.zeros(ws[i].shape[0], device=dev, dtype=torch.float32)
+            grads[2 * i] = conv_wgrad(inp, g, ws[i].shape, stride, dil, gbias=gb)
+            grads[2 * i + 1] = gb
+            if i > 0:
+                prev_lrelu = cfg[i - 1][2]
+                g = conv_dgrad(g, ws[i], stride, dil, inp.shape[2:], mask=inp if prev_lrelu else None,
+                               nmask=inp.shape[1] if prev_lrelu else 0)
+            elif ctx.needs_input_grad[0]:
+                g = conv_dgrad(g, ws[i], stride, dil, inp.shape[2:])
+            else:
+                g = None
+        return (g, gres, None) + tuple(grads)
+
+
+def conv_chain(x, layers, res=None):
+    """layers: sequence of modules exposing .weight, .bias, .stride, .dilation, .is_relu (modules.ConvBlock)."""
+    if not x.is_cuda:
+        raise RuntimeError("irr_amd conv runs on the HIP device only (no CPU fallback)")
+    cfg = tuple((int(l.stride), int(l.dilation), bool(l.is_relu)) for l in layers)
+    wb = []
+    for l in layers:
+        wb += [l.weight, l.bias]
+    return _ConvChainFn.apply(x, res, cfg, *wb)

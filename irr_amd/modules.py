@@ -87,7 +87,7 @@ class FeatureExtractor(nn.Module):
     def forward(self, x):
         pyramid = []
         for pair in self.convs:
-            x = pair[1](pair[0](x))
+            x = C.conv_chain(x, [pair[0], pair[1]])
             pyramid.append(x)
         return pyramid[::-1]
 
@@ -152,9 +152,7 @@ class _Context(nn.Module):
             conv(96, 64, 3, 1, 16), conv(64, 32, 3, 1, 1), conv(32, ch_out, isReLU=False))
 
     def forward(self, x, res=None):
-        for layer in list(self.convs)[:-1]:
-            x = layer(x)
-        return self.convs[6](x, res=res)                 # optional fused "est + context(...)"
+        return C.conv_chain(x, list(self.convs), res=res)     # optional fused "est + context(...)"
 
 
 class ContextNetwork(_Context):
@@ -217,7 +215,7 @@ class RefineFlow(_Refine):
     def forward(self, flow, diff_img, feature, scale=(1.0, 1.0)):
         flow_m = subtract_mean(flow)
         norm2_img = torch.linalg.vector_norm(diff_img, ord=2, dim=1, keepdim=True)
-        feat = self.convs(torch.cat([flow_m, norm2_img, feature], dim=1))
+        feat = C.conv_chain(torch.cat([flow_m, norm2_img, feature], dim=1), list(self.convs))
         return Fn.refine_tail(feat, flow, scale)
 
 
@@ -225,5 +223,5 @@ class RefineOcc(_Refine):
     """models/irr_modules.py:107-139."""
 
     def forward(self, occ, feat1, feat2):
-        feat = self.convs(torch.cat([occ, feat1, feat2], dim=1))
+        feat = C.conv_chain(torch.cat([occ, feat1, feat2], dim=1), list(self.convs))
         return Fn.refine_tail(feat, occ, (1.0, 1.0))
