@@ -138,10 +138,12 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
 
 def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in_hw: Tuple[int, int],
                gx: Optional[torch.Tensor] = None, accumulate: bool = False,
-               mask: Optional[torch.Tensor] = None, nmask: int = 0) -> torch.Tensor:
+               mask: Optional[torch.Tensor] = None, nmask: int = 0,
+               res: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
     """gx (+)= conv_transpose(gy, weight); gy must already carry the activation derivative.
     mask/nmask: afterwards gx[:, :nmask] *= LeakyReLU'(mask[:, :nmask]) in the same launch (mask = the saved
-    activation that produced this conv's input), i.e. gx comes out as a PRE-activation gradient."""
+    activation that produced this conv's input), i.e. gx comes out as a PRE-activation gradient.
+    res/alpha: gx = res + alpha * conv_transpose(...) (residual branches: the skip gradient is added in the epilogue)."""
     B, cout, oh, ow = gy.shape
     cout_w, cin, k, _ = weight.shape
     assert cout == cout_w
@@ -149,6 +151,8 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
     if gx is None:
         gx = torch.empty(B, cin, H, W, device=gy.device, dtype=torch.float32)
         accumulate = False
+    if (res is not None or alpha != 1.0) and not (stride == 1 and cout >= 1 and BACKEND != "miopen"):
+        raise ValueError("res/alpha epilogue is only wired for stride-1 data gradients")
     if BACKEND == "miopen":
         v = torch.nn.grad.conv2d_input((B, cin, H, W), weight.detach(), gy, stride=stride,
                                        padding=((k - 1) * dil) // 2, dilation=dil)
@@ -167,8 +171,9 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         cout = 2
     if stride == 1 and cout >= 2:
         wp = packed_weights(weight, True)
-        args = ("irr_conv2d_fwd_f32", hip.ptr(gy), hip.ptr(wp), None, None, hip.ptr(gx), B, cout, oh, ow, cin, H, W,
-                k, 1, dil, hip.bs(gy), hip.bs(gx), 0, 0, 1.0, int(accumulate), *margs, hip.stream())
+        args = ("irr_conv2d_fwd_f32", hip.ptr(gy), hip.ptr(wp), None, hip.ptr(res), hip.ptr(gx), B, cout, oh, ow, cin, H, W,
+                k, 1, dil, hip.bs(gy), hip.bs(gx), hip.bs(res) if res is not None else 0, 0, float(alpha),
+                int(accumulate), *margs, hip.stream())
         if TIMER is None:
             hip.call(*args)
         else:
@@ -465,3 +470,89 @@ def conv_chain(x, layers, res=None):
     for l in layers:
         wb += [l.weight, l.bias]
     return _ConvChainFn.apply(x, res, cfg, *wb)
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd: OccUpsampleNetwork (models/irr_modules.py:30-56) as ONE node
+# ----------------------------------------------------------------------------------------------
+class _OccUpsampleFn(torch.autograd.Function):
+    """x_in -> init_conv -> 3 x [x += 0.1 * res_convs(x)] (shared weights) -> x_init + res_end_conv(x) -> out_convs + occ.
+
+    The network runs on 32-channel maps at 1/2 and full resolution (41 % of all conv activation traffic,
+    SURVEY.md Appendix A (iv)), so elementwise passes are expensive here.  The backward therefore uses the
+    epilogue features of the MFMA data-gradient launch for every skip connection and activation:
+    ``g_x = g_y + dgrad(...)`` (res), ``0.1 *`` (alpha), ``*= LeakyReLU'(t)`` (mask) and ``+=`` (accumulate);
+    bias gradients come from the wgrad launches."""
+
+    @staticmethod
+    def forward(ctx, occ_up, x_in, w_init, b_init, w_r0, b_r0, w_r1, b_r1, w_end, b_end, w_out, b_out, mul_const):
+        x_in = x_in if _planes_dense(x_in) else x_in.contiguous()
+        occ_up = occ_up if _planes_dense(occ_up) else occ_up.contiguous()
+        x_init = conv_forward(x_in, w_init, b_init, 1, 1, True)
+        xs = [x_init]
+        ts = []
+        for _ in range(3):
+            t = conv_forward(xs[-1], w_r0, b_r0, 1, 1, True)
+            ts.append(t)
+            xs.append(conv_forward(t, w_r1, b_r1, 1, 1, False, res=xs[-1], alpha=mul_const))
+        e = conv_forward(xs[-1], w_end, b_end, 1, 1, True)
+        x2 = torch.add(x_init, e)
+        o = conv_forward(x2, w_out, b_out, 1, 1, True)
+        out = torch.add(o, occ_up)
+        ctx.mul_const = mul_const
+        ctx.wobjs = (w_init, w_r0, w_r1, w_end, w_out)
+        ctx.save_for_backward(x_in, xs[0], xs[1], xs[2], xs[3], ts[0], ts[1], ts[2], e, x2, o)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x_in, x0, x1, x2r, x3, t1, t2, t3, e, x2, o = ctx.saved_tensors
+        w_init, w_r0, w_r1, w_end, w_out = ctx.wobjs
+        mc = ctx.mul_const
+        dev = g_out.device
+        hw_ = x0.shape[2:]
+        g_out = g_out if _planes_dense(g_out) else g_out.contiguous()
+        z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)
+        # out = occ_up + lrelu(conv_out(x2))
+        gpre_o = torch.empty_like(g_out)
+        gb_out = z(w_out.shape[0])
+        lrelu_bwd_bias(g_out, o, True, gpre_o, gb_out)                       # 1-channel tensor
+        gw_out = conv_wgrad(x2, gpre_o, w_out.shape, 1, 1)
+        g_x2 = conv_dgrad(gpre_o, w_out, 1, 1, hw_)                          # (B,32,H,W); also the gradient of x_init via the skip
+        # x2 = x_init + e, e = lrelu(conv_end(x3))
+        gpre_e = torch.empty_like(g_x2)
+        gb_end = z(w_end.shape[0])
+        lrelu_bwd_bias(g_x2, e, True, gpre_e, gb_end)
+        gw_end = conv_wgrad(x3, gpre_e, w_end.shape, 1, 1)
+        g_x = conv_dgrad(gpre_e, w_end, 1, 1, hw_)                           # gradient w.r.t. x3
+        # three residual blocks with shared weights: x_i = x_{i-1} + mc * conv_r1(t_i), t_i = lrelu(conv_r0(x_{i-1}))
+        gw_r0 = torch.zeros_like(w_r0)
+        gw_r1 = torch.zeros_like(w_r1)
+        gb_r0, gb_r1 = z(w_r0.shape[0]), z(w_r1.shape[0])
+        xs = [x0, x1, x2r]
+        ts = [t1, t2, t3]
+        for i in (2, 1, 0):
+            conv_wgrad(ts[i], g_x, w_r1.shape, 1, 1, gw=gw_r1, gbias=gb_r1)      # scaled by mc once, below
+            gpre_t = conv_dgrad(g_x, w_r1, 1, 1, hw_, mask=ts[i], nmask=ts[i].shape[1], alpha=mc)
+            conv_wgrad(xs[i], gpre_t, w_r0.shape, 1, 1, gw=gw_r0, gbias=gb_r0)
+            if i > 0:
+                g_x = conv_dgrad(gpre_t, w_r0, 1, 1, hw_, res=g_x)                # skip + branch in one launch
+            else:
+                # x_0 = x_init: add the x2 skip gradient (accumulate into g_x2) and apply init_conv's LeakyReLU'
+                conv_dgrad(gpre_t, w_r0, 1, 1, hw_, gx=g_x2, accumulate=True, res=g_x, mask=x0, nmask=x0.shape[1])
+        gw_r1 *= mc
+        gb_r1 *= mc
+        gpre_init = g_x2
+        gb_init = z(w_init.shape[0])
+        gw_init = conv_wgrad(x_in, gpre_init, w_init.shape, 1, 1, gbias=gb_init)
+        g_xin = conv_dgrad(gpre_init, w_init, 1, 1, hw_) if ctx.needs_input_grad[1] else None
+        g_occ_up = g_out if ctx.needs_input_grad[0] else None
+        return (g_occ_up, g_xin, gw_init, gb_init, gw_r0, gb_r0, gw_r1, gb_r1, gw_end, gb_end, gw_out, gb_out, None)
+
+
+def occ_upsample_net(occ_up, x_in, mod):
+    """mod: modules.OccUpsampleNetwork.  occ_up = nearest-x2 occlusion map, x_in = cat([occ_up, guide])."""
+    return _OccUpsampleFn.apply(occ_up, x_in, mod.init_conv.weight, mod.init_conv.bias, mod.res_convs[0].weight,
+                                mod.res_convs[0].bias, mod.res_convs[1].weight, mod.res_convs[1].bias,
+                                mod.res_end_conv.weight, mod.res_end_conv.bias, mod.out_convs.weight, mod.out_convs.bias,
+                                float(mod.mul_const))

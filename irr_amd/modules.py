@@ -186,12 +186,7 @@ class OccUpsampleNetwork(nn.Module):
         if occ.shape[2:] != x.shape[2:]:
             raise ValueError("IRR-PWC input height/width must be multiples of 64 (models/irr_modules.py:24-25 "
                              "bilinear fallback is not implemented)")
-        x_init = self.init_conv(torch.cat([occ, x], dim=1))
-        x_res = x_init
-        for _ in range(3):                                # shared weights, applied 3x
-            x_res = self.res_convs[1](self.res_convs[0](x_res), res=x_res, alpha=self.mul_const)
-        x_init = self.res_end_conv(x_res, res=x_init)
-        return self.out_convs(x_init, res=occ)
+        return C.occ_upsample_net(occ, torch.cat([occ, x], dim=1), self)
 
 
 def subtract_mean(t):
