@@ -296,6 +296,30 @@ def gen_pwcnet_plumbing(out_dir):
                         stats=np.array([float(o["flow"].mean()), float(o["flow"].abs().mean())]))
 
 
+
+
+def gen_noise_floor(out_dir, B=2, H=128, W=192):
+    """Reference self-noise in as-is mode (mask >= 1.0): the SAME reference model evaluated with 8 and with 1
+    CPU threads (different summation orders inside MKL-DNN) -- the yardstick for as-is parity (SURVEY finding 4)."""
+    P = O.synthetic_params(0)
+    batch = O.synthetic_batch(B, H, W, 1234)
+    res = {}
+    for mode, robust in (("asis", False), ("robust", True)):
+        set_mode(False, robust)
+        m, _ = ref_model(P)
+        m.eval()
+        outs = []
+        for th in (8, 1):
+            torch.set_num_threads(th)
+            with torch.no_grad():
+                outs.append(m({"input1": batch["input1"], "input2": batch["input2"]})["flow"])
+        torch.set_num_threads(8)
+        res[f"{mode}_self_epe_8thr_vs_1thr"] = np.array([float(torch.norm(outs[0] - outs[1], dim=1).mean())])
+    set_mode(False, False)
+    np.savez_compressed(os.path.join(out_dir, "noise_floor.npz"), **res)
+    print({k: float(v[0]) for k, v in res.items()})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
@@ -303,10 +327,11 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
-    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "pwcnet": gen_pwcnet_plumbing}
+    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "pwcnet": gen_pwcnet_plumbing, "noise": gen_noise_floor}
     for k, fn in steps.items():
         if a.only and k not in a.only.split(","):
             continue
         print("generating", k, flush=True)
         fn(a.out)
     print("done")
+
