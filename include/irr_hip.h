@@ -170,6 +170,24 @@ int irr_upsample_nearest2x_fwd_f32(const float* x, float* out, int B, int C, int
 int irr_upsample_nearest2x_bwd_f32(const float* gout, float* gx, int B, int C, int H, int W,
                                    long gout_bs, long gx_bs, void* stream);
 
+/* ---- multi-scale loss, per-pixel parts (losses.py:8-18, 39-48, 515-577) ------------------------------------
+ * The scalar algebra (level weights 0.32..0.0003125, flow/occ balancing) stays on the host side; these entry points
+ * do everything that touches pixels.
+ *   irr_avgpool_f32      out = scale * s x s mean of in  (== adaptive_avg_pool2d for the integer ratios 1..64), in (BC,h*s,w*s)
+ *   irr_epe_sum_fwd      *out += weight * sum_{b,p} || tgt - flow ||_2            flow, tgt: (B,2,h,w)
+ *   irr_epe_sum_bwd      gflow = gscale[0]*weight * (flow - tgt)/||.||            (0 where the norm is 0)
+ *   irr_f1bal_sums       sums[b][0..3] += { -sum t log(s+eps), -sum (1-t) log(1-s+eps), sum t, sum s },  s = sigmoid(logit)
+ *   irr_f1bal_bwd        glogit = gscale[0]*weight * d/dlogit [ tp/(st+sp+eps) + fn/((N-st)+(N-sp)+eps) ]
+ * gscale is a 1-element DEVICE array (the upstream gradient times the balancing weight), so nothing syncs. */
+int irr_avgpool_f32(const float* in, float* out, int BC, int h, int w, int s, float scale, void* stream);
+int irr_epe_sum_fwd_f32(const float* flow, const float* tgt, float* out, int B, int HW, long flow_bs, long tgt_bs,
+                        float weight, void* stream);
+int irr_epe_sum_bwd_f32(const float* flow, const float* tgt, const float* gscale, float* gflow, int B, int HW,
+                        long flow_bs, long tgt_bs, long g_bs, float weight, void* stream);
+int irr_f1bal_sums_f32(const float* logit, const float* tgt, float* sums, int B, int HW, long l_bs, long t_bs, void* stream);
+int irr_f1bal_bwd_f32(const float* logit, const float* tgt, const float* sums, const float* gscale, float* glogit,
+                      int B, int HW, long l_bs, long t_bs, long g_bs, float weight, void* stream);
+
 /* ---- fused Adam over one flat arena ------------------------------------------------------------------
  * torch.optim.Adam semantics (runtime.py:189; lr 1e-4, weight_decay 4e-4 as L2-in-gradient,
  * scripts/IRR-PWC_flyingChairsOcc.sh:29-31) over n contiguous fp32 elements (16-byte aligned pointers):

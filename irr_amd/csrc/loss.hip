@@ -1,0 +1,165 @@
+// Per-pixel parts of MultiScaleEPE_PWC_Bi_Occ_upsample (losses.py:515-577):
+//   * target pyramid: adaptive_avg_pool2d to each level (losses.py:16-18) == s x s mean for the integer ratios that occur
+//   * flow term:  sum_p || avgpool(target)_p - flow_p ||_2                     (losses.py:8-10, 544-549)
+//   * occ  term:  per-sample sums of f1_score_bal_loss on sigmoid(logits)      (losses.py:39-48, 551-558)
+// Forward kernels reduce to a handful of floats with wave shuffles + one atomic per block; backward kernels are
+// pure elementwise.  The scalar algebra (level weights, flow/occ balancing) stays on the host side.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// out[b,c,y,x] = scale * mean_{s x s} in[b,c,y*s+i,x*s+j]
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int h, int w,
+                                                     int s, float scale, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % w);
+  const long r = i / w;
+  const int y = (int)(r % h);
+  const long bc = r / h;
+  const float* p = in + (bc * h * s + (long)y * s) * ((long)w * s) + (long)x * s;
+  float acc = 0.f;
+  for (int a = 0; a < s; ++a)
+    for (int b = 0; b < s; ++b) acc += p[(long)a * w * s + b];
+  out[i] = scale * acc / (float)(s * s);
+}
+
+// flow, tgt: (B,2,h,w) ; *out += weight * sum_p sqrt(du^2 + dv^2)
+__global__ __launch_bounds__(256) void epe_fwd_kernel(const float* __restrict__ flow, const float* __restrict__ tgt,
+                                                     float* __restrict__ out, long hw, long flow_bs, long tgt_bs, float weight) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const float* f = flow + (long)b * flow_bs;
+  const float* t = tgt + (long)b * tgt_bs;
+  float s = 0.f;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long)gridDim.x * blockDim.x) {
+    const float du = t[p] - f[p], dv = t[hw + p] - f[hw + p];
+    s += sqrtf(du * du + dv * dv);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, weight * s);
+}
+
+// gflow = gscale[0] * weight * (flow - tgt) / epe      (0 where epe == 0, as torch.norm's backward)
+__global__ __launch_bounds__(256) void epe_bwd_kernel(const float* __restrict__ flow, const float* __restrict__ tgt,
+                                                     const float* __restrict__ gscale, float* __restrict__ gflow, long hw,
+                                                     long flow_bs, long tgt_bs, long g_bs, float weight) {
+  const int b = blockIdx.y;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= hw) return;
+  const float* f = flow + (long)b * flow_bs;
+  const float* t = tgt + (long)b * tgt_bs;
+  float* g = gflow + (long)b * g_bs;
+  const float du = f[p] - t[p], dv = f[hw + p] - t[hw + p];
+  const float n = sqrtf(du * du + dv * dv);
+  const float k = n > 0.f ? gscale[0] * weight / n : 0.f;
+  g[p] = k * du;
+  g[hw + p] = k * dv;
+}
+
+// sums[b][0..3] += { -sum t log(s+eps), -sum (1-t) log(1-s+eps), sum t, sum s }   with s = sigmoid(logit)
+__global__ __launch_bounds__(256) void f1_sums_kernel(const float* __restrict__ logit, const float* __restrict__ tgt,
+                                                     float* __restrict__ sums, long hw, long l_bs, long t_bs) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const float* l = logit + (long)b * l_bs;
+  const float* t = tgt + (long)b * t_bs;
+  const float eps = 1e-8f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long)gridDim.x * blockDim.x) {
+    const float s = 1.f / (1.f + expf(-l[p]));
+    const float tt = t[p];
+    a0 -= tt * logf(s + eps);
+    a1 -= (1.f - tt) * logf((1.f - s) + eps);
+    a2 += tt;
+    a3 += s;
+  }
+  a0 = block_sum(a0, red);
+  a1 = block_sum(a1, red);
+  a2 = block_sum(a2, red);
+  a3 = block_sum(a3, red);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(sums + b * 4 + 0, a0);
+    unsafeAtomicAdd(sums + b * 4 + 1, a1);
+    unsafeAtomicAdd(sums + b * 4 + 2, a2);
+    unsafeAtomicAdd(sums + b * 4 + 3, a3);
+  }
+}
+
+// loss_b = c * ( tp/D1 + fn/D2 ), D1 = st+sp+eps, D2 = 2N-st-sp+eps ; glogit = gscale[0]*weight * dloss/ds * s(1-s)
+__global__ __launch_bounds__(256) void f1_bwd_kernel(const float* __restrict__ logit, const float* __restrict__ tgt,
+                                                    const float* __restrict__ sums, const float* __restrict__ gscale,
+                                                    float* __restrict__ glogit, long hw, long l_bs, long t_bs, long g_bs,
+                                                    float weight) {
+  const int b = blockIdx.y;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= hw) return;
+  const float eps = 1e-8f;
+  const float tp = sums[b * 4 + 0], fn = sums[b * 4 + 1], st = sums[b * 4 + 2], sp = sums[b * 4 + 3];
+  const float N = (float)hw;
+  const float D1 = st + sp + eps, D2 = (N - st) + (N - sp) + eps;
+  const float s = 1.f / (1.f + expf(-logit[(long)b * l_bs + p]));
+  const float tt = tgt[(long)b * t_bs + p];
+  const float dls = -tt / ((s + eps) * D1) - tp / (D1 * D1) + (1.f - tt) / (((1.f - s) + eps) * D2) + fn / (D2 * D2);
+  glogit[(long)b * g_bs + p] = gscale[0] * weight * dls * s * (1.f - s);
+}
+
+}  // namespace
+
+extern "C" int irr_avgpool_f32(const float* in, float* out, int BC, int h, int w, int s, float scale, void* stream) {
+  if (!in || !out || BC <= 0 || h <= 0 || w <= 0 || s <= 0) return IRR_EINVAL;
+  const long n = (long)BC * h * w;
+  hipLaunchKernelGGL(avgpool_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, h, w, s, scale, n);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_epe_sum_fwd_f32(const float* flow, const float* tgt, float* out, int B, int HW, long flow_bs,
+                                   long tgt_bs, float weight, void* stream) {
+  if (!flow || !tgt || !out || B <= 0 || HW <= 0 || B > 65535) return IRR_EINVAL;
+  int bx = irr_cdiv(HW, 256 * 8);
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(epe_fwd_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, flow, tgt, out, (long)HW, flow_bs,
+                     tgt_bs, weight);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_epe_sum_bwd_f32(const float* flow, const float* tgt, const float* gscale, float* gflow, int B, int HW,
+                                   long flow_bs, long tgt_bs, long g_bs, float weight, void* stream) {
+  if (!flow || !tgt || !gscale || !gflow || B <= 0 || HW <= 0 || B > 65535) return IRR_EINVAL;
+  hipLaunchKernelGGL(epe_bwd_kernel, dim3(irr_cdiv(HW, 256), B), dim3(256), 0, (hipStream_t)stream, flow, tgt, gscale,
+                     gflow, (long)HW, flow_bs, tgt_bs, g_bs, weight);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_f1bal_sums_f32(const float* logit, const float* tgt, float* sums, int B, int HW, long l_bs, long t_bs,
+                                  void* stream) {
+  if (!logit || !tgt || !sums || B <= 0 || HW <= 0 || B > 65535) return IRR_EINVAL;
+  int bx = irr_cdiv(HW, 256 * 8);
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(f1_sums_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, logit, tgt, sums, (long)HW, l_bs, t_bs);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_f1bal_bwd_f32(const float* logit, const float* tgt, const float* sums, const float* gscale,
+                                 float* glogit, int B, int HW, long l_bs, long t_bs, long g_bs, float weight,
+                                 void* stream) {
+  if (!logit || !tgt || !sums || !gscale || !glogit || B <= 0 || HW <= 0 || B > 65535) return IRR_EINVAL;
+  hipLaunchKernelGGL(f1_bwd_kernel, dim3(irr_cdiv(HW, 256), B), dim3(256), 0, (hipStream_t)stream, logit, tgt, sums,
+                     gscale, glogit, (long)HW, l_bs, t_bs, g_bs, weight);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}

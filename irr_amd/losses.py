@@ -2,39 +2,120 @@
 ``losses.MultiScaleEPE_PWC_Bi_Occ_upsample`` (losses.py:515-577): same constructor (``args`` with
 ``batch_size`` and ``model_div_flow``), same ``forward(output_dict, target_dict) -> loss_dict`` keys.
 
-The one semantic change: the data-dependent Python branch ``if f_loss > o_loss`` (losses.py:560-567, a
-device->host sync) is evaluated on the device with ``torch.where`` so the step never blocks and can be
-captured in a hipGraph.  ``reduce_fn`` (optional) all-reduces the two detached scalars across data-parallel
-ranks so the balancing weights equal those of a single-process run on the global batch.
+Everything that touches pixels runs in libirr_hip.so (target pyramid, EPE sums, balanced-F1 sums and their
+gradients, csrc/loss.hip); what remains here is scalar algebra on a handful of device floats.
+
+One semantic change: the data-dependent Python branch ``if f_loss > o_loss`` (losses.py:560-567, a
+device->host sync) is evaluated on the device with ``torch.where`` so the step never blocks.  ``reduce_fn``
+(optional) all-reduces the two detached scalars across data-parallel ranks so the balancing weights equal those
+of a single-process run on the global batch.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as tf
+
+from . import hip
+
+LEVEL_WEIGHTS = [0.32, 0.08, 0.02, 0.01, 0.005, 0.00125, 0.0003125]      # losses.py:522
 
 
-def _elementwise_epe(input_flow, target_flow):
-    return torch.linalg.vector_norm(target_flow - input_flow, ord=2, dim=1, keepdim=True)
+def _need_cuda(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError("irr_amd loss kernels run on the HIP device only (no CPU fallback)")
 
 
-def _downsample2d_as(inputs, target_as):
-    h, w = target_as.shape[2:]
-    return tf.adaptive_avg_pool2d(inputs, [h, w])
+def _dense(t):
+    b, c, h, w = t.shape
+    sb, sc, sh, sw = t.stride()
+    ok = (sw == 1 or w == 1) and (sh == w or h == 1) and (sc == h * w or c == 1)
+    return t if ok else t.contiguous()
 
 
-def f1_score_bal_loss(y_pred, y_true):
-    """losses.py:39-48."""
-    eps = 1e-8
-    tp = -(y_true * torch.log(y_pred + eps)).sum(dim=(1, 2, 3))
-    fn = -((1 - y_true) * torch.log((1 - y_pred) + eps)).sum(dim=(1, 2, 3))
-    denom_tp = y_true.sum(dim=(1, 2, 3)) + y_pred.sum(dim=(1, 2, 3)) + eps
-    denom_fn = (1 - y_true).sum(dim=(1, 2, 3)) + (1 - y_pred).sum(dim=(1, 2, 3)) + eps
-    return ((tp / denom_tp).sum() + (fn / denom_fn).sum()) * y_pred.size(2) * y_pred.size(3) * 0.5
+def avg_pool_to(t: torch.Tensor, h: int, w: int, scale: float = 1.0) -> torch.Tensor:
+    """scale * adaptive_avg_pool2d(t, [h, w]) for integer ratios (losses.py:16-18)."""
+    _need_cuda(t)
+    B, C, H, W = t.shape
+    if H % h or W % w or H // h != W // w:
+        raise ValueError(f"target {H}x{W} is not an integer multiple of level size {h}x{w}")
+    t = t.contiguous()
+    out = torch.empty(B, C, h, w, device=t.device, dtype=torch.float32)
+    hip.call("irr_avgpool_f32", hip.ptr(t), hip.ptr(out), B * C, h, w, H // h, float(scale), hip.stream())
+    return out
+
+
+class _EpeSum(torch.autograd.Function):
+    """weight * sum_p ||tgt - flow||_2  (losses.py:8-10 with .sum())."""
+
+    @staticmethod
+    def forward(ctx, flow, tgt, weight: float):
+        _need_cuda(flow, tgt)
+        flow, tgt = _dense(flow), _dense(tgt)
+        B, _, h, w = flow.shape
+        out = torch.zeros(1, device=flow.device, dtype=torch.float32)
+        hip.call("irr_epe_sum_fwd_f32", hip.ptr(flow), hip.ptr(tgt), hip.ptr(out), B, h * w, hip.bs(flow), hip.bs(tgt),
+                 weight, hip.stream())
+        ctx.weight = weight
+        ctx.save_for_backward(flow, tgt)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        flow, tgt = ctx.saved_tensors
+        B, _, h, w = flow.shape
+        g = g.contiguous()
+        gf = torch.empty(B, 2, h, w, device=flow.device, dtype=torch.float32)
+        hip.call("irr_epe_sum_bwd_f32", hip.ptr(flow), hip.ptr(tgt), hip.ptr(g), hip.ptr(gf), B, h * w, hip.bs(flow),
+                 hip.bs(tgt), hip.bs(gf), ctx.weight, hip.stream())
+        return gf, None, None
+
+
+class _F1BalLoss(torch.autograd.Function):
+    """weight * f1_score_bal_loss(sigmoid(logit), target)  (losses.py:39-48, 553-556)."""
+
+    @staticmethod
+    def forward(ctx, logit, tgt, weight: float):
+        _need_cuda(logit, tgt)
+        logit, tgt = _dense(logit), _dense(tgt)
+        B, _, h, w = logit.shape
+        sums = torch.zeros(B, 4, device=logit.device, dtype=torch.float32)
+        hip.call("irr_f1bal_sums_f32", hip.ptr(logit), hip.ptr(tgt), hip.ptr(sums), B, h * w, hip.bs(logit), hip.bs(tgt),
+                 hip.stream())
+        eps = 1e-8
+        n = float(h * w)
+        tp, fn, st, sp = sums[:, 0], sums[:, 1], sums[:, 2], sums[:, 3]
+        val = ((tp / (st + sp + eps)).sum() + (fn / ((n - st) + (n - sp) + eps)).sum()) * h * w * 0.5
+        ctx.weight = weight * h * w * 0.5
+        ctx.save_for_backward(logit, tgt, sums)
+        return (val * weight).reshape(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        logit, tgt, sums = ctx.saved_tensors
+        B, _, h, w = logit.shape
+        g = g.contiguous()
+        gl = torch.empty(B, 1, h, w, device=logit.device, dtype=torch.float32)
+        hip.call("irr_f1bal_bwd_f32", hip.ptr(logit), hip.ptr(tgt), hip.ptr(sums), hip.ptr(g), hip.ptr(gl), B, h * w,
+                 hip.bs(logit), hip.bs(tgt), hip.bs(gl), ctx.weight, hip.stream())
+        return gl, None, None
+
+
+def balance_and_total(flow_loss, occ_loss, batch_size, reduce_fn=None):
+    """losses.py:560-571 on device scalars: the smaller of the two terms is scaled up to the larger one."""
+    f_loss, o_loss = flow_loss.detach(), occ_loss.detach()
+    if reduce_fn is not None:
+        f_loss, o_loss = reduce_fn(f_loss, o_loss)
+    gt = f_loss > o_loss
+    one = torch.ones_like(f_loss)
+    f_l_w = torch.where(gt, one, o_loss / f_loss)
+    o_l_w = torch.where(gt, f_loss / o_loss, one)
+    return {"flow_loss": flow_loss / batch_size, "occ_loss": occ_loss / batch_size,
+            "total_loss": (flow_loss * f_l_w + occ_loss * o_l_w) / batch_size}
 
 
 def fbeta_score(y_true, y_pred, beta, eps=1e-8):
-    """losses.py:24-37."""
+    """losses.py:24-37 (evaluation metric only)."""
     beta2 = beta ** 2
     y_pred, y_true = y_pred.float(), y_true.float()
     true_positive = (y_pred * y_true).sum(dim=2).sum(dim=2)
@@ -48,57 +129,44 @@ class MultiScaleEPE_PWC_Bi_Occ_upsample(nn.Module):
         super().__init__()
         self._args = args
         self._batch_size = args.batch_size
-        self._weights = [0.32, 0.08, 0.02, 0.01, 0.005, 0.00125, 0.0003125]
+        self._weights = list(LEVEL_WEIGHTS)
         self.occ_activ = nn.Sigmoid()
-        self.f1_score_bal_loss = f1_score_bal_loss
         self._reduce_fn = reduce_fn
 
     def forward(self, output_dict, target_dict):
         loss_dict = {}
         if self.training:
             output_flo, output_occ = output_dict['flow'], output_dict['occ']
-            target_flo_f = self._args.model_div_flow * target_dict["target1"]
-            target_flo_b = self._args.model_div_flow * target_dict["target2"]
-            target_occ_f, target_occ_b = target_dict["target_occ1"], target_dict["target_occ2"]
-
-            flow_loss = 0
-            occ_loss = 0
+            div = float(self._args.model_div_flow)
+            t_flo = (target_dict["target1"], target_dict["target2"])           # div_flow folded into the pooling kernel
+            t_occ = (target_dict["target_occ1"], target_dict["target_occ2"])
             pooled = {}
 
-            def pool(t, key, like):
-                k = (key, like.shape[2], like.shape[3])
-                if k not in pooled:
-                    pooled[k] = _downsample2d_as(t, like)
-                return pooled[k]
+            def pool(kind, idx, like):
+                key = (kind, idx, like.shape[2], like.shape[3])
+                if key not in pooled:
+                    src = t_flo[idx] if kind == "f" else t_occ[idx]
+                    pooled[key] = avg_pool_to(src, like.shape[2], like.shape[3], div if kind == "f" else 1.0)
+                return pooled[key]
 
+            flow_terms, occ_terms = [], []
             for ii, output_ii in enumerate(output_flo):
-                loss_ii = 0
-                for jj in range(0, len(output_ii) // 2):
-                    loss_ii = loss_ii + _elementwise_epe(output_ii[2 * jj], pool(target_flo_f, "ff", output_ii[2 * jj])).sum()
-                    loss_ii = loss_ii + _elementwise_epe(output_ii[2 * jj + 1], pool(target_flo_b, "fb", output_ii[2 * jj + 1])).sum()
-                flow_loss = flow_loss + self._weights[ii] * loss_ii / len(output_ii)
-
+                wgt = self._weights[ii] / len(output_ii)
+                for jj in range(len(output_ii) // 2):
+                    for d in (0, 1):                                              # forward / backward direction
+                        o = output_ii[2 * jj + d]
+                        flow_terms.append(_EpeSum.apply(o, pool("f", d, o), wgt))
             for ii, output_ii in enumerate(output_occ):
-                loss_ii = 0
-                for jj in range(0, len(output_ii) // 2):
-                    output_occ_f = self.occ_activ(output_ii[2 * jj])
-                    output_occ_b = self.occ_activ(output_ii[2 * jj + 1])
-                    loss_ii = loss_ii + self.f1_score_bal_loss(output_occ_f, pool(target_occ_f, "of", output_occ_f))
-                    loss_ii = loss_ii + self.f1_score_bal_loss(output_occ_b, pool(target_occ_b, "ob", output_occ_b))
-                occ_loss = occ_loss + self._weights[ii] * loss_ii / len(output_ii)
-
-            f_loss, o_loss = flow_loss.detach(), occ_loss.detach()
-            if self._reduce_fn is not None:
-                f_loss, o_loss = self._reduce_fn(f_loss, o_loss)
-            gt = f_loss > o_loss                          # losses.py:560-567, evaluated on the device
-            one = torch.ones_like(f_loss)
-            f_l_w = torch.where(gt, one, o_loss / f_loss)
-            o_l_w = torch.where(gt, f_loss / o_loss, one)
-
-            loss_dict["flow_loss"] = flow_loss / self._batch_size
-            loss_dict["occ_loss"] = occ_loss / self._batch_size
-            loss_dict["total_loss"] = (flow_loss * f_l_w + occ_loss * o_l_w) / self._batch_size
+                wgt = self._weights[ii] / len(output_ii)
+                for jj in range(len(output_ii) // 2):
+                    for d in (0, 1):
+                        o = output_ii[2 * jj + d]
+                        occ_terms.append(_F1BalLoss.apply(o, pool("o", d, o), wgt))
+            flow_loss = torch.cat(flow_terms).sum()
+            occ_loss = torch.cat(occ_terms).sum()
+            loss_dict = balance_and_total(flow_loss, occ_loss, self._batch_size, self._reduce_fn)
         else:
-            loss_dict["epe"] = _elementwise_epe(output_dict["flow"], target_dict["target1"]).mean()
+            tgt = target_dict["target1"]
+            loss_dict["epe"] = torch.linalg.vector_norm(tgt - output_dict["flow"], ord=2, dim=1, keepdim=True).mean()
             loss_dict["F1"] = fbeta_score(target_dict["target_occ1"], torch.round(self.occ_activ(output_dict["occ"])), 1)
         return loss_dict

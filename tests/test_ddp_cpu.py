@@ -23,12 +23,13 @@ class Toy(nn.Module):
 
 
 def _loss(model, batch, reduce_fn):
-    import irr_amd
+    """CPU stand-in for the per-pixel terms (those are HIP kernels) + the product's balancing algebra."""
+    from irr_amd.losses import balance_and_total
     flow, occ = model(batch["input1"])
-    out = {"flow": [[flow, flow * 0.5]], "occ": [[occ, occ * 0.5]]}
-    args = types.SimpleNamespace(batch_size=batch["input1"].shape[0], model_div_flow=0.05)
-    lm = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(args, reduce_fn=reduce_fn).train()
-    return lm(out, batch)
+    flow_loss = torch.norm(batch["target1"] - flow, dim=1).sum() + torch.norm(batch["target2"] - 0.5 * flow, dim=1).sum()
+    s = torch.sigmoid(occ)
+    occ_loss = -(batch["target_occ1"] * torch.log(s + 1e-8)).sum() - ((1 - batch["target_occ2"]) * torch.log(1 - s + 1e-8)).sum()
+    return balance_and_total(flow_loss, occ_loss, batch["input1"].shape[0], reduce_fn)
 
 
 def _make_batch(n):
@@ -81,11 +82,7 @@ def test_two_rank_gloo_matches_single_process():
     model = Toy()
     arena = ddp.GradArena(model.named_parameters())
     full = _make_batch(4)
-    import irr_amd
-    flow, occ = model(full["input1"])
-    out = {"flow": [[flow, flow * 0.5]], "occ": [[occ, occ * 0.5]]}
-    lm = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(types.SimpleNamespace(batch_size=4, model_div_flow=0.05)).train()
-    ld = lm(out, full)
+    ld = _loss(model, full, None)
     arena.zero_grad()
     ld["total_loss"].backward()
     assert torch.allclose(arena.flat, res[0][1], rtol=1e-4, atol=1e-6), (arena.flat - res[0][1]).abs().max()
