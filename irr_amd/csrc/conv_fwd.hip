@@ -54,7 +54,11 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, uint32_t vo
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
 }
 
-template <int MT, int NT, int KS>
+// SPLITK (tiny pyramid levels only, MT = NT = 1): the four waves of a block share ONE output tile and each walks
+// a quarter of the channel pairs; partial tiles meet in LDS and wave 0 runs the epilogue.  At 6x7 / 12x14
+// resolution there are too few tiles to fill 1024 SIMDs and a single wave would otherwise run the whole
+// K loop (up to 2547 dependent steps) alone.
+template <int MT, int NT, int KS, bool SPLITK = false>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
   constexpr int KK = KS * KS;
   // Ring refill placement.  Default (CONV_ORDER 3): the refill loads of a k-step are threaded BETWEEN its MFMAs
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
   const long ohw = (long)a.OH * a.OW;
   const long hw = (long)a.H * a.W;
   const long total = (long)a.B * ohw;
-  const long pbase = ((long)blockIdx.x * 4 + wave) * (NT * 32);
+  const long pbase = SPLITK ? (long)blockIdx.x * (NT * 32) : ((long)blockIdx.x * 4 + wave) * (NT * 32);
   if (pbase >= total) return;
   const int cog = blockIdx.y;
 
@@ -132,10 +136,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
     for (int s = 0; s < NT; ++s) rb[slot][s] = (CONV_ABL >= 1) ? 0.25f + s : buf_load(xr, voff[s][tap], xs);
   };
 
+  const int cp_begin = SPLITK ? (ncp * wave) / 4 : 0;
+  const int cp_end = SPLITK ? (ncp * (wave + 1)) / 4 : ncp;
 #pragma unroll
-  for (int d = 0; d < D; ++d) issue(d, d / KK, d % KK);
+  for (int d = 0; d < D; ++d) issue(d, cp_begin + d / KK, d % KK);
 
-  for (int cp = 0; cp < ncp; ++cp) {
+  for (int cp = cp_begin; cp < cp_end; ++cp) {
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) {
       const int slot = tap % D;
@@ -185,6 +191,18 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
       }
 #endif
     }
+  }
+
+  if (SPLITK) {
+    __shared__ float part[3][16][64];
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[wave - 1][r][lane] = acc[0][0][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += (part[0][r][lane] + part[1][r][lane]) + part[2][r][lane];
   }
 
   // ---- epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*half, j = lane&31 ----
@@ -250,9 +268,20 @@ int launch(const ConvArgs& a, hipStream_t st) {
   return e == hipSuccess ? 0 : (int)e;
 }
 
+template <int KS>
+int launch_splitk(const ConvArgs& a, hipStream_t st) {
+  const long total = (long)a.B * a.OH * a.OW;
+  dim3 grid(irr_cdiv(total, 32), a.CoP / 32, 1);
+  hipLaunchKernelGGL((conv_fwd_kernel<1, 1, KS, true>), grid, dim3(256), 0, st, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 // (MT, NT) tiling choice, shared by the launcher and by irr_conv2d_fwd_variant (bench / profile labelling)
-static void pick_variant(int cot, long total, int* mt, int* nt) {
+// *mt == 0 means: split-K variant (<1,1> tile, 4 waves over the channel pairs)
+static void pick_variant(int cot, long total, int* mt, int* nt, int cin = 0) {
   const long ptiles = (total + 31) / 32;
+  if (ptiles * cot < 2048 && cin >= 64) { *mt = 0; *nt = 1; return; }
   if (ptiles * cot < 4096) {            // small problems: favour many waves over register blocking
     if (cot >= 2 && ptiles * ((cot + 1) / 2) >= 1024) { *mt = 2; *nt = 1; return; }
     *mt = 1; *nt = 1; return;
@@ -266,7 +295,8 @@ static void pick_variant(int cot, long total, int* mt, int* nt) {
 template <int KS>
 int dispatch(const ConvArgs& a, hipStream_t st) {
   int mt, nt;
-  pick_variant(a.CoP / 32, (long)a.B * a.OH * a.OW, &mt, &nt);
+  pick_variant(a.CoP / 32, (long)a.B * a.OH * a.OW, &mt, &nt, a.Cin);
+  if (mt == 0) return launch_splitk<KS>(a, st);
   switch (mt * 10 + nt) {
     case 11: return launch<1, 1, KS>(a, st);
     case 21: return launch<2, 1, KS>(a, st);
