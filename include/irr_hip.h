@@ -96,6 +96,14 @@ int irr_resize_bilinear_ac_bwd_f32(const float* gout, float* gx, int B, int C, i
 long irr_conv_packed_weight_elems(int Cin, int Cout, int k);
 int irr_conv_pack_weights_f32(const float* w, float* wp, int Cin, int Cout, int k, int transpose, void* stream);
 
+/* Combined data-gradient weights: rows [row_offset, row_offset+w_cout) of a packed (transposed, tap-flipped) matrix
+ * with CoP columns are filled from layer weights w (w_cout, w_cin, k, k) restricted to input channels
+ * [chan0, chan0+nchan).  Several layers that read the same channel range of a DenseNet buffer can thus be
+ * back-propagated into that range by ONE launch of irr_conv2d_fwd_f32 over their concatenated output gradients.
+ * The destination must hold irr_conv_packed_weight_elems(total_rows, nchan, k) floats, zero-initialised. */
+int irr_conv_pack_weights_sub_f32(const float* w, float* wp, int w_cin, int w_cout, int k, int chan0, int nchan,
+                                  int CoP, int row_offset, void* stream);
+
 /* y = epilogue(conv(x, wp) + bias):
  *   v = acc + bias[co] (bias nullable);  if (lrelu) v = v>0 ? v : 0.1 v;
  *   y = res ? res + alpha*v : alpha*v      (res nullable; OccUpsampleNetwork residual adds,

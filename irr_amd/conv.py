@@ -349,33 +349,75 @@ class _DenseEstimatorFn(torch.autograd.Function):
             g_est = G[:, ctot:] + g_est if g_est is not None else G[:, ctot:].clone()
         grads_w = [None] * 6
         grads_b = [None] * 6
-        # Walk conv_last, conv5 .. conv1.  Each data-gradient launch accumulates into the channel suffix of G
-        # and, in the same epilogue, multiplies the slice of the NEXT layer to be processed (the first
-        # GROW[i-1] channels of that suffix, which has just received its last contribution) by LeakyReLU' of the
-        # saved activations -- so every G slice is already a pre-activation gradient when its turn comes, and
-        # the bias gradients come out of the wgrad launches: no separate elementwise pass over G.
+        # conv_last first: its data gradient touches every channel (K is tiny, the launch is memory-bound) and its
+        # epilogue turns the c5 slice into a pre-activation gradient.  Then the buffer is back-propagated COLUMN-WISE:
+        # for each slice T = c4, c3, c2, c1, x (in that order) ONE launch sums the contributions of all later layers,
+        # reading their concatenated pre-activation gradients G[:, :t0] (contiguous by construction) against a
+        # combined packed weight matrix, accumulates into G[:, T] once and applies LeakyReLU'(buf[:, T]) in the same
+        # epilogue.  Versus layer-by-layer accumulation this replaces up to five small-K read-modify-write launches
+        # per slice by a single large-K one.  Bias gradients ride on the wgrad launches.
         if g_est is not None:
             grads_b[5] = torch.zeros(E, device=dev, dtype=torch.float32)
             grads_w[5] = conv_wgrad(buf[:, :ctot], g_est, ws[5].shape, 1, 1, gbias=grads_b[5])
             conv_dgrad(g_est, ws[5], 1, 1, (H, W), gx=G[:, :ctot], accumulate=True, mask=buf[:, :ctot], nmask=32)
         else:
             lrelu_bwd_bias(G[:, :32], buf[:, :32], True, G[:, :32], None)
-        off = 0
-        for i in range(4, -1, -1):
-            co = _DenseEstimatorFn.GROW[i]
-            gslice = G[:, off:off + co]                       # already d/d(pre-activation)
-            grads_b[i] = torch.zeros(co, device=dev, dtype=torch.float32)
-            grads_w[i] = conv_wgrad(buf[:, off + co:ctot], gslice, ws[i].shape, 1, 1, gbias=grads_b[i])
-            nm = _DenseEstimatorFn.GROW[i - 1] if i > 0 else 0
-            conv_dgrad(gslice, ws[i], 1, 1, (H, W), gx=G[:, off + co:ctot], accumulate=True,
-                       mask=buf[:, off + co:ctot] if nm else None, nmask=nm)
-            off += co
+        packs = _dense_column_packs(ws[:5], cin0)
+        grads_b[4] = torch.zeros(32, device=dev, dtype=torch.float32)
+        grads_w[4] = conv_wgrad(buf[:, 32:ctot], G[:, :32], ws[4].shape, 1, 1, gbias=grads_b[4])      # conv5
+        bounds = [(32, 96), (96, 192), (192, 320), (320, 448), (448, ctot)]
+        for k_, (t0, t1) in enumerate(bounds):
+            last = k_ == 4
+            if last and not ctx.needs_input_grad[0]:
+                break
+            args = ("irr_conv2d_fwd_f32", hip.ptr(G), hip.ptr(packs[k_]), None, None, hip.ptr(G[:, t0:t1]), B, t0, H, W,
+                    t1 - t0, H, W, 3, 1, 1, hip.bs(G), hip.bs(G), 0, 0, 1.0, 1,
+                    None if last else hip.ptr(buf[:, t0:t1]), 0 if last else hip.bs(buf), 0 if last else t1 - t0,
+                    hip.stream())
+            if TIMER is None:
+                hip.call(*args)
+            else:
+                TIMER.wrap(hip.lib().irr_conv2d_fwd_variant(B, t1 - t0, H, W, 3), 2.0 * B * H * W * t0 * (t1 - t0) * 9,
+                           lambda: hip.call(*args))
+            if not last:                                   # G[:, t0:t1] is now the pre-activation gradient of conv(4-k_)
+                i = 3 - k_
+                grads_b[i] = torch.zeros(t1 - t0, device=dev, dtype=torch.float32)
+                grads_w[i] = conv_wgrad(buf[:, t1:ctot], G[:, t0:t1], ws[i].shape, 1, 1, gbias=grads_b[i])
         gx = G[:, 448:ctot] if ctx.needs_input_grad[0] else None
         gbase = g_est if (has_base and ctx.needs_input_grad[1]) else None
         out = [gx, gbase]
         for i in range(6):
             out += [grads_w[i], grads_b[i]]
         return tuple(out)
+
+
+def _dense_column_packs(ws5, cin0: int):
+    """Combined (transposed, flipped) packed weights for the five column targets c4, c3, c2, c1, x of the DenseNet
+    buffer; cached on the first weight tensor and rebuilt when any of the five conv weights changed."""
+    tags = tuple((w.data_ptr(), w._version) for w in ws5) + (WEIGHT_EPOCH[0], cin0)
+    holder = ws5[0].__dict__.setdefault("_irr_dense_packs", {})
+    if holder.get("tag") == tags:
+        return holder["packs"]
+    grow = _DenseEstimatorFn.GROW                         # out channels of conv1..conv5
+    in0 = [448, 320, 192, 96, 32]                         # first buffer channel read by conv1..conv5
+    row0 = {5: 0, 4: 32, 3: 96, 2: 192, 1: 320}           # row (= G channel) where conv i's gradient slice starts
+    bounds = [(32, 96), (96, 192), (192, 320), (320, 448), (448, 448 + cin0)]
+    packs = []
+    dev = ws5[0].device
+    for (t0, t1) in bounds:
+        n = t1 - t0
+        cop = (n + 31) // 32 * 32
+        wp = torch.zeros(hip.lib().irr_conv_packed_weight_elems(t0, n, 3), device=dev, dtype=torch.float32)
+        for i in (5, 4, 3, 2, 1):
+            if in0[i - 1] > t0:
+                continue                                  # conv i does not read this slice
+            w = ws5[i - 1].detach().contiguous()
+            hip.call("irr_conv_pack_weights_sub_f32", hip.ptr(w), hip.ptr(wp), w.shape[1], w.shape[0], 3,
+                     t0 - in0[i - 1], n, cop, row0[i], hip.stream())
+        packs.append(wp)
+    holder["tag"] = tags
+    holder["packs"] = packs
+    return packs
 
 
 def dense_estimator(x, base, weights_and_biases):

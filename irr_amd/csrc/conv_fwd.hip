@@ -258,6 +258,23 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   wp[i] = v;
 }
 
+// Sub-block pack for COMBINED data-gradient weights (DenseNet backward): rows [row_offset, row_offset + w_cout) of the
+// packed matrix take the transposed+flipped weights of one layer restricted to its input channels
+// [chan0, chan0 + nchan):  wp[((r/2*KK + tap)*2 + (r&1))*CoP + c] = w[r - row_offset][chan0 + c][KK-1-tap].
+__global__ void pack_weights_sub_kernel(const float* __restrict__ w, float* __restrict__ wp, int w_cin, int w_cout, int KK,
+                                        int chan0, int nchan, int CoP, int row_offset, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % CoP);
+  long r1 = i / CoP;
+  const int tap = (int)(r1 % KK);
+  const int rl = (int)(r1 / KK);                 // local row = output channel of the layer
+  const int r = row_offset + rl;
+  float v = 0.f;
+  if (c < nchan) v = w[((long)rl * w_cin + chan0 + c) * KK + (KK - 1 - tap)];
+  wp[(((long)(r >> 1) * KK + tap) * 2 + (r & 1)) * CoP + c] = v;
+}
+
 template <int MT, int NT, int KS>
 int launch(const ConvArgs& a, hipStream_t st) {
   const long total = (long)a.B * a.OH * a.OW;
@@ -329,6 +346,18 @@ extern "C" int irr_conv_pack_weights_f32(const float* w, float* wp, int Cin, int
   const long n = irr_conv_packed_weight_elems(Cin, Cout, k);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, Cin, Cout,
                      k * k, CoP, transpose, n);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_conv_pack_weights_sub_f32(const float* w, float* wp, int w_cin, int w_cout, int k, int chan0, int nchan,
+                                             int CoP, int row_offset, void* stream) {
+  if (!w || !wp || w_cin <= 0 || w_cout <= 0 || (k != 1 && k != 3) || chan0 < 0 || nchan <= 0 || chan0 + nchan > w_cin ||
+      CoP < nchan || (CoP & 31) || row_offset < 0)
+    return IRR_EINVAL;
+  const long n = (long)w_cout * k * k * CoP;
+  hipLaunchKernelGGL(pack_weights_sub_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, w_cin,
+                     w_cout, k * k, chan0, nchan, CoP, row_offset, n);
   IRR_LAUNCH_CHECK();
   return 0;
 }
