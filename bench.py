@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--width", type=int, default=448)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-async-wgrad", action="store_true", help="keep weight gradients on the main stream")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,6 +102,8 @@ def main():
     loss = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(args, reduce_fn=ddp.reduce_losses() if world > 1 else None).train()
     mal = ModelAndLoss(args, model, loss).train()
     arena = ddp.GradArena(model.named_parameters())
+    if not a.no_async_wgrad:
+        arena.enable_async_wgrad()
     opt = FusedAdam(model, arena, lr=1e-4, weight_decay=4e-4)
     step = TrainStep(mal, opt, grad_sync=arena.sync)
     batch = synthetic_batch(a.batch, a.height, a.width, 1234 + rank, device)

@@ -129,8 +129,9 @@ int irr_conv2d_fwd_variant(int B, int Cout, int OH, int OW, int k);
  * gw is the plain (Cout,Cin,k,k) tensor and is ACCUMULATED into (caller zeroes it when it wants "=").
  * ws: caller-owned scratch of Cout*Cin*k*k floats (split-K partials land there with coalesced atomics in
  * [co][tap][ci] order and are then added to gw).
- * gbias (nullable): gbias[co] += sum_{b,y,x} gy[b,co,y,x] (the bias gradient, taken from the staged gy tiles). */
-int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias,
+ * gbias (nullable): gbias[co] += sum_{b,y,x} gy[b,co,y,x] (the bias gradient, taken from the staged gy tiles).
+ * alpha scales both results (residual branches y = x + alpha*conv(t): models/irr_modules.py:51-53). */
+int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                          int B, int Cin, int H, int W, int Cout, int OH, int OW,
                          int k, int stride, int dil, long x_bs, long gy_bs, void* stream);
 
@@ -140,7 +141,7 @@ int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, 
 int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const float* bias, const float* res, float* y,
                                int B, int Cin, int H, int W, int Cout, int k, int dil,
                                long x_bs, long y_bs, long res_bs, int lrelu, float alpha, int accumulate, void* stream);
-int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias,
+int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                                  int B, int Cin, int H, int W, int Cout, int k, int dil,
                                  long x_bs, long gy_bs, void* stream);
 

@@ -199,7 +199,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
 
 
 def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil: int,
-               gw: Optional[torch.Tensor] = None, gbias: Optional[torch.Tensor] = None) -> torch.Tensor:
+               gw: Optional[torch.Tensor] = None, gbias: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
     """gw += d/dW; gw (Cout,Cin,k,k) is created zeroed when not given.  gbias (optional, (Cout,)) += sum of gy over
     (b, h, w): the bias gradient comes out of the same launch (the gy tiles are staged there anyway)."""
     cout, cin, k, _ = weight_shape
@@ -208,20 +208,79 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
     if gw is None:
         gw = torch.zeros(cout, cin, k, k, device=x.device, dtype=torch.float32)
     if BACKEND == "miopen":
-        gw += torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), gy, stride=stride,
-                                          padding=((k - 1) * dil) // 2, dilation=dil)
+        gw += alpha * torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), gy, stride=stride,
+                                                  padding=((k - 1) * dil) // 2, dilation=dil)
         if gbias is not None:
-            gbias += gy.sum(dim=(0, 2, 3))
+            gbias += alpha * gy.sum(dim=(0, 2, 3))
         return gw
     assert gw.is_contiguous()
     ws = torch.empty(cout * cin * k * k, device=x.device, dtype=torch.float32)
     if cout <= 4 and stride == 1:
-        hip.call("irr_conv2d_smallco_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), B, cin, H, W, cout, k, dil,
+        hip.call("irr_conv2d_smallco_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W, cout, k, dil,
                  hip.bs(x), hip.bs(gy), hip.stream())
         return gw
-    hip.call("irr_conv2d_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), B, cin, H, W, cout, oh, ow, k, stride, dil,
+    hip.call("irr_conv2d_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W, cout, oh, ow, k, stride, dil,
              hip.bs(x), hip.bs(gy), hip.stream())
     return gw
+
+
+class WgradSide:
+    """Asynchronous weight-gradient lane (training harness opt-in, see irr_amd.ddp.GradArena.enable_async_wgrad).
+
+    dgrad and wgrad of a layer are independent once the pre-activation gradient exists, and only dgrad is on the
+    critical path of backward.  With this object installed, every weight/bias gradient is accumulated straight into
+    the flat gradient arena on a SECOND HIP stream: the wgrad kernels fill the SIMDs that the tail of a dgrad launch
+    (or a whole coarse-level launch, which cannot fill 256 CUs) leaves idle.  Autograd then receives ``None`` for
+    those parameters; GradArena.sync() joins the lane before the all-reduce / optimizer step."""
+
+    def __init__(self, views):
+        self.views = views                      # id(parameter) -> flat-arena view with the parameter's shape
+        dev = next(iter(views.values())).device
+        self.stream = torch.cuda.Stream(device=dev)
+
+    def route(self, weight, bias):
+        gw = self.views.get(id(weight))
+        if gw is None:
+            return None
+        gb = self.views.get(id(bias)) if bias is not None else None
+        return gw, gb
+
+    def launch(self, fn, tensors):
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.stream)     # keep the caching allocator from recycling them too early
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
+SIDE: Optional[WgradSide] = None
+
+
+def wgrad_param(x, gy, weight, bias, stride: int, dil: int, want_bias: bool = True, alpha: float = 1.0,
+                acc=None):
+    """Weight (+bias) gradient of one conv use.  Returns (gw, gb) tensors for autograd -- or (None, None) when the
+    result was accumulated asynchronously into the gradient arena (SIDE lane).  ``acc`` = optional (gw, gb) pair to
+    accumulate into (shared weights used several times inside one autograd node)."""
+    routed = SIDE.route(weight, bias) if SIDE is not None else None
+    if routed is not None:
+        gwv, gbv = routed
+        SIDE.launch(lambda: conv_wgrad(x, gy, weight.shape, stride, dil, gw=gwv, gbias=gbv if want_bias else None,
+                                       alpha=alpha), (x, gy))
+        return None, None
+    if acc is not None:
+        gw, gb = acc
+    else:
+        gw = None
+        gb = torch.zeros(weight.shape[0], device=x.device, dtype=torch.float32) if (want_bias and bias is not None) else None
+    gw = conv_wgrad(x, gy, weight.shape, stride, dil, gw=gw, gbias=gb if want_bias else None, alpha=alpha)
+    return gw, gb
 
 
 def lrelu_bwd_bias(gy: torch.Tensor, y: Optional[torch.Tensor], lrelu: bool, gpre: Optional[torch.Tensor],
@@ -255,6 +314,7 @@ class _ConvBlock(torch.autograd.Function):
         ctx.save_for_backward(x, weight, act if lrelu else None)
         ctx.has_bias = bias is not None
         ctx.weight_obj = weight            # the Parameter object that carries the packed-weight cache
+        ctx.bias_obj = bias
         return y
 
     @staticmethod
@@ -274,7 +334,12 @@ class _ConvBlock(torch.autograd.Function):
             if lrelu:
                 g = gpre
         gx = conv_dgrad(g, ctx.weight_obj, stride, dil, x.shape[2:]) if ctx.needs_input_grad[0] else None
-        gw = conv_wgrad(x, g, weight.shape, stride, dil, gbias=gb if bias_in_wgrad else None) if want_w else None
+        gw = None
+        if want_w:
+            if bias_in_wgrad:
+                gw, gb = wgrad_param(x, g, ctx.weight_obj, ctx.bias_obj, stride, dil, want_bias=True)
+            else:
+                gw, _ = wgrad_param(x, g, ctx.weight_obj, None, stride, dil, want_bias=False)
         return gx, gw, gb, None, None, None, gres, None
 
 
@@ -326,6 +391,7 @@ class _DenseEstimatorFn(torch.autograd.Function):
             out = conv_forward(buf[:, :ctot], ws[5], bs[5], 1, 1, False)
         ctx.save_for_backward(buf, *ws)
         ctx.cfg = (cin0, E, has_base)
+        ctx.wobjs, ctx.bobjs = ws, bs
         return buf, out
 
     @staticmethod
@@ -357,14 +423,12 @@ class _DenseEstimatorFn(torch.autograd.Function):
         # epilogue.  Versus layer-by-layer accumulation this replaces up to five small-K read-modify-write launches
         # per slice by a single large-K one.  Bias gradients ride on the wgrad launches.
         if g_est is not None:
-            grads_b[5] = torch.zeros(E, device=dev, dtype=torch.float32)
-            grads_w[5] = conv_wgrad(buf[:, :ctot], g_est, ws[5].shape, 1, 1, gbias=grads_b[5])
+            grads_w[5], grads_b[5] = wgrad_param(buf[:, :ctot], g_est, ctx.wobjs[5], ctx.bobjs[5], 1, 1)
             conv_dgrad(g_est, ws[5], 1, 1, (H, W), gx=G[:, :ctot], accumulate=True, mask=buf[:, :ctot], nmask=32)
         else:
             lrelu_bwd_bias(G[:, :32], buf[:, :32], True, G[:, :32], None)
         packs = _dense_column_packs(ws[:5], cin0)
-        grads_b[4] = torch.zeros(32, device=dev, dtype=torch.float32)
-        grads_w[4] = conv_wgrad(buf[:, 32:ctot], G[:, :32], ws[4].shape, 1, 1, gbias=grads_b[4])      # conv5
+        grads_w[4], grads_b[4] = wgrad_param(buf[:, 32:ctot], G[:, :32], ctx.wobjs[4], ctx.bobjs[4], 1, 1)   # conv5
         bounds = [(32, 96), (96, 192), (192, 320), (320, 448), (448, ctot)]
         for k_, (t0, t1) in enumerate(bounds):
             last = k_ == 4
@@ -381,8 +445,7 @@ class _DenseEstimatorFn(torch.autograd.Function):
                            lambda: hip.call(*args))
             if not last:                                   # G[:, t0:t1] is now the pre-activation gradient of conv(4-k_)
                 i = 3 - k_
-                grads_b[i] = torch.zeros(t1 - t0, device=dev, dtype=torch.float32)
-                grads_w[i] = conv_wgrad(buf[:, t1:ctot], G[:, t0:t1], ws[i].shape, 1, 1, gbias=grads_b[i])
+                grads_w[i], grads_b[i] = wgrad_param(buf[:, t1:ctot], G[:, t0:t1], ctx.wobjs[i], ctx.bobjs[i], 1, 1)
         gx = G[:, 448:ctot] if ctx.needs_input_grad[0] else None
         gbase = g_est if (has_base and ctx.needs_input_grad[1]) else None
         out = [gx, gbase]
@@ -465,6 +528,7 @@ class _ConvChainFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.has_res = res is not None
         ctx.weight_objs = ws
+        ctx.bias_objs = bs
         ctx.save_for_backward(x, *[a for a in acts[:-1]], *( [acts[-1]] if cfg[-1][2] else [] ))
         return cur
 
@@ -489,9 +553,7 @@ class _ConvChainFn(torch.autograd.Function):
         for i in range(n - 1, -1, -1):
             stride, dil, _ = cfg[i]
             inp = acts[i - 1] if i > 0 else x
-            gb = torch.zeros(ws[i].shape[0], device=dev, dtype=torch.float32)
-            grads[2 * i] = conv_wgrad(inp, g, ws[i].shape, stride, dil, gbias=gb)
-            grads[2 * i + 1] = gb
+            grads[2 * i], grads[2 * i + 1] = wgrad_param(inp, g, ws[i], ctx.bias_objs[i], stride, dil)
             if i > 0:
                 prev_lrelu = cfg[i - 1][2]
                 g = conv_dgrad(g, ws[i], stride, dil, inp.shape[2:], mask=inp if prev_lrelu else None,
@@ -543,6 +605,7 @@ class _OccUpsampleFn(torch.autograd.Function):
         out = torch.add(o, occ_up)
         ctx.mul_const = mul_const
         ctx.wobjs = (w_init, w_r0, w_r1, w_end, w_out)
+        ctx.bobjs = (b_init, b_r0, b_r1, b_end, b_out)
         ctx.save_for_backward(x_in, xs[0], xs[1], xs[2], xs[3], ts[0], ts[1], ts[2], e, x2, o)
         return out
 
@@ -550,6 +613,7 @@ class _OccUpsampleFn(torch.autograd.Function):
     def backward(ctx, g_out):
         x_in, x0, x1, x2r, x3, t1, t2, t3, e, x2, o = ctx.saved_tensors
         w_init, w_r0, w_r1, w_end, w_out = ctx.wobjs
+        b_init, b_r0, b_r1, b_end, b_out = ctx.bobjs
         mc = ctx.mul_const
         dev = g_out.device
         hw_ = x0.shape[2:]
@@ -559,34 +623,33 @@ class _OccUpsampleFn(torch.autograd.Function):
         gpre_o = torch.empty_like(g_out)
         gb_out = z(w_out.shape[0])
         lrelu_bwd_bias(g_out, o, True, gpre_o, gb_out)                       # 1-channel tensor
-        gw_out = conv_wgrad(x2, gpre_o, w_out.shape, 1, 1)
+        gw_out, _ = wgrad_param(x2, gpre_o, w_out, None, 1, 1, want_bias=False)
         g_x2 = conv_dgrad(gpre_o, w_out, 1, 1, hw_)                          # (B,32,H,W); also the gradient of x_init via the skip
         # x2 = x_init + e, e = lrelu(conv_end(x3))
         gpre_e = torch.empty_like(g_x2)
         gb_end = z(w_end.shape[0])
         lrelu_bwd_bias(g_x2, e, True, gpre_e, gb_end)
-        gw_end = conv_wgrad(x3, gpre_e, w_end.shape, 1, 1)
+        gw_end, _ = wgrad_param(x3, gpre_e, w_end, None, 1, 1, want_bias=False)
         g_x = conv_dgrad(gpre_e, w_end, 1, 1, hw_)                           # gradient w.r.t. x3
         # three residual blocks with shared weights: x_i = x_{i-1} + mc * conv_r1(t_i), t_i = lrelu(conv_r0(x_{i-1}))
-        gw_r0 = torch.zeros_like(w_r0)
-        gw_r1 = torch.zeros_like(w_r1)
-        gb_r0, gb_r1 = z(w_r0.shape[0]), z(w_r1.shape[0])
+        routed = SIDE is not None and SIDE.route(w_r0, b_r0) is not None
+        acc_r0 = None if routed else (torch.zeros_like(w_r0), z(w_r0.shape[0]))
+        acc_r1 = None if routed else (torch.zeros_like(w_r1), z(w_r1.shape[0]))
         xs = [x0, x1, x2r]
         ts = [t1, t2, t3]
         for i in (2, 1, 0):
-            conv_wgrad(ts[i], g_x, w_r1.shape, 1, 1, gw=gw_r1, gbias=gb_r1)      # scaled by mc once, below
+            wgrad_param(ts[i], g_x, w_r1, b_r1, 1, 1, alpha=mc, acc=acc_r1)
             gpre_t = conv_dgrad(g_x, w_r1, 1, 1, hw_, mask=ts[i], nmask=ts[i].shape[1], alpha=mc)
-            conv_wgrad(xs[i], gpre_t, w_r0.shape, 1, 1, gw=gw_r0, gbias=gb_r0)
+            wgrad_param(xs[i], gpre_t, w_r0, b_r0, 1, 1, acc=acc_r0)
             if i > 0:
                 g_x = conv_dgrad(gpre_t, w_r0, 1, 1, hw_, res=g_x)                # skip + branch in one launch
             else:
                 # x_0 = x_init: add the x2 skip gradient (accumulate into g_x2) and apply init_conv's LeakyReLU'
                 conv_dgrad(gpre_t, w_r0, 1, 1, hw_, gx=g_x2, accumulate=True, res=g_x, mask=x0, nmask=x0.shape[1])
-        gw_r1 *= mc
-        gb_r1 *= mc
+        gw_r0, gb_r0 = acc_r0 if acc_r0 is not None else (None, None)
+        gw_r1, gb_r1 = acc_r1 if acc_r1 is not None else (None, None)
         gpre_init = g_x2
-        gb_init = z(w_init.shape[0])
-        gw_init = conv_wgrad(x_in, gpre_init, w_init.shape, 1, 1, gbias=gb_init)
+        gw_init, gb_init = wgrad_param(x_in, gpre_init, w_init, b_init, 1, 1)
         g_xin = conv_dgrad(gpre_init, w_init, 1, 1, hw_) if ctx.needs_input_grad[1] else None
         g_occ_up = g_out if ctx.needs_input_grad[0] else None
         return (g_occ_up, g_xin, gw_init, gb_init, gw_r0, gb_r0, gw_r1, gb_r1, gw_end, gb_end, gw_out, gb_out, None)

@@ -62,9 +62,9 @@ __global__ __launch_bounds__(256) void conv_smallco_fwd_kernel(const float* __re
 // ws[co][tap][ci] += sum over this block's pixels of gy[co][p] * x[ci][p + off(tap)]
 template <int NC, int KS>
 __global__ __launch_bounds__(256) void conv_smallco_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                                float* __restrict__ ws, float* __restrict__ gbias, int B,
-                                                                int Cin, int H, int W, int dil, long x_bs, long gy_bs,
-                                                                int pix_per_block) {
+                                                                float* __restrict__ ws, float* __restrict__ gbias, float alpha,
+                                                                int B, int Cin, int H, int W, int dil, long x_bs,
+                                                                long gy_bs, int pix_per_block) {
   constexpr int KK = KS * KS;
   const long hw = (long)H * W;
   const int ci = blockIdx.y, b = blockIdx.z;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_smallco_wgrad_kernel(const float* __
       float sb = bsum[c];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) sb += __shfl_down(sb, o, 64);
-      if (lane == 0) unsafeAtomicAdd(gbias + c, sb);
+      if (lane == 0) unsafeAtomicAdd(gbias + c, alpha * sb);
     }
   }
 #pragma unroll
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void conv_smallco_wgrad_kernel(const float* __
   if (threadIdx.x < NC * KK) {
     const int c = threadIdx.x / KK, t = threadIdx.x - c * KK;
     const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    unsafeAtomicAdd(ws + ((long)c * KK + t) * Cin + ci, s);
+    unsafeAtomicAdd(ws + ((long)c * KK + t) * Cin + ci, alpha * s);
   }
 }
 
@@ -171,8 +171,8 @@ extern "C" int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const 
                                   lrelu, alpha, accumulate);
 }
 
-extern "C" int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, int B,
-                                            int Cin, int H, int W, int Cout, int k, int dil, long x_bs, long gy_bs,
+extern "C" int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
+                                            int B, int Cin, int H, int W, int Cout, int k, int dil, long x_bs, long gy_bs,
                                             void* stream) {
   if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 1 || Cout > 4) return IRR_EINVAL;
   if ((k != 1 && k != 3) || dil < 1 || B > 65535 || Cin > 65535) return IRR_EINVAL;
@@ -187,8 +187,8 @@ extern "C" int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, flo
   if (ppb < 1024) ppb = 1024;
   dim3 grid(irr_cdiv(hw, ppb), Cin, B);
 #define IRR_SMALL_WG(N, K)                                                                                        \
-  hipLaunchKernelGGL((conv_smallco_wgrad_kernel<N, K>), grid, dim3(256), 0, st, x, gy, ws, gbias, B, Cin, H, W, dil, \
-                     x_bs, gy_bs, (int)ppb)
+  hipLaunchKernelGGL((conv_smallco_wgrad_kernel<N, K>), grid, dim3(256), 0, st, x, gy, ws, gbias, alpha, B, Cin, H, W, \
+                     dil, x_bs, gy_bs, (int)ppb)
   if (k == 3) {
     switch (Cout) { case 1: IRR_SMALL_WG(1, 3); break; case 2: IRR_SMALL_WG(2, 3); break;
                     case 3: IRR_SMALL_WG(3, 3); break; default: IRR_SMALL_WG(4, 3); break; }

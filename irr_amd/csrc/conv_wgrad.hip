@@ -32,6 +32,7 @@ struct WgArgs {
   const float* gy;
   float* gw;                    // workspace, [Cout][KK][Cin]
   float* gbias;                 // optional: gbias[co] += sum of gy over pixels (taken from the staged gy tiles)
+  float alpha;                  // scales both results (residual branches: y = x + alpha*conv(...))
   int B, Cin, H, W, Cout, OH, OW;
   int stride, dil, pad;
   long x_bs, gy_bs;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);          // reduce over the 32 pixels of the half-wave
       const int co = co0 + 2 * wa + half + ia * NA;
-      if (px == 0 && 2 * wa + ia * NA < AROWS && co < a.Cout) unsafeAtomicAdd(a.gbias + co, v);
+      if (px == 0 && 2 * wa + ia * NA < AROWS && co < a.Cout) unsafeAtomicAdd(a.gbias + co, a.alpha * v);
     }
   }
 
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a
       // workspace layout [co][tap][ci]: lanes (ci) are contiguous -> one cache line per half-wave atomic
       float* dst = a.gw + ((long)co * KK + ty_w * KS) * a.Cin + ci;
 #pragma unroll
-      for (int t = 0; t < KS; ++t) unsafeAtomicAdd(dst + (long)t * a.Cin, acc[t][r]);
+      for (int t = 0; t < KS; ++t) unsafeAtomicAdd(dst + (long)t * a.Cin, a.alpha * acc[t][r]);
     }
   }
 }
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(MTB * 3 * 64) void conv_wgrad_halo_kernel(const WgA
       for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
       const int q = 2 * wa + half + i * NA;
       const int co = co0 + q / TR;
-      if (hl == 0 && q < ALOADS && co < a.Cout) unsafeAtomicAdd(a.gbias + co, v);
+      if (hl == 0 && q < ALOADS && co < a.Cout) unsafeAtomicAdd(a.gbias + co, a.alpha * v);
     }
   }
 
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(MTB * 3 * 64) void conv_wgrad_halo_kernel(const WgA
       if (co >= a.Cout) continue;
       float* dst = a.gw + ((long)co * KK + ty_w * KS) * a.Cin + ci;
 #pragma unroll
-      for (int t = 0; t < KS; ++t) unsafeAtomicAdd(dst + (long)t * a.Cin, acc[t][r]);
+      for (int t = 0; t < KS; ++t) unsafeAtomicAdd(dst + (long)t * a.Cin, a.alpha * acc[t][r]);
     }
   }
 }
@@ -553,8 +554,8 @@ __global__ __launch_bounds__(256) void dgrad_strided_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, int B, int Cin, int H,
-                                    int W,
+extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
+                                    int Cin, int H, int W,
                                     int Cout, int OH, int OW, int k, int stride, int dil, long x_bs, long gy_bs,
                                     void* stream) {
   if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return IRR_EINVAL;
@@ -562,7 +563,7 @@ extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
   WgArgs a;
   const long n = (long)Cout * Cin * k * k;
   IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, (hipStream_t)stream));
-  a.x = x; a.gy = gy; a.gw = ws; a.gbias = gbias;
+  a.x = x; a.gy = gy; a.gw = ws; a.gbias = gbias; a.alpha = alpha;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW;
   a.stride = stride; a.dil = dil; a.pad = ((k - 1) * dil) / 2;
   a.x_bs = x_bs; a.gy_bs = gy_bs; a.chunks_per_block = 0;

@@ -130,8 +130,24 @@ class GradArena:
         if self._pending[bi] == 0:
             self._launch(bi)
 
+    def enable_async_wgrad(self):
+        """Route every weight/bias gradient of the MFMA conv nodes straight into this arena on a second HIP stream
+        (irr_amd.conv.WgradSide): the wgrad launches then overlap the data-gradient chain instead of sitting on
+        its critical path.  Autograd no longer sees those gradients, so buckets are reduced at sync()."""
+        from . import conv
+        self._side_lane = conv.WgradSide({id(p): p.grad for _, p in self.order})
+        conv.SIDE = self._side_lane
+
+    def disable_async_wgrad(self):
+        from . import conv
+        if getattr(self, "_side_lane", None) is not None and conv.SIDE is self._side_lane:
+            conv.SIDE = None
+        self._side_lane = None
+
     def sync(self):
         """call between backward() and optimizer.step(): flush, wait, average."""
+        if getattr(self, "_side_lane", None) is not None:
+            self._side_lane.join()
         if self.world == 1:
             return
         for bi in range(len(self.buckets)):
