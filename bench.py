@@ -146,6 +146,15 @@ def main():
                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "launches": st["calls"], "avg_launch_us": round(st["seconds"] / st["calls"] * 1e6, 2),
                     "flop_per_launch": st["flops"] / st["calls"],
+                    "concurrent_lanes": 1 if a.no_async_wgrad else 2,
+                    "note": ("durations include time-sharing the chip with the asynchronous weight-gradient lane "
+                             "(second HIP stream) during backward; 'exclusive' = the forward-pass launches of the same "
+                             "kernel, which run alone") if not a.no_async_wgrad else "single stream",
+                    "exclusive": ({"achieved": round(st["fwd_flops"] / st["fwd_seconds"] / 1e12, 2),
+                                   "frac": round(st["fwd_flops"] / st["fwd_seconds"] / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                   "launches": st["fwd_calls"],
+                                   "avg_launch_us": round(st["fwd_seconds"] / st["fwd_calls"] * 1e6, 2)}
+                                  if st["fwd_calls"] else None),
                     "all_conv_fwd_dgrad": {"achieved": round(tot_f / tot_s / 1e12, 2), "seconds_per_step": round(tot_s / a.steps, 5),
                                            "flops_per_step": tot_f / a.steps}}
     if rank == 0 and roof is not None:

@@ -29,23 +29,31 @@ class KernelTimer:
     def __init__(self):
         self.records = []          # (variant code, flops, start event, stop event)
 
-    def wrap(self, variant: int, flops: float, launch):
+    def wrap(self, variant: int, flops: float, launch, phase: str = "fwd"):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         launch()
         e.record()
-        self.records.append((variant, flops, s, e))
+        self.records.append((variant, flops, s, e, phase))
 
     def summary(self):
+        """{variant: {calls, flops, seconds, fwd_calls, fwd_flops, fwd_seconds}} -- the fwd_* entries cover only the
+        forward-pass launches, which never share the chip with the asynchronous weight-gradient lane."""
         torch.cuda.synchronize()
         agg = {}
-        for variant, flops, s, e in self.records:
-            a = agg.setdefault(variant, [0, 0.0, 0.0])
+        for variant, flops, s, e, phase in self.records:
+            a = agg.setdefault(variant, [0, 0.0, 0.0, 0, 0.0, 0.0])
+            dt = s.elapsed_time(e) * 1e-3
             a[0] += 1
             a[1] += flops
-            a[2] += s.elapsed_time(e) * 1e-3
+            a[2] += dt
+            if phase == "fwd":
+                a[3] += 1
+                a[4] += flops
+                a[5] += dt
         self.records.clear()
-        return {v: {"calls": a[0], "flops": a[1], "seconds": a[2]} for v, a in agg.items()}
+        return {v: {"calls": a[0], "flops": a[1], "seconds": a[2], "fwd_calls": a[3], "fwd_flops": a[4],
+                    "fwd_seconds": a[5]} for v, a in agg.items()}
 
 
 TIMER: Optional[KernelTimer] = None
@@ -178,7 +186,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
             hip.call(*args)
         else:
             TIMER.wrap(hip.lib().irr_conv2d_fwd_variant(B, cin, H, W, k), 2.0 * B * H * W * cout * cin * k * k,
-                       lambda: hip.call(*args))
+                       lambda: hip.call(*args), "dgrad")
     elif stride == 2 and k == 3 and dil == 1 and H == 2 * oh and W == 2 * ow and cout >= 2:
         # transposed stride-2 conv == stride-1 conv (flipped weights) of the zero-interleaved gradient
         z = torch.zeros(B, cout, H, W, device=gy.device, dtype=torch.float32)
@@ -442,7 +450,7 @@ class _DenseEstimatorFn(torch.autograd.Function):
                 hip.call(*args)
             else:
                 TIMER.wrap(hip.lib().irr_conv2d_fwd_variant(B, t1 - t0, H, W, 3), 2.0 * B * H * W * t0 * (t1 - t0) * 9,
-                           lambda: hip.call(*args))
+                           lambda: hip.call(*args), "dgrad")
             if not last:                                   # G[:, t0:t1] is now the pre-activation gradient of conv(4-k_)
                 i = 3 - k_
                 grads_w[i], grads_b[i] = wgrad_param(buf[:, t1:ctot], G[:, t0:t1], ctx.wobjs[i], ctx.bobjs[i], 1, 1)
