@@ -350,8 +350,11 @@ __global__ __launch_bounds__(MTB * 3 * 64) void conv_wgrad_halo_kernel(const WgA
 #pragma unroll
     for (int i = 0; i < NR; ++i) issue1(i);
   }
-  constexpr int KSTEPS = TR * (TC / 2);
-  constexpr int PER = (NR + KSTEPS - 1) / KSTEPS;
+  constexpr int KROW = TC / 2;                  // k-steps per tile row
+  // next stage's loads are threaded between the MFMAs of the first LROWS tile rows (static schedule); the remaining
+  // rows run a rolled loop, which keeps the register footprint of tall tiles (TR = 4) in check
+  constexpr int LROWS = (TR <= 2) ? TR : 2;
+  constexpr int PER = (NR + LROWS * KROW - 1) / (LROWS * KROW);
   for (long c = c_begin; c < c_end; ++c) {
     if (WG_ABL < 3) __syncthreads();
     if (WG_ABL < 2 || c == c_begin) store_stage();
@@ -361,8 +364,8 @@ __global__ __launch_bounds__(MTB * 3 * 64) void conv_wgrad_halo_kernel(const WgA
     const float* arow = &SA[wm * 32 + j][half];
     const float* brow = &SB[j][ty_w * 32 + half];
 #pragma unroll
-    for (int k = 0; k < KSTEPS; ++k) {
-      const int r = k / (TC / 2), cpair = k - r * (TC / 2);
+    for (int k = 0; k < LROWS * KROW; ++k) {
+      const int r = k / KROW, cpair = k - r * KROW;
       const float av = arow[r * 32 + 2 * cpair];
       float bv[KS];
 #pragma unroll
@@ -375,6 +378,17 @@ __global__ __launch_bounds__(MTB * 3 * 64) void conv_wgrad_halo_kernel(const WgA
           for (int u = t; u < PER; u += KS)
             if (k * PER + u < NR) issue1(k * PER + u);
         }
+      }
+    }
+    for (int r = LROWS; r < TR; ++r) {
+#pragma unroll 5
+      for (int cpair = 0; cpair < KROW; ++cpair) {
+        const float av = arow[r * 32 + 2 * cpair];
+        float bv[KS];
+#pragma unroll
+        for (int t = 0; t < KS; ++t) bv[t] = brow[r * 32 + 2 * cpair + t];
+#pragma unroll
+        for (int t = 0; t < KS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
       }
     }
   }
@@ -467,9 +481,15 @@ int launch_halo(WgArgs a, hipStream_t st) {
 
 static int dispatch_halo(const WgArgs& a, hipStream_t st) {
   const int cot = (a.Cout + 31) / 32;
+#ifdef WG_TR4
+  if (cot == 1) return launch_halo<1, 4>(a, st);
+  if (cot == 2) return launch_halo<2, 4>(a, st);
+  if (cot == 3) return launch_halo<3, 4>(a, st);
+#else
   if (cot == 1) return launch_halo<1, 2>(a, st);
   if (cot == 2) return launch_halo<2, 2>(a, st);
   if (cot == 3) return launch_halo<3, 2>(a, st);
+#endif
   return launch_halo<4, 2>(a, st);
 }
 
