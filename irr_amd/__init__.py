@@ -13,4 +13,7 @@ from .losses import MultiScaleEPE_PWC_Bi_Occ_upsample  # noqa: E402,F401
 
 from . import ddp, optim, train  # noqa: E402,F401
 
+from . import pwcnet as _pwcnet  # noqa: E402
+
+PWCNet_baseline = _pwcnet.PWCNet       # models/__init__.py:27 `PWCNet = pwcnet.PWCNet` (ablation baseline, config 0)
 IRR_PWC = PWCNet          # models/__init__.py:35 rebinds the module name to the class

@@ -281,21 +281,31 @@ def gen_init(out_dir):
 
 
 def gen_pwcnet_plumbing(out_dir):
-    """BASELINE config 0: pwcnet.py forward on one random 128x192 pair (plumbing)."""
-    set_mode(False, False)
+    """BASELINE config 0: pwcnet.py forward on one random 128x192 pair (plumbing), as-is and robust-mask modes,
+    plus the reference's own as-is noise (8 vs 1 CPU threads)."""
     args = types.SimpleNamespace(batch_size=1, model_div_flow=0.05)
-    torch.manual_seed(0)
-    m = models.PWCNet(args)
-    m.eval()
     g = torch.Generator().manual_seed(4321)
     i1 = torch.rand(1, 3, 128, 192, generator=g)
     i2 = torch.rand(1, 3, 128, 192, generator=g)
-    with torch.no_grad():
-        o = m({"input1": i1, "input2": i2})
-    np.savez_compressed(os.path.join(out_dir, "pwcnet_plumbing.npz"), flow=npf(o["flow"]),
-                        stats=np.array([float(o["flow"].mean()), float(o["flow"].abs().mean())]))
-
-
+    d = {}
+    for mode, robust in (("asis", False), ("robust", True)):
+        set_mode(False, robust)
+        torch.manual_seed(0)
+        m = models.PWCNet(args)
+        m.eval()
+        outs = []
+        for th in (8, 1):
+            torch.set_num_threads(th)
+            with torch.no_grad():
+                outs.append(m({"input1": i1, "input2": i2})["flow"])
+        torch.set_num_threads(8)
+        d[f"{mode}_flow"] = npf(outs[0])
+        d[f"{mode}_self_epe"] = np.array([float(torch.norm(outs[0] - outs[1], dim=1).mean())])
+    set_mode(False, False)
+    d["flow"] = d["asis_flow"]
+    d["stats"] = np.array([float(np.mean(d["asis_flow"])), float(np.abs(d["asis_flow"]).mean())])
+    print({k: float(v[0]) for k, v in d.items() if k.endswith("self_epe")}, d["stats"])
+    np.savez_compressed(os.path.join(out_dir, "pwcnet_plumbing.npz"), **d)
 
 
 def gen_noise_floor(out_dir, B=2, H=128, W=192):

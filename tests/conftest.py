@@ -16,3 +16,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The C-ABI library is git-ignored: build it on demand (hipcc cross-compiles gfx950 without a GPU)."""
+    from irr_amd import build, hip
+    if not os.path.exists(hip.LIB_PATH):
+        build.build(verbose=False)
+    yield
