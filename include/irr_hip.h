@@ -207,6 +207,30 @@ int irr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* ex
                       float lr, float beta1, float beta2, float eps, float weight_decay,
                       float bias_corr1, float bias_corr2, float grad_scale, void* stream);
 
+/* ---- on-GPU training augmentation: RandomAffineFlowOcc (augmentations.py:368-653) -----------------------------
+ * The random parameters (thetas, mirror signs, crop origin) are sampled by the host exactly as the reference does
+ * (augmentations.py:469-517, 66-96, 565-585); these entry points do the per-pixel work, computing only the crop window
+ * [y0, y0+OH) x [x0, x0+OW) of the H x W augmented frame (OH=H, OW=W, y0=x0=0 when there is no crop).
+ * Per batch element, ``inv`` holds (b1,b2,b4,b5,a3,a6) of the inverted map and ``theta`` the six affine parameters
+ * (a1..a6) in normalised [-1,1] coordinates (transform_coords :415-440, inverse_transform_coords :391-413).
+ *
+ *   irr_affine_warp_f32      transform_image (:519-523) = transform_coords + Interp2(clamp=False)
+ *                            (utils/interpolation.py:82-141: floor/clamped neighbours, zero where the query leaves the
+ *                            frame).  noise != NULL (standard-normal samples, dense B x C x OH x OW) additionally applies
+ *                            clamp(v + noise_std*n, 0, 1) (augmentations.py:630-637).  src (B,C,H,W), dst (B,C,OH,OW).
+ *   irr_affine_flow_occ_f32  transform_flow (:525-548) of ``flow`` under (theta_a -> theta_b), resampled with inv_a, and,
+ *                            when occ/occ_out are given (both or neither), transform_image of the 1-channel ``occ`` fused
+ *                            with check_out_of_bound (:550-563) evaluated in the cropped frame:
+ *                            occ_out = clamp(occ' + [x+u', y+v' outside OW x OH], 0, 1).
+ */
+int irr_affine_warp_f32(const float* src, float* dst, const float* inv, const float* noise, float noise_std,
+                        int B, int C, int H, int W, int OH, int OW, int y0, int x0, long src_bs, long dst_bs,
+                        void* stream);
+int irr_affine_flow_occ_f32(const float* flow, const float* occ, float* flow_out, float* occ_out,
+                            const float* inv_a, const float* theta_a, const float* theta_b, int B, int H, int W,
+                            int OH, int OW, int y0, int x0, long flow_bs, long occ_bs, long flow_out_bs,
+                            long occ_out_bs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,7 +35,8 @@ if os.environ.get("IRR_CONV_ORDER"):
     COMMON = COMMON + ["-DCONV_ORDER=" + os.environ["IRR_CONV_ORDER"]]
 if os.environ.get("IRR_WG_TR4"):
     COMMON = COMMON + ["-DWG_TR4=1"]
-EXTRA = {"warp.hip": ["-ffp-contract=off"], "resize.hip": ["-ffp-contract=off"]}
+EXTRA = {"warp.hip": ["-ffp-contract=off"], "resize.hip": ["-ffp-contract=off"],
+         "augment.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:

@@ -330,6 +330,41 @@ def gen_noise_floor(out_dir, B=2, H=128, W=192):
     print({k: float(v[0]) for k, v in res.items()})
 
 
+def gen_augment(out_dir):
+    """RandomAffineFlowOcc of the imported reference (CPU; seeds fixed) -> inputs, sampled thetas and outputs.
+    Cases: no noise / no crop; no noise + crop; noise (only the thetas and the noise-free tensors are comparable)."""
+    import augmentations as ref_aug
+    import augment_oracle  # noqa: F401  (import check only)
+    d = {}
+    for name, (B, H, W, noise, crop, seed) in {"plain": (3, 48, 64, False, None, 11), "crop": (2, 64, 96, False, [48, 64], 12),
+                                               "noise": (2, 32, 48, True, None, 13)}.items():
+        g = torch.Generator().manual_seed(100 + seed)
+        ex = {"input1": torch.rand(B, 3, H, W, generator=g), "input2": torch.rand(B, 3, H, W, generator=g),
+              "target1": 4 * torch.randn(B, 2, H, W, generator=g), "target2": 4 * torch.randn(B, 2, H, W, generator=g),
+              "target_occ1": (torch.rand(B, 1, H, W, generator=g) < 0.3).float(),
+              "target_occ2": (torch.rand(B, 1, H, W, generator=g) < 0.3).float()}
+        for k, v in ex.items():
+            d[f"{name}_in_{k}"] = npf(v)
+        aug = ref_aug.RandomAffineFlowOcc(types.SimpleNamespace(), addnoise=noise, crop=crop)
+        captured = []
+        orig = aug.apply_random_transforms_to_params
+
+        def wrapped(*a, **k):
+            t = orig(*a, **k)
+            captured.append(t.clone())
+            return t
+        aug.apply_random_transforms_to_params = wrapped
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        out = aug({k: v.clone() for k, v in ex.items()})
+        d[f"{name}_theta1_sampled"] = npf(captured[0])
+        d[f"{name}_theta2_sampled"] = npf(captured[1])
+        for k in ex:
+            d[f"{name}_out_{k}"] = npf(out[k])
+        d[f"{name}_cfg"] = np.array([B, H, W, int(noise), crop[0] if crop else 0, crop[1] if crop else 0, seed], np.int64)
+    np.savez_compressed(os.path.join(out_dir, "augment.npz"), **d)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
@@ -337,7 +372,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
-    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "pwcnet": gen_pwcnet_plumbing, "noise": gen_noise_floor}
+    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "pwcnet": gen_pwcnet_plumbing, "noise": gen_noise_floor, "augment": gen_augment}
     for k, fn in steps.items():
         if a.only and k not in a.only.split(","):
             continue
