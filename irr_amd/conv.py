@@ -330,7 +330,9 @@ class _ConvBlock(torch.autograd.Function):
         x, weight, act = ctx.saved_tensors
         stride, dil, lrelu, alpha, has_res = ctx.cfg
         gy = gy if _planes_dense(gy) else gy.contiguous()
-        gres = gy if (has_res and ctx.needs_input_grad[6]) else None
+        # gy is also read by the asynchronous wgrad lane: hand autograd its own copy, because the engine may
+        # accumulate further gradients of `res` into the returned tensor IN PLACE on the main stream
+        gres = gy.clone() if (has_res and ctx.needs_input_grad[6]) else None
         g = gy if alpha == 1.0 else gy * alpha
         cout = weight.shape[0]
         gb = torch.zeros(cout, device=gy.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
@@ -455,7 +457,9 @@ class _DenseEstimatorFn(torch.autograd.Function):
                 i = 3 - k_
                 grads_w[i], grads_b[i] = wgrad_param(buf[:, t1:ctot], G[:, t0:t1], ctx.wobjs[i], ctx.bobjs[i], 1, 1)
         gx = G[:, 448:ctot] if ctx.needs_input_grad[0] else None
-        gbase = g_est if (has_base and ctx.needs_input_grad[1]) else None
+        # g_est is still being read by the asynchronous wgrad lane (conv_last): autograd gets its own copy, because
+        # the engine may accumulate the other gradients of `base` into the returned tensor IN PLACE
+        gbase = g_est.clone() if (has_base and ctx.needs_input_grad[1]) else None
         out = [gx, gbase]
         for i in range(6):
             out += [grads_w[i], grads_b[i]]
@@ -550,7 +554,8 @@ class _ConvChainFn(torch.autograd.Function):
         a_last = saved[n] if cfg[-1][2] else None
         ws = ctx.weight_objs
         gy = gy if _planes_dense(gy) else gy.contiguous()
-        gres = gy if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        # (copy: gy may still be read by the asynchronous wgrad lane while autograd accumulates into gres in place)
+        gres = gy.clone() if (ctx.has_res and ctx.needs_input_grad[1]) else None
         dev = gy.device
         g = gy
         if cfg[-1][2]:                                        # activation on the chain output: one pass on a small tensor
