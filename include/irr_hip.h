@@ -125,6 +125,33 @@ int irr_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, const
  * (conv_fwd_kernel<MT,NT,k>); used to label bench.py's roofline line and to find the kernel in rocprof output. */
 int irr_conv2d_fwd_variant(int B, int Cout, int OH, int OW, int k);
 
+/* ---- fp32-faithful 3x3 stride-1 convolution on the bf16 matrix pipe (csrc/conv_x3.hip) --------------------
+ * Same operator and epilogue as irr_conv2d_fwd_f32 for k = 3, stride = 1, Cin >= 16.  Every fp32 operand is split
+ * exactly into three bf16 pieces and each product is accumulated in fp32 from its six leading piece products
+ * (error <= 2^-24 |a*b| per product: the error class of an fp32 FMA chain), which runs at 6/16 of the cost of the
+ * fp32 MFMA.  Weights are consumed pre-split:
+ *   wq[(((chunk*9 + tap)*3 + piece)*CoT + cot)*64 + lane] = 8 bf16 (16 B): output channel cot*32 + (lane & 31),
+ *   input channels chunk*16 + 8*(lane >> 5) + 0..7  (the last chunk covers [Cin-16, Cin) when Cin % 16 != 0, with
+ *   zeros for channels an earlier chunk already covered);  CoT = ceil(Cout/32).
+ * transpose != 0: w is the ORIGINAL (Cin, Cout, 3, 3) tensor used transposed + tap-flipped (stride-1 data gradient).
+ * irr_conv_pack_weights_x3_sub: the combined-matrix variant of irr_conv_pack_weights_sub_f32 (rows of other layers
+ * are left untouched; the destination must be zero-initialised; total_rows % 16 == 0, row_offset % 8 == 0).
+ * irr_conv2d_x3_eligible: non-zero (= a code naming the template instantiation) when irr_conv2d_fwd_x3 accepts the
+ * problem AND it is large enough to fill the chip; 0 -> use irr_conv2d_fwd_f32. */
+long irr_conv_x3_packed_bytes(int Cin, int Cout);
+int irr_conv_pack_weights_x3(const float* w, void* wq, int Cin, int Cout, int transpose, void* stream);
+int irr_conv_pack_weights_x3_sub(const float* w, void* wq, int w_cin, int w_cout, int total_rows, int chan0,
+                                 int nchan, int row_offset, void* stream);
+int irr_conv2d_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil);
+/* tuning knob (tests use 0 to exercise the kernel on small problems): minimum number of blocks a launch must have
+ * for irr_conv2d_x3_eligible to accept it; n < 0 only queries.  Returns the previous value (default 256). */
+int irr_conv_x3_set_min_blocks(int n);
+int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bias, const float* res, float* y,
+                      int B, int Cin, int H, int W, int Cout, int dil,
+                      long x_bs, long y_bs, long res_bs,
+                      int lrelu, float alpha, int accumulate,
+                      const float* mask, long mask_bs, int nmask, void* stream);
+
 /* dW[co][ci][tap] += sum_{b,y,x} gy[b,co,y,x] * x[b,ci,y*stride+(ty-pad), x*stride+(tx-pad)]
  * gw is the plain (Cout,Cin,k,k) tensor and is ACCUMULATED into (caller zeroes it when it wants "=").
  * ws: caller-owned scratch of Cout*Cin*k*k floats (split-K partials land there with coalesced atomics in

@@ -33,6 +33,8 @@ if os.environ.get("IRR_CONV_ABL"):
     COMMON = COMMON + ["-DCONV_ABL=" + os.environ["IRR_CONV_ABL"]]
 if os.environ.get("IRR_CONV_ORDER"):
     COMMON = COMMON + ["-DCONV_ORDER=" + os.environ["IRR_CONV_ORDER"]]
+if os.environ.get("IRR_X3_ABL"):
+    COMMON = COMMON + ["-DX3_ABL=" + os.environ["IRR_X3_ABL"]]
 if os.environ.get("IRR_WG_TR4"):
     COMMON = COMMON + ["-DWG_TR4=1"]
 EXTRA = {"warp.hip": ["-ffp-contract=off"], "resize.hip": ["-ffp-contract=off"],

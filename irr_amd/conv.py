@@ -99,6 +99,51 @@ def packed_weights(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
     return wp
 
 
+# "x3": 3x3 stride-1 convs run on the bf16 matrix pipe with exact 3-way operand splits (csrc/conv_x3.hip, fp32-faithful)
+# wherever irr_conv2d_x3_eligible accepts the problem; "f32": the fp32-MFMA kernel everywhere (A/B runs).
+MATH = os.environ.get("IRR_CONV_MATH", "x3")
+
+
+def set_math(name: str) -> None:
+    global MATH
+    if name not in ("x3", "f32"):
+        raise ValueError(name)
+    MATH = name
+
+
+_X3_ENV_DONE = [False]
+
+
+def x3_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, dil: int) -> int:
+    if MATH != "x3" or BACKEND != "hip":
+        return 0
+    if not _X3_ENV_DONE[0]:
+        _X3_ENV_DONE[0] = True
+        if os.environ.get("IRR_X3_MIN_BLOCKS"):          # tests: exercise the kernel on small problems too
+            hip.lib().irr_conv_x3_set_min_blocks(int(os.environ["IRR_X3_MIN_BLOCKS"]))
+    return int(hip.lib().irr_conv2d_x3_eligible(B, cin, H, W, cout, k, stride, dil))
+
+
+def packed_weights_x3(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
+    """Pre-split (3 x bf16) packed copy of ``weight`` for irr_conv2d_fwd_x3; cached like packed_weights()."""
+    cache = weight.__dict__.setdefault("_irr_packed_x3", {})
+    w = weight.detach()
+    tag = (w.data_ptr(), w._version, tuple(w.shape), WEIGHT_EPOCH[0])
+    hit = cache.get(bool(transpose))
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    cout, cin, k, _ = w.shape
+    assert k == 3
+    lcin, lcout = (cout, cin) if transpose else (cin, cout)
+    n = hip.lib().irr_conv_x3_packed_bytes(lcin, lcout)
+    wq = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == w.device) else \
+        torch.empty(n, device=w.device, dtype=torch.uint8)
+    wc = w.contiguous()
+    hip.call("irr_conv_pack_weights_x3", hip.ptr(wc), hip.ptr(wq), lcin, lcout, int(transpose), hip.stream())
+    cache[bool(transpose)] = (tag, wq)
+    return wq
+
+
 # ----------------------------------------------------------------------------------------------
 # primitives (no autograd)
 # ----------------------------------------------------------------------------------------------
@@ -131,16 +176,27 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                  hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, k, dil, hip.bs(x), hip.bs(out),
                  hip.bs(res) if res is not None else 0, int(lrelu), float(alpha), int(accumulate), hip.stream())
         return out
-    wp = packed_weights(weight, False)
-    args = ("irr_conv2d_fwd_f32", hip.ptr(x), hip.ptr(wp), hip.ptr(bias.detach() if bias is not None else None),
-            hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, oh, ow, k, stride, dil,
-            hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
-            int(lrelu), float(alpha), int(accumulate), None, 0, 0, hip.stream())
+    code = x3_code(B, cin, H, W, cout, k, stride, dil)
+    if code:
+        wq = packed_weights_x3(weight, False)
+        args = ("irr_conv2d_fwd_x3", hip.ptr(x), hip.ptr(wq), hip.ptr(bias.detach() if bias is not None else None),
+                hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, dil,
+                hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
+                int(lrelu), float(alpha), int(accumulate), None, 0, 0, hip.stream())
+        variant = 100000 + code
+    else:
+        wp = packed_weights(weight, False)
+        args = ("irr_conv2d_fwd_f32", hip.ptr(x), hip.ptr(wp), hip.ptr(bias.detach() if bias is not None else None),
+                hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, oh, ow, k, stride, dil,
+                hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
+                int(lrelu), float(alpha), int(accumulate), None, 0, 0, hip.stream())
+        variant = None
     if TIMER is None:
         hip.call(*args)
     else:
-        TIMER.wrap(hip.lib().irr_conv2d_fwd_variant(B, cout, oh, ow, k), 2.0 * B * oh * ow * cout * cin * k * k,
-                   lambda: hip.call(*args))
+        if variant is None:
+            variant = hip.lib().irr_conv2d_fwd_variant(B, cout, oh, ow, k)
+        TIMER.wrap(variant, 2.0 * B * oh * ow * cout * cin * k * k, lambda: hip.call(*args))
     return out
 
 
@@ -178,15 +234,25 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         weight = torch.cat([weight.detach(), torch.zeros_like(weight.detach())], dim=0)
         cout = 2
     if stride == 1 and cout >= 2:
-        wp = packed_weights(weight, True)
-        args = ("irr_conv2d_fwd_f32", hip.ptr(gy), hip.ptr(wp), None, hip.ptr(res), hip.ptr(gx), B, cout, oh, ow, cin, H, W,
-                k, 1, dil, hip.bs(gy), hip.bs(gx), hip.bs(res) if res is not None else 0, 0, float(alpha),
-                int(accumulate), *margs, hip.stream())
+        code = x3_code(B, cout, oh, ow, cin, k, 1, dil)
+        if code:
+            wq = packed_weights_x3(weight, True)
+            args = ("irr_conv2d_fwd_x3", hip.ptr(gy), hip.ptr(wq), None, hip.ptr(res), hip.ptr(gx), B, cout, oh, ow, cin,
+                    dil, hip.bs(gy), hip.bs(gx), hip.bs(res) if res is not None else 0, 0, float(alpha),
+                    int(accumulate), *margs, hip.stream())
+            variant = 100000 + code
+        else:
+            wp = packed_weights(weight, True)
+            args = ("irr_conv2d_fwd_f32", hip.ptr(gy), hip.ptr(wp), None, hip.ptr(res), hip.ptr(gx), B, cout, oh, ow, cin, H, W,
+                    k, 1, dil, hip.bs(gy), hip.bs(gx), hip.bs(res) if res is not None else 0, 0, float(alpha),
+                    int(accumulate), *margs, hip.stream())
+            variant = None
         if TIMER is None:
             hip.call(*args)
         else:
-            TIMER.wrap(hip.lib().irr_conv2d_fwd_variant(B, cin, H, W, k), 2.0 * B * H * W * cout * cin * k * k,
-                       lambda: hip.call(*args), "dgrad")
+            if variant is None:
+                variant = hip.lib().irr_conv2d_fwd_variant(B, cin, H, W, k)
+            TIMER.wrap(variant, 2.0 * B * H * W * cout * cin * k * k, lambda: hip.call(*args), "dgrad")
     elif stride == 2 and k == 3 and dil == 1 and H == 2 * oh and W == 2 * ow and cout >= 2:
         # transposed stride-2 conv == stride-1 conv (flipped weights) of the zero-interleaved gradient
         z = torch.zeros(B, cout, H, W, device=gy.device, dtype=torch.float32)
@@ -437,22 +503,27 @@ class _DenseEstimatorFn(torch.autograd.Function):
             conv_dgrad(g_est, ws[5], 1, 1, (H, W), gx=G[:, :ctot], accumulate=True, mask=buf[:, :ctot], nmask=32)
         else:
             lrelu_bwd_bias(G[:, :32], buf[:, :32], True, G[:, :32], None)
-        packs = _dense_column_packs(ws[:5], cin0)
+        use_x3 = [bool(x3_code(B, t0, H, W, t1 - t0, 3, 1, 1)) for (t0, t1) in ((32, 96), (96, 192), (192, 320), (320, 448), (448, ctot))]
+        packs = _dense_column_packs(ws[:5], cin0, tuple(use_x3))
         grads_w[4], grads_b[4] = wgrad_param(buf[:, 32:ctot], G[:, :32], ctx.wobjs[4], ctx.bobjs[4], 1, 1)   # conv5
         bounds = [(32, 96), (96, 192), (192, 320), (320, 448), (448, ctot)]
         for k_, (t0, t1) in enumerate(bounds):
             last = k_ == 4
             if last and not ctx.needs_input_grad[0]:
                 break
-            args = ("irr_conv2d_fwd_f32", hip.ptr(G), hip.ptr(packs[k_]), None, None, hip.ptr(G[:, t0:t1]), B, t0, H, W,
-                    t1 - t0, H, W, 3, 1, 1, hip.bs(G), hip.bs(G), 0, 0, 1.0, 1,
-                    None if last else hip.ptr(buf[:, t0:t1]), 0 if last else hip.bs(buf), 0 if last else t1 - t0,
-                    hip.stream())
+            margs = (None if last else hip.ptr(buf[:, t0:t1]), 0 if last else hip.bs(buf), 0 if last else t1 - t0)
+            if use_x3[k_]:
+                args = ("irr_conv2d_fwd_x3", hip.ptr(G), hip.ptr(packs[k_]), None, None, hip.ptr(G[:, t0:t1]), B, t0, H, W,
+                        t1 - t0, 1, hip.bs(G), hip.bs(G), 0, 0, 1.0, 1, *margs, hip.stream())
+                variant = 100000 + x3_code(B, t0, H, W, t1 - t0, 3, 1, 1)
+            else:
+                args = ("irr_conv2d_fwd_f32", hip.ptr(G), hip.ptr(packs[k_]), None, None, hip.ptr(G[:, t0:t1]), B, t0, H, W,
+                        t1 - t0, H, W, 3, 1, 1, hip.bs(G), hip.bs(G), 0, 0, 1.0, 1, *margs, hip.stream())
+                variant = hip.lib().irr_conv2d_fwd_variant(B, t1 - t0, H, W, 3)
             if TIMER is None:
                 hip.call(*args)
             else:
-                TIMER.wrap(hip.lib().irr_conv2d_fwd_variant(B, t1 - t0, H, W, 3), 2.0 * B * H * W * t0 * (t1 - t0) * 9,
-                           lambda: hip.call(*args), "dgrad")
+                TIMER.wrap(variant, 2.0 * B * H * W * t0 * (t1 - t0) * 9, lambda: hip.call(*args), "dgrad")
             if not last:                                   # G[:, t0:t1] is now the pre-activation gradient of conv(4-k_)
                 i = 3 - k_
                 grads_w[i], grads_b[i] = wgrad_param(buf[:, t1:ctot], G[:, t0:t1], ctx.wobjs[i], ctx.bobjs[i], 1, 1)
@@ -466,11 +537,12 @@ class _DenseEstimatorFn(torch.autograd.Function):
         return tuple(out)
 
 
-def _dense_column_packs(ws5, cin0: int):
+def _dense_column_packs(ws5, cin0: int, use_x3=(False,) * 5):
     """Combined (transposed, flipped) packed weights for the five column targets c4, c3, c2, c1, x of the DenseNet
-    buffer; cached on the first weight tensor and rebuilt when any of the five conv weights changed."""
+    buffer; cached on the first weight tensor (per kernel-family choice) and rebuilt when any of the five conv weights
+    changed.  use_x3[k]: column k runs on irr_conv2d_fwd_x3 and needs the pre-split layout."""
     tags = tuple((w.data_ptr(), w._version) for w in ws5) + (WEIGHT_EPOCH[0], cin0)
-    holder = ws5[0].__dict__.setdefault("_irr_dense_packs", {})
+    holder = ws5[0].__dict__.setdefault("_irr_dense_packs", {}).setdefault(tuple(use_x3), {})
     if holder.get("tag") == tags:
         return holder["packs"]
     grow = _DenseEstimatorFn.GROW                         # out channels of conv1..conv5
@@ -479,16 +551,23 @@ def _dense_column_packs(ws5, cin0: int):
     bounds = [(32, 96), (96, 192), (192, 320), (320, 448), (448, 448 + cin0)]
     packs = []
     dev = ws5[0].device
-    for (t0, t1) in bounds:
+    for k_, (t0, t1) in enumerate(bounds):
         n = t1 - t0
         cop = (n + 31) // 32 * 32
-        wp = torch.zeros(hip.lib().irr_conv_packed_weight_elems(t0, n, 3), device=dev, dtype=torch.float32)
+        if use_x3[k_]:
+            wp = torch.zeros(hip.lib().irr_conv_x3_packed_bytes(t0, n), device=dev, dtype=torch.uint8)
+        else:
+            wp = torch.zeros(hip.lib().irr_conv_packed_weight_elems(t0, n, 3), device=dev, dtype=torch.float32)
         for i in (5, 4, 3, 2, 1):
             if in0[i - 1] > t0:
                 continue                                  # conv i does not read this slice
             w = ws5[i - 1].detach().contiguous()
-            hip.call("irr_conv_pack_weights_sub_f32", hip.ptr(w), hip.ptr(wp), w.shape[1], w.shape[0], 3,
-                     t0 - in0[i - 1], n, cop, row0[i], hip.stream())
+            if use_x3[k_]:
+                hip.call("irr_conv_pack_weights_x3_sub", hip.ptr(w), hip.ptr(wp), w.shape[1], w.shape[0], t0,
+                         t0 - in0[i - 1], n, row0[i], hip.stream())
+            else:
+                hip.call("irr_conv_pack_weights_sub_f32", hip.ptr(w), hip.ptr(wp), w.shape[1], w.shape[0], 3,
+                         t0 - in0[i - 1], n, cop, row0[i], hip.stream())
         packs.append(wp)
     holder["tag"] = tags
     holder["packs"] = packs

@@ -1,0 +1,506 @@
+// fp32-faithful 3x3 stride-1 convolution on the bf16 matrix pipe of gfx950 (IRR-PWC conv() blocks,
+// models/pwc_modules.py:8-19, models/irr_modules.py:7-18; forward and stride-1 data gradient).
+//
+// Why: the fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 MFMA rate (157 vs 2500 TFLOP/s) and the
+// fp32 direct-conv kernel of conv_fwd.hip already sits at 80-89 % of that peak.  Here every fp32 operand is split
+// EXACTLY into three bf16 pieces, x = hi + mid + lo (round-to-nearest each time: |mid| <= 2^-8 |x|,
+// |lo| <= 2^-17 |x|, and the 24-bit significand is covered completely), and the product a*b is accumulated in
+// fp32 from the six piece products of weight >= 2^-17:
+//     a*b ~= ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh          (dropped: am*bl + al*bm + al*bl <= 2^-24 |ab|)
+// Each piece product is exact in fp32 (8x8-bit significands), so the result carries the same error class as an
+// fp32 FMA chain (one rounding of relative size <= 2^-24 per product) at 6/16 of the fp32-MFMA cost: an effective
+// fp32 roof of 2500/6 = 417 TFLOP/s.
+//
+// Formulation: D[co][px] += W[co][k] * X[k][px] with v_mfma_f32_32x32x16_bf16; k = 16 input channels of one tap.
+//   * block = CT co-tile waves x PG pixel-group waves; a wave owns ONE 32-channel co-tile x NT sub-tiles of 32 pixels
+//     (NT*16 accumulator VGPRs).  The block's pixels form a TR x TC tile of one sample.
+//   * per 16-channel chunk the (TR+2d) x (TC+2d) halo patch is loaded ONCE (coalesced dword loads, out-of-image
+//     positions answered with 0 by the buffer bounds check), split into the three pieces in registers and written
+//     to LDS as six planes [piece][k-group g][pixel] of 16 B (= the 8 bf16 k-values a lane feeds to the MFMA), so the
+//     nine taps are nine shifted conflict-free ds_read_b128 views of the same patch: the split costs 1/9 of a
+//     per-tap split and no activation is re-read from L1/L2 per tap.
+//   * weights are pre-split at pack time (irr_conv_pack_weights_x3): one coalesced 1 KiB buffer_load_dwordx4 per
+//     (chunk, tap, piece, co-tile) is exactly the A fragment; prefetched one tap ahead.
+//   * the next chunk's patch is prefetched into VGPRs while the current chunk's 9 x NT x 6 MFMAs run.
+//   * epilogue identical to conv_fwd.hip (bias, LeakyReLU, residual/scale, "+=", LeakyReLU'-mask).
+#include "common.h"
+
+#ifndef X3_ABL
+#define X3_ABL 0     // ablation builds (timing only, results wrong): 1 = no weight loads in the loop, 2 = no LDS reads in the loop,
+#endif               // 3 = producers skip their global loads, 4 = independent accumulators (no dependent MFMA chain)
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t OOB = 0x80000000u;     // voffset marker: beyond num_records -> the load returns 0, touches nothing
+
+struct X3Args {
+  const float* x;
+  const u32x4* wq;
+  const float* bias;
+  const float* res;
+  float* y;
+  int B, Cin, H, W, Cout;
+  int dil;
+  int CoT, nchunk;
+  int TR, TC, tiles_x, tiles_y;
+  long x_bs, y_bs, res_bs;
+  int lrelu, accumulate;
+  float alpha;
+  const float* mask;
+  long mask_bs;
+  int nmask;
+};
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ float lo_f(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_f(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// exact 3-way bf16 split of 8 floats -> three packed 8 x bf16 fragments
+__device__ __forceinline__ void split8(const float* v, u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a = v[2 * q], b = v[2 * q + 1];
+    const uint32_t hp = pk_bf16(a, b);
+    const float ra = a - lo_f(hp), rb = b - hi_f(hp);
+    const uint32_t mp = pk_bf16(ra, rb);
+    const float sa = ra - lo_f(mp), sb = rb - hi_f(mp);
+    h[q] = hp;
+    m[q] = mp;
+    l[q] = pk_bf16(sa, sb);
+  }
+}
+
+__device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// Block = CT*PG consumer waves (MFMA) + 4 producer waves (load, split, publish), one block per CU, LDS double-buffered:
+// while the consumers run the 9 x NT x 6 MFMAs of chunk c out of buffer c&1, the producers write chunk c+1 into the
+// other buffer (and already hold chunk c+2's global loads in flight).  One s_barrier per chunk.
+template <int CT, int PG, int NT, int PLANE_PIX>
+__global__ __launch_bounds__((CT* PG + 4) * 64) void conv_x3_kernel(const X3Args a) {
+  constexpr int NCONS = CT * PG;
+  constexpr int PTHR = 4 * 64;
+  constexpr int NR = (2 * PLANE_PIX + PTHR - 1) / PTHR;      // staging rounds: one (pixel, k-group) unit per thread per round
+  constexpr int BUF = 6 * PLANE_PIX;                        // 16-B units per buffer: [piece][g][pixel]
+  extern __shared__ u32x4 lds[];                            // 2 buffers
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bt = blockIdx.x;
+  const int tx = bt % a.tiles_x;
+  bt /= a.tiles_x;
+  const int ty = bt % a.tiles_y;
+  const int b = bt / a.tiles_y;
+  const int y0 = ty * a.TR, x0 = tx * a.TC;
+  const int d = a.dil;
+  const int LW = a.TC + 2 * d, LH = a.TR + 2 * d;
+  const long hw = (long)a.H * a.W;
+
+  if (wave >= NCONS) {
+    // ================= producers =================
+    const int ptid = tid - NCONS * 64;
+    const int npix = LH * LW;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)0x80000000u, 0x00020000);
+    uint32_t svoff[NR];
+    int swidx[NR];                                          // LDS index (16-B units) of the unit's hi piece, -1 = none
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int u = r * PTHR + ptid;
+      const int gg = u >= npix ? 1 : 0;
+      const int pix = u - gg * npix;
+      const bool inr = u < 2 * npix;
+      const int ly = pix / LW, lx = pix - ly * LW;
+      const int iy = y0 - d + ly, ix = x0 - d + lx;
+      const bool ok = inr && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      svoff[r] = ok ? (uint32_t)(((long)b * a.x_bs + (long)gg * 8 * hw + (long)iy * a.W + ix) * 4) : OOB;
+      swidx[r] = inr ? gg * PLANE_PIX + pix : -1;
+    }
+    const uint32_t hw4 = (uint32_t)(hw * 4);
+    const int tail_base = a.Cin - 16;                      // last chunk re-reads [Cin-16, Cin) (duplicates have zero weights)
+    float raw[NR][8];
+    auto issue_x = [&](int c) {
+      const int ch0 = (c == a.nchunk - 1) ? tail_base : c * 16;
+      const uint32_t s0 = (uint32_t)ch0 * hw4;
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          raw[r][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)svoff[r], (int)(s0 + e * hw4), 0));
+    };
+    issue_x(0);
+    for (int c = 0; c < a.nchunk; ++c) {
+      u32x4* buf = lds + (c & 1) * BUF;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        u32x4 h, m, l;
+        split8(raw[r], h, m, l);
+        if (swidx[r] >= 0) {
+          buf[swidx[r]] = h;
+          buf[swidx[r] + 2 * PLANE_PIX] = m;
+          buf[swidx[r] + 4 * PLANE_PIX] = l;
+        }
+      }
+      if (c + 1 < a.nchunk && X3_ABL != 3) issue_x(c + 1);
+      __syncthreads();                                      // barrier #c: chunk c is published
+    }
+    return;
+  }
+
+  // ================= consumers =================
+  const int ct = wave % CT, pg = wave / CT;
+  const int j = lane & 31, g = lane >> 5;
+  const int cot = blockIdx.y * CT + ct;
+  const bool active = cot < a.CoT;
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wq, (short)0, (int)0xffffffffu, 0x00020000);
+  int xidx[NT];                                            // LDS index (16-B units) of the lane's pixel, tap (0,0), piece hi
+#pragma unroll
+  for (int s = 0; s < NT; ++s) {
+    const int t = (pg * NT + s) * 32 + j;
+    const int row = t / a.TC, col = t - row * a.TC;
+    xidx[s] = g * PLANE_PIX + row * LW + col;
+  }
+  const uint32_t wvoff = (uint32_t)((cot * 64 + lane) * 16);
+  const uint32_t wpiece = (uint32_t)a.CoT * 1024u;         // bytes between pieces
+  const uint32_t wtap = 3u * wpiece;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int s = 0; s < NT; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+  // weight fragments: 3 slots, fetched TWO taps ahead (9 taps = 0 mod 3, so the slot of a tap is the same in every chunk)
+  u32x4 wa[3][3];
+  auto issue_w = [&](int slot, int c, int tap) {
+    const uint32_t so = ((uint32_t)c * 9u + (uint32_t)tap) * wtap;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      wa[slot][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)wvoff, (int)(so + p * wpiece), 0));
+  };
+  if (active) {
+    issue_w(0, 0, 0);
+    issue_w(1, 0, 1);
+  }
+
+  // Sub-tiles go through the matrix pipe in PAIRS with alternating accumulators (a dependent MFMA cannot issue until
+  // its predecessor has written back).  One step = one (tap, pair); the LDS reads of step i+1 are issued ahead of the
+  // MFMAs of step i, across tap boundaries too, so only the first step after a barrier waits for the LDS.
+  constexpr int NP = (NT + 1) / 2;
+  constexpr int NSTEP = 9 * NP;
+  u32x4 xb[2][2][3];                               // [buffer][sub-tile of the pair][piece]
+
+  for (int c = 0; c < a.nchunk; ++c) {
+    __syncthreads();                                        // barrier #c: chunk c is in buffer c&1
+    if (!active) continue;
+    const u32x4* buf = lds + (c & 1) * BUF;
+    const bool more = c + 1 < a.nchunk;
+    auto read_step = [&](int bsel, int step) {
+      const int tap = step / NP, sp = step - tap * NP;
+      const int toff = ((tap / 3) * LW + (tap % 3)) * d;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          if (2 * sp + q < NT) xb[bsel][q][p] = buf[xidx[2 * sp + q] + toff + 2 * p * PLANE_PIX];
+    };
+    read_step(0, 0);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      const int tap = step / NP, sp = step - tap * NP;
+      const int slot = tap % 3;
+      const int cur = step & 1;
+      if (sp == 0 && X3_ABL != 1) {                // weights two taps ahead (into the slot tap-1 just released)
+        const int t2 = tap + 2;
+        const int nc = t2 >= 9 ? (more ? c + 1 : c) : c;
+        issue_w(t2 % 3, nc, t2 % 9);
+      }
+      if (step + 1 < NSTEP) read_step(cur ^ 1, step + 1);
+      __builtin_amdgcn_sched_barrier(0);          // keep the next step's LDS reads AHEAD of this step's MFMAs
+      const int s0 = 2 * sp, s1 = 2 * sp + 1;
+      if (s1 < NT) {
+        f32x16 t0 = acc[s0], t1 = acc[s1];
+        t0 = mma(wa[slot][2], xb[cur][0][0], t0);      // lo * hi
+        t1 = mma(wa[slot][2], xb[cur][1][0], t1);
+        t0 = mma(wa[slot][0], xb[cur][0][2], t0);      // hi * lo
+        t1 = mma(wa[slot][0], xb[cur][1][2], t1);
+        t0 = mma(wa[slot][1], xb[cur][0][1], t0);      // mid * mid
+        t1 = mma(wa[slot][1], xb[cur][1][1], t1);
+        t0 = mma(wa[slot][1], xb[cur][0][0], t0);      // mid * hi
+        t1 = mma(wa[slot][1], xb[cur][1][0], t1);
+        t0 = mma(wa[slot][0], xb[cur][0][1], t0);      // hi * mid
+        t1 = mma(wa[slot][0], xb[cur][1][1], t1);
+        t0 = mma(wa[slot][0], xb[cur][0][0], t0);      // hi * hi
+        t1 = mma(wa[slot][0], xb[cur][1][0], t1);
+        acc[s0] = t0;
+        acc[s1] = t1;
+      } else {
+        f32x16 t0 = acc[s0];
+        t0 = mma(wa[slot][2], xb[cur][0][0], t0);
+        t0 = mma(wa[slot][0], xb[cur][0][2], t0);
+        t0 = mma(wa[slot][1], xb[cur][0][1], t0);
+        t0 = mma(wa[slot][1], xb[cur][0][0], t0);
+        t0 = mma(wa[slot][0], xb[cur][0][1], t0);
+        t0 = mma(wa[slot][0], xb[cur][0][0], t0);
+        acc[s0] = t0;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!active) return;
+
+  // ---- epilogue: D[i][jj], i = (r&3) + 8*(r>>2) + 4*g, jj = lane&31 ----
+  const long ohw = hw;
+#pragma unroll
+  for (int s = 0; s < NT; ++s) {
+    const int t = (pg * NT + s) * 32 + j;
+    const int row = t / a.TC, col = t - row * a.TC;
+    const int oy = y0 + row, ox = x0 + col;
+    if (oy >= a.H || ox >= a.W) continue;
+    const long pofs = (long)oy * a.W + ox;
+    float* yb = a.y + (long)b * a.y_bs + pofs;
+    const float* rb = a.res ? a.res + (long)b * a.res_bs + pofs : nullptr;
+    const float* mb = a.mask ? a.mask + (long)b * a.mask_bs + pofs : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      if (co >= a.Cout) continue;
+      float v = acc[s][r] + (a.bias ? a.bias[co] : 0.f);
+      if (a.lrelu) v = irr_lrelu(v);
+      float* dst = yb + (long)co * ohw;
+      if (rb) v = rb[(long)co * ohw] + a.alpha * v;
+      else v *= a.alpha;
+      if (a.accumulate) v += *dst;
+      if (mb && co < a.nmask) v *= irr_lrelu_grad(mb[(long)co * ohw]);
+      *dst = v;
+    }
+  }
+}
+
+// ---- weight packing: wq[(((chunk*9 + tap)*3 + piece)*CoT + cot)*64 + lane] = 8 bf16 (k-group g = lane>>5, row i = lane&31) ----
+// mode 0: w is (Cout, Cin, 3, 3)                    -> forward
+// mode 1: w is (Cin, Cout, 3, 3) = original layout, used transposed + flipped -> stride-1 data gradient
+// mode 2: sub-block of a COMBINED data-gradient matrix (DenseNet backward): rows [row_offset, row_offset + w_cout)
+//         take layer weights w (w_cout, w_cin, 3, 3) transposed+flipped, restricted to input channels [chan0, chan0+Cout)
+__global__ void pack_x3_kernel(const float* __restrict__ w, u32x4* __restrict__ wq, int Cin, int Cout, int CoT, int nchunk,
+                               int mode, int w_cin, int chan0, int row_offset, int w_cout, long nunits) {
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nunits) return;
+  const int lane = (int)(u & 63);
+  long r = u >> 6;
+  const int cot = (int)(r % CoT);
+  r /= CoT;
+  const int tap = (int)(r % 9);
+  const int chunk = (int)(r / 9);
+  const int g = lane >> 5, i = lane & 31;
+  const int co = cot * 32 + i;
+  const bool tail = (chunk == nchunk - 1) && (Cin & 15);
+  const int ch0 = (tail ? Cin - 16 : chunk * 16) + 8 * g;
+  float v[8];
+  bool any = false;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = ch0 + e;
+    float val = 0.f;
+    const bool dup = tail && ci < (nchunk - 1) * 16;
+    if (!dup && ci >= 0 && ci < Cin && co < Cout) {
+      if (mode == 0) val = w[((long)co * Cin + ci) * 9 + tap];
+      else if (mode == 1) val = w[((long)ci * Cout + co) * 9 + (8 - tap)];
+      else if (ci >= row_offset && ci < row_offset + w_cout) {
+        val = w[((long)(ci - row_offset) * w_cin + chan0 + co) * 9 + (8 - tap)];
+        any = true;
+      }
+    }
+    v[e] = val;
+  }
+  if (mode == 2 && !any) return;                   // rows of other layers: leave untouched
+  u32x4 h, m, l;
+  split8(v, h, m, l);
+  const long base = (((long)chunk * 9 + tap) * 3 * CoT + cot) * 64 + lane;
+  wq[base] = h;
+  wq[base + (long)CoT * 64] = m;
+  wq[base + 2L * CoT * 64] = l;
+}
+
+struct TileCfg { int nt, tr, tc; };
+
+// choose the TR x TC tile (TR*TC = 32*NT*PG pixels) that wastes the fewest MFMA columns, then the smallest halo
+static bool pick_tile(int H, int W, int dil, int PG, int plane_pix, const int* nts, int n_nts, TileCfg* out) {
+  double best = 1e30;
+  bool found = false;
+  for (int q = 0; q < n_nts; ++q) {
+    const int P = 32 * nts[q] * PG;
+    for (int tc = 4; tc <= P; ++tc) {
+      if (P % tc) continue;
+      const int tr = P / tc;
+      if ((long)(tr + 2 * dil) * (tc + 2 * dil) > plane_pix) continue;
+      const double tiles = (double)((H + tr - 1) / tr) * ((W + tc - 1) / tc);
+      const double cost = tiles * P * (1.0 + 0.05 * (double)(tr + 2 * dil) * (tc + 2 * dil) / P);
+      if (cost < best) { best = cost; out->nt = nts[q]; out->tr = tr; out->tc = tc; found = true; }
+    }
+  }
+  return found;
+}
+
+template <int CT, int PG, int NT, int PLANE_PIX>
+int launch_x3(X3Args& a, const TileCfg& t, hipStream_t st) {
+  a.TR = t.tr; a.TC = t.tc;
+  a.tiles_x = (a.W + t.tc - 1) / t.tc;
+  a.tiles_y = (a.H + t.tr - 1) / t.tr;
+  dim3 grid((unsigned)((long)a.B * a.tiles_x * a.tiles_y), (unsigned)((a.CoT + CT - 1) / CT), 1);
+  constexpr size_t lds_bytes = 2 * 6 * (size_t)PLANE_PIX * 16;
+  static bool attr_set = false;                    // > 64 KiB of LDS needs the opt-in (once per instantiation)
+  if (!attr_set) {
+    hipError_t e0 = hipFuncSetAttribute((const void*)conv_x3_kernel<CT, PG, NT, PLANE_PIX>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e0 != hipSuccess) return (int)e0;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_x3_kernel<CT, PG, NT, PLANE_PIX>), grid, dim3((CT * PG + 4) * 64), lds_bytes, st, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+// block shape: CT co-tile waves (x PG pixel groups) per block
+static int pick_ct(int CoT) {
+  if (CoT == 1) return 1;
+  if (CoT == 2) return 2;
+  if (CoT % 4 == 0) return 4;
+  if (CoT % 3 == 0) return 3;
+  return (CoT % 4 == 3 || CoT > 8) ? 4 : 3;
+}
+
+struct Plan { int ct, pg, plane; TileCfg t; long blocks; };
+
+static int g_min_blocks = 256;     // launches with fewer blocks cannot fill the 256 CUs: they stay on the fp32 kernels
+
+static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) {
+  if (Cin < 16 || dil < 1 || H < 8 || W < 8) return false;
+  if (Cin < 64 && g_min_blocks > 0) return false;       // two or three chunks: prologue/epilogue dominate, fp32 kernel wins
+  const int CoT = (Cout + 31) / 32;
+  p->ct = pick_ct(CoT);
+  static const int nts78[2] = {8, 7};
+  static const int nts4[1] = {4};
+  bool ok;
+  if (p->ct >= 3) {
+    p->pg = 1;
+    p->plane = 352;
+    ok = pick_tile(H, W, dil, 1, 352, nts78, 2, &p->t);
+    if (!ok) { p->plane = 616; ok = pick_tile(H, W, dil, 1, 616, nts78, 2, &p->t); }
+  } else if (p->ct == 2) {
+    p->pg = 2;
+    p->plane = 616;
+    ok = pick_tile(H, W, dil, 2, 616, nts78, 2, &p->t);
+  } else {
+    p->pg = 4;
+    p->plane = 616;
+    ok = pick_tile(H, W, dil, 4, 616, nts4, 1, &p->t);
+  }
+  if (!ok) return false;
+  p->blocks = (long)B * ((H + p->t.tr - 1) / p->t.tr) * ((W + p->t.tc - 1) / p->t.tc) * ((CoT + p->ct - 1) / p->ct);
+  // padded work must stay close to the real work, and the launch must fill the chip
+  const double eff = (double)H * W / ((double)((H + p->t.tr - 1) / p->t.tr) * ((W + p->t.tc - 1) / p->t.tc) * p->t.tr * p->t.tc);
+  if (eff < 0.70) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int irr_conv_x3_set_min_blocks(int n) {
+  const int old = g_min_blocks;
+  if (n >= 0) g_min_blocks = n;
+  return old;
+}
+
+extern "C" long irr_conv_x3_packed_bytes(int Cin, int Cout) {
+  const long CoT = (Cout + 31) / 32, nchunk = (Cin + 15) / 16;
+  return nchunk * 9 * 3 * CoT * 64 * 16;
+}
+
+extern "C" int irr_conv_pack_weights_x3(const float* w, void* wq, int Cin, int Cout, int transpose, void* stream) {
+  if (!w || !wq || Cin < 16 || Cout <= 0) return IRR_EINVAL;
+  const int CoT = (Cout + 31) / 32, nchunk = (Cin + 15) / 16;
+  const long nunits = (long)nchunk * 9 * CoT * 64;
+  hipLaunchKernelGGL(pack_x3_kernel, dim3(irr_cdiv(nunits, 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)wq, Cin, Cout,
+                     CoT, nchunk, transpose ? 1 : 0, 0, 0, 0, 0, nunits);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_conv_pack_weights_x3_sub(const float* w, void* wq, int w_cin, int w_cout, int total_rows, int chan0,
+                                            int nchan, int row_offset, void* stream) {
+  if (!w || !wq || w_cin <= 0 || w_cout <= 0 || total_rows < 16 || (total_rows & 15) || chan0 < 0 || nchan <= 0 ||
+      chan0 + nchan > w_cin || row_offset < 0 || (row_offset & 7) || (w_cout & 7) || row_offset + w_cout > total_rows)
+    return IRR_EINVAL;
+  const int CoT = (nchan + 31) / 32, nchunk = total_rows / 16;
+  const long nunits = (long)nchunk * 9 * CoT * 64;
+  hipLaunchKernelGGL(pack_x3_kernel, dim3(irr_cdiv(nunits, 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)wq, total_rows,
+                     nchan, CoT, nchunk, 2, w_cin, chan0, row_offset, w_cout, nunits);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_conv2d_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil) {
+  if (k != 3 || stride != 1 || B <= 0) return 0;
+  Plan p;
+  if (!make_plan(B, Cin, H, W, Cout, dil, &p)) return 0;
+  if (p.blocks < g_min_blocks) return 0;            // tiny pyramid levels stay on the fp32 split-K kernel
+  return p.ct * 1000 + p.pg * 100 + p.t.nt * 10 + (p.plane == 352 ? 1 : p.plane == 616 ? 2 : 3);
+}
+
+extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bias, const float* res, float* y, int B,
+                                 int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
+                                 float alpha, int accumulate, const float* mask, long mask_bs, int nmask, void* stream) {
+  if (!x || !wq || !y || B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1) return IRR_EINVAL;
+  Plan p;
+  if (!make_plan(B, Cin, H, W, Cout, dil, &p)) return IRR_EINVAL;
+  X3Args a;
+  a.wq = (const u32x4*)wq; a.bias = bias;
+  a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.dil = dil;
+  a.CoT = (Cout + 31) / 32; a.nchunk = (Cin + 15) / 16;
+  a.x_bs = x_bs; a.y_bs = y_bs; a.res_bs = res_bs;
+  a.lrelu = lrelu; a.accumulate = accumulate; a.alpha = alpha;
+  a.mask_bs = mask_bs; a.nmask = nmask;
+  // 32-bit byte voffsets below the 2 GiB out-of-range marker: split the batch accordingly
+  const long lim = (1L << 29) - (long)(Cin + 16) * H * W - 64;        // elements
+  if (lim <= 0) return IRR_EINVAL;
+  long per = x_bs > 0 ? lim / x_bs : B;
+  if (per < 1) per = 1;
+  if (per > B) per = B;
+  for (int b0 = 0; b0 < B; b0 += (int)per) {
+    a.B = (B - b0) < per ? (B - b0) : (int)per;
+    a.x = x + (long)b0 * x_bs;
+    a.y = y + (long)b0 * y_bs;
+    a.res = res ? res + (long)b0 * res_bs : nullptr;
+    a.mask = mask ? mask + (long)b0 * mask_bs : nullptr;
+    int rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int key = p.ct * 1000 + p.pg * 100 + p.t.nt * 10 + (p.plane == 352 ? 1 : p.plane == 616 ? 2 : 3);
+    switch (key) {
+      case 4181: rc = launch_x3<4, 1, 8, 352>(a, p.t, st); break;
+      case 4171: rc = launch_x3<4, 1, 7, 352>(a, p.t, st); break;
+      case 4182: rc = launch_x3<4, 1, 8, 616>(a, p.t, st); break;
+      case 4172: rc = launch_x3<4, 1, 7, 616>(a, p.t, st); break;
+      case 3181: rc = launch_x3<3, 1, 8, 352>(a, p.t, st); break;
+      case 3171: rc = launch_x3<3, 1, 7, 352>(a, p.t, st); break;
+      case 3182: rc = launch_x3<3, 1, 8, 616>(a, p.t, st); break;
+      case 3172: rc = launch_x3<3, 1, 7, 616>(a, p.t, st); break;
+      case 2282: rc = launch_x3<2, 2, 8, 616>(a, p.t, st); break;
+      case 2272: rc = launch_x3<2, 2, 7, 616>(a, p.t, st); break;
+      case 1442: rc = launch_x3<1, 4, 4, 616>(a, p.t, st); break;
+      default: return IRR_EINVAL;
+    }
+    if (rc) return rc;
+  }
+  return 0;
+}

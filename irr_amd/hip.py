@@ -19,7 +19,7 @@ HEADER = os.path.join(os.path.dirname(_PKG), "include", "irr_hip.h")
 LIB_PATH = os.path.join(_PKG, "lib", "libirr_hip.so")
 
 _CTYPES = {
-    "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "void*": ctypes.c_void_p,
+    "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
     "const int*": ctypes.c_void_p, "int*": ctypes.c_void_p,
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
 }

@@ -1,0 +1,78 @@
+"""Accuracy (vs an fp64 CPU convolution) and speed of the bf16x3-split conv kernel next to the fp32-MFMA kernel."""
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from irr_amd import conv as C, hip  # noqa: E402
+
+ACC = [  # cin, cout, dil, B, H, W
+    (115, 128, 1, 2, 24, 28), (565, 128, 1, 1, 16, 48), (371, 96, 1, 1, 33, 47), (531, 32, 1, 2, 20, 36),
+    (128, 64, 1, 1, 40, 24), (32, 32, 1, 1, 70, 90), (128, 128, 2, 1, 24, 28), (128, 128, 4, 1, 24, 28), (16, 565, 1, 1, 24, 28),
+    (243, 128, 1, 1, 48, 56),
+]
+PERF = [  # name, cin, cout, dil, B, H, W
+    ("ctx.conv0 L4", 565, 128, 1, 64, 96, 112), ("dense.conv1 L4", 115, 128, 1, 64, 96, 112),
+    ("dense.conv3 L4", 371, 96, 1, 64, 96, 112), ("dense.conv5 L4", 531, 32, 1, 64, 96, 112),
+    ("refine 128->64 L4", 128, 64, 1, 64, 96, 112), ("ctx d2 L4", 128, 128, 2, 64, 96, 112), ("ctx d4 L4", 128, 128, 4, 64, 96, 112),
+    ("occup 32->32 L6", 32, 32, 1, 32, 384, 448), ("occup 32->32 L5", 32, 32, 1, 64, 192, 224),
+    ("dense.conv2 L3", 243, 128, 1, 64, 48, 56), ("dgrad ctx0 L4", 128, 565, 1, 64, 96, 112),
+]
+
+
+def timeit(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    hip.lib().irr_conv_x3_set_min_blocks(0)
+    print("== accuracy: max |err| / max |ref|, fp64 reference ==")
+    for cin, cout, dil, B, H, W in ACC:
+        g = torch.Generator().manual_seed(cin * 7 + cout)
+        x = torch.randn(B, cin, H, W, generator=g) * torch.exp(torch.randn(B, cin, 1, 1, generator=g))
+        w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=dil, dilation=dil)
+        gy = torch.randn(B, cout, H, W, generator=g)
+        gref = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=dil, dilation=dil)
+        out = {}
+        for m in ("f32", "x3"):
+            C.set_math(m)
+            code = C.x3_code(B, cin, H, W, cout, 3, 1, dil)
+            y = C.conv_forward(x.cuda(), w.cuda(), b.cuda(), 1, dil, False)
+            gx = C.conv_dgrad(gy.cuda(), w.cuda(), 1, dil, (H, W))
+            out[m] = ((y.cpu().double() - ref).abs().max().item() / ref.abs().max().item(),
+                      (gx.cpu().double() - gref).abs().max().item() / gref.abs().max().item(), code)
+        print(f"{cin:4d}->{cout:4d} d{dil} {B}x{H}x{W}: fwd f32 {out['f32'][0]:.2e} x3 {out['x3'][0]:.2e} | dgrad f32 {out['f32'][1]:.2e} "
+              f"x3 {out['x3'][1]:.2e}  code {out['x3'][2]}", flush=True)
+    hip.lib().irr_conv_x3_set_min_blocks(256)
+    if "--noperf" in sys.argv:
+        return
+    print("== speed ==")
+    for name, cin, cout, dil, B, H, W in PERF:
+        x = torch.randn(B, cin, H, W, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+        b = torch.randn(cout, device="cuda")
+        gf = 2.0 * B * H * W * cout * cin * 9 / 1e9
+        row = f"{name:20s} {gf:8.1f} GF "
+        for m in ("f32", "x3"):
+            C.set_math(m)
+            t = timeit(lambda: C.conv_forward(x, w, b, 1, dil, True))
+            row += f" {m}: {t:6.2f} ms {gf / t:6.1f} TF"
+        row += f"  code {C.x3_code(B, cin, H, W, cout, 3, 1, dil)}"
+        print(row, flush=True)
+
+
+if __name__ == "__main__":
+    main()
