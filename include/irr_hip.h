@@ -144,7 +144,7 @@ int irr_conv_pack_weights_x3_sub(const float* w, void* wq, int w_cin, int w_cout
                                  int nchan, int row_offset, void* stream);
 int irr_conv2d_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil);
 /* tuning knob (tests use 0 to exercise the kernel on small problems): minimum number of blocks a launch must have
- * for irr_conv2d_x3_eligible to accept it; n < 0 only queries.  Returns the previous value (default 256). */
+ * for irr_conv2d_x3_eligible to accept it; n < 0 only queries.  Returns the previous value (default 384). */
 int irr_conv_x3_set_min_blocks(int n);
 int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bias, const float* res, float* y,
                       int B, int Cin, int H, int W, int Cout, int dil,

@@ -21,7 +21,6 @@
 //     per-tap split and no activation is re-read from L1/L2 per tap.
 //   * weights are pre-split at pack time (irr_conv_pack_weights_x3): one coalesced 1 KiB buffer_load_dwordx4 per
 //     (chunk, tap, piece, co-tile) is exactly the A fragment; prefetched one tap ahead.
-//   * the next chunk's patch is prefetched into VGPRs while the current chunk's 9 x NT x 6 MFMAs run.
 //   * epilogue identical to conv_fwd.hip (bias, LeakyReLU, residual/scale, "+=", LeakyReLU'-mask).
 #include "common.h"
 
@@ -83,20 +82,23 @@ __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// Block = CT*PG consumer waves (MFMA) + 4 producer waves (load, split, publish), one block per CU, LDS double-buffered:
-// while the consumers run the 9 x NT x 6 MFMAs of chunk c out of buffer c&1, the producers write chunk c+1 into the
-// other buffer (and already hold chunk c+2's global loads in flight).  One s_barrier per chunk.
+// Block = CT*PG symmetric waves, two blocks per CU (256 registers per wave, 128 of them accumulators): every wave
+// takes part in staging a chunk's patch (load -> split -> LDS), then runs its 9 x NT x 6 MFMAs; while one block
+// stages, the other block on the CU keeps the matrix pipe busy.  (A producer/consumer-specialised variant with one
+// 8-wave block per CU and double-buffered LDS was built and measured: 5-20 % slower on every layer shape, because
+// nothing overlaps a block's prologue/epilogue there; on random data both variants run into the same power-limited
+// clock: all-zero operands run 32 % faster than random ones on the same launch.)
 template <int CT, int PG, int NT, int PLANE_PIX>
-__global__ __launch_bounds__((CT* PG + 4) * 64) void conv_x3_kernel(const X3Args a) {
-  constexpr int NCONS = CT * PG;
-  constexpr int PTHR = 4 * 64;
-  constexpr int NR = (2 * PLANE_PIX + PTHR - 1) / PTHR;      // staging rounds: one (pixel, k-group) unit per thread per round
-  constexpr int BUF = 6 * PLANE_PIX;                        // 16-B units per buffer: [piece][g][pixel]
-  extern __shared__ u32x4 lds[];                            // 2 buffers
+__global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a) {
+  constexpr int NTHR = CT * PG * 64;
+  constexpr int NR = (2 * PLANE_PIX + NTHR - 1) / NTHR;      // staging rounds: one (pixel, k-group) unit per thread per round
+  __shared__ u32x4 lds[6 * PLANE_PIX];                      // [piece][g][pixel] x 16 B
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave % CT, pg = wave / CT;
+  const int j = lane & 31, g = lane >> 5;
   int bt = blockIdx.x;
   const int tx = bt % a.tiles_x;
   bt /= a.tiles_x;
@@ -105,64 +107,33 @@ __global__ __launch_bounds__((CT* PG + 4) * 64) void conv_x3_kernel(const X3Args
   const int y0 = ty * a.TR, x0 = tx * a.TC;
   const int d = a.dil;
   const int LW = a.TC + 2 * d, LH = a.TR + 2 * d;
+  const int npix = LH * LW;
   const long hw = (long)a.H * a.W;
-
-  if (wave >= NCONS) {
-    // ================= producers =================
-    const int ptid = tid - NCONS * 64;
-    const int npix = LH * LW;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)0x80000000u, 0x00020000);
-    uint32_t svoff[NR];
-    int swidx[NR];                                          // LDS index (16-B units) of the unit's hi piece, -1 = none
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const int u = r * PTHR + ptid;
-      const int gg = u >= npix ? 1 : 0;
-      const int pix = u - gg * npix;
-      const bool inr = u < 2 * npix;
-      const int ly = pix / LW, lx = pix - ly * LW;
-      const int iy = y0 - d + ly, ix = x0 - d + lx;
-      const bool ok = inr && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      svoff[r] = ok ? (uint32_t)(((long)b * a.x_bs + (long)gg * 8 * hw + (long)iy * a.W + ix) * 4) : OOB;
-      swidx[r] = inr ? gg * PLANE_PIX + pix : -1;
-    }
-    const uint32_t hw4 = (uint32_t)(hw * 4);
-    const int tail_base = a.Cin - 16;                      // last chunk re-reads [Cin-16, Cin) (duplicates have zero weights)
-    float raw[NR][8];
-    auto issue_x = [&](int c) {
-      const int ch0 = (c == a.nchunk - 1) ? tail_base : c * 16;
-      const uint32_t s0 = (uint32_t)ch0 * hw4;
-#pragma unroll
-      for (int r = 0; r < NR; ++r)
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          raw[r][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)svoff[r], (int)(s0 + e * hw4), 0));
-    };
-    issue_x(0);
-    for (int c = 0; c < a.nchunk; ++c) {
-      u32x4* buf = lds + (c & 1) * BUF;
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        u32x4 h, m, l;
-        split8(raw[r], h, m, l);
-        if (swidx[r] >= 0) {
-          buf[swidx[r]] = h;
-          buf[swidx[r] + 2 * PLANE_PIX] = m;
-          buf[swidx[r] + 4 * PLANE_PIX] = l;
-        }
-      }
-      if (c + 1 < a.nchunk && X3_ABL != 3) issue_x(c + 1);
-      __syncthreads();                                      // barrier #c: chunk c is published
-    }
-    return;
-  }
-
-  // ================= consumers =================
-  const int ct = wave % CT, pg = wave / CT;
-  const int j = lane & 31, g = lane >> 5;
   const int cot = blockIdx.y * CT + ct;
   const bool active = cot < a.CoT;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)0x80000000u, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wq, (short)0, (int)0xffffffffu, 0x00020000);
+
+  // ---- staging roles ----
+  uint32_t svoff[NR];
+  int swidx[NR];                                            // LDS index (16-B units) of the unit's hi piece, -1 = none
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int u = r * NTHR + tid;
+    const int gg = u >= npix ? 1 : 0;
+    const int pix = u - gg * npix;
+    const bool inr = u < 2 * npix;
+    const int ly = pix / LW, lx = pix - ly * LW;
+    const int iy = y0 - d + ly, ix = x0 - d + lx;
+    const bool ok = inr && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    svoff[r] = ok ? (uint32_t)(((long)b * a.x_bs + (long)gg * 8 * hw + (long)iy * a.W + ix) * 4) : OOB;
+    swidx[r] = inr ? gg * PLANE_PIX + pix : -1;
+  }
+  const uint32_t hw4 = (uint32_t)(hw * 4);
+  const int tail_base = a.Cin - 16;                        // last chunk re-reads [Cin-16, Cin) (duplicates have zero weights)
+
+  // ---- compute roles ----
   int xidx[NT];                                            // LDS index (16-B units) of the lane's pixel, tap (0,0), piece hi
 #pragma unroll
   for (int s = 0; s < NT; ++s) {
@@ -180,82 +151,80 @@ __global__ __launch_bounds__((CT* PG + 4) * 64) void conv_x3_kernel(const X3Args
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 
-  // weight fragments: 3 slots, fetched TWO taps ahead (9 taps = 0 mod 3, so the slot of a tap is the same in every chunk)
-  u32x4 wa[3][3];
+  float raw[NR][8];
+  auto issue_x = [&](int c) {
+    const int ch0 = (c == a.nchunk - 1) ? tail_base : c * 16;
+    const uint32_t s0 = (uint32_t)ch0 * hw4;
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        raw[r][e] = (X3_ABL == 3 && c > 0) ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)svoff[r], (int)(s0 + e * hw4), 0));
+  };
+  u32x4 wa[2][3];
   auto issue_w = [&](int slot, int c, int tap) {
     const uint32_t so = ((uint32_t)c * 9u + (uint32_t)tap) * wtap;
 #pragma unroll
     for (int p = 0; p < 3; ++p)
       wa[slot][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)wvoff, (int)(so + p * wpiece), 0));
   };
-  if (active) {
-    issue_w(0, 0, 0);
-    issue_w(1, 0, 1);
-  }
-
-  // Sub-tiles go through the matrix pipe in PAIRS with alternating accumulators (a dependent MFMA cannot issue until
-  // its predecessor has written back).  One step = one (tap, pair); the LDS reads of step i+1 are issued ahead of the
-  // MFMAs of step i, across tap boundaries too, so only the first step after a barrier waits for the LDS.
-  constexpr int NP = (NT + 1) / 2;
-  constexpr int NSTEP = 9 * NP;
-  u32x4 xb[2][2][3];                               // [buffer][sub-tile of the pair][piece]
+  if (active) issue_w(0, 0, 0);
 
   for (int c = 0; c < a.nchunk; ++c) {
-    __syncthreads();                                        // barrier #c: chunk c is in buffer c&1
-    if (!active) continue;
-    const u32x4* buf = lds + (c & 1) * BUF;
-    const bool more = c + 1 < a.nchunk;
-    auto read_step = [&](int bsel, int step) {
-      const int tap = step / NP, sp = step - tap * NP;
-      const int toff = ((tap / 3) * LW + (tap % 3)) * d;
+    // load the chunk's halo patch, split it into its three bf16 pieces and publish it.  (No register prefetch across
+    // the MFMA phase: 128 of the wave's 256 registers are accumulators; the second block on the CU covers the wait.)
+    issue_x(c);
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          if (2 * sp + q < NT) xb[bsel][q][p] = buf[xidx[2 * sp + q] + toff + 2 * p * PLANE_PIX];
-    };
-    read_step(0, 0);
-#pragma unroll
-    for (int step = 0; step < NSTEP; ++step) {
-      const int tap = step / NP, sp = step - tap * NP;
-      const int slot = tap % 3;
-      const int cur = step & 1;
-      if (sp == 0 && X3_ABL != 1) {                // weights two taps ahead (into the slot tap-1 just released)
-        const int t2 = tap + 2;
-        const int nc = t2 >= 9 ? (more ? c + 1 : c) : c;
-        issue_w(t2 % 3, nc, t2 % 9);
+    for (int r = 0; r < NR; ++r) {
+      u32x4 h, m, l;
+      split8(raw[r], h, m, l);
+      if (swidx[r] >= 0) {
+        lds[swidx[r]] = h;
+        lds[swidx[r] + 2 * PLANE_PIX] = m;
+        lds[swidx[r] + 4 * PLANE_PIX] = l;
       }
-      if (step + 1 < NSTEP) read_step(cur ^ 1, step + 1);
-      __builtin_amdgcn_sched_barrier(0);          // keep the next step's LDS reads AHEAD of this step's MFMAs
-      const int s0 = 2 * sp, s1 = 2 * sp + 1;
-      if (s1 < NT) {
-        f32x16 t0 = acc[s0], t1 = acc[s1];
-        t0 = mma(wa[slot][2], xb[cur][0][0], t0);      // lo * hi
-        t1 = mma(wa[slot][2], xb[cur][1][0], t1);
-        t0 = mma(wa[slot][0], xb[cur][0][2], t0);      // hi * lo
-        t1 = mma(wa[slot][0], xb[cur][1][2], t1);
-        t0 = mma(wa[slot][1], xb[cur][0][1], t0);      // mid * mid
-        t1 = mma(wa[slot][1], xb[cur][1][1], t1);
-        t0 = mma(wa[slot][1], xb[cur][0][0], t0);      // mid * hi
-        t1 = mma(wa[slot][1], xb[cur][1][0], t1);
-        t0 = mma(wa[slot][0], xb[cur][0][1], t0);      // hi * mid
-        t1 = mma(wa[slot][0], xb[cur][1][1], t1);
-        t0 = mma(wa[slot][0], xb[cur][0][0], t0);      // hi * hi
-        t1 = mma(wa[slot][0], xb[cur][1][0], t1);
-        acc[s0] = t0;
-        acc[s1] = t1;
-      } else {
-        f32x16 t0 = acc[s0];
-        t0 = mma(wa[slot][2], xb[cur][0][0], t0);
-        t0 = mma(wa[slot][0], xb[cur][0][2], t0);
-        t0 = mma(wa[slot][1], xb[cur][0][1], t0);
-        t0 = mma(wa[slot][1], xb[cur][0][0], t0);
-        t0 = mma(wa[slot][0], xb[cur][0][1], t0);
-        t0 = mma(wa[slot][0], xb[cur][0][0], t0);
-        acc[s0] = t0;
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();
+    const bool more = c + 1 < a.nchunk;
+    if (active) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int slot = tap & 1;
+        // weights of the next tap (next chunk's tap 0 after the last one; clamped re-read at the very end)
+        if (X3_ABL != 1) {
+          const int nt = tap == 8 ? 0 : tap + 1;
+          const int nc = tap == 8 ? (more ? c + 1 : c) : c;
+          issue_w(slot ^ 1, nc, nt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int toff = ((tap / 3) * LW + (tap % 3)) * d;
+        u32x4 xb[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) xb[0][p] = lds[xidx[0] + toff + 2 * p * PLANE_PIX];
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+          const int cur = s & 1;
+          if (s + 1 < NT) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) xb[cur ^ 1][p] = lds[xidx[s + 1] + toff + 2 * p * PLANE_PIX];
+          }
+          __builtin_amdgcn_sched_barrier(0);        // keep the next sub-tile's LDS reads AHEAD of this one's six MFMAs
+          f32x16 t = acc[s];
+          t = mma(wa[slot][2], xb[cur][0], t);      // lo * hi
+          t = mma(wa[slot][0], xb[cur][2], t);      // hi * lo
+          t = mma(wa[slot][1], xb[cur][1], t);      // mid * mid
+          t = mma(wa[slot][1], xb[cur][0], t);      // mid * hi
+          t = mma(wa[slot][0], xb[cur][1], t);      // hi * mid
+          t = mma(wa[slot][0], xb[cur][0], t);      // hi * hi
+          acc[s] = t;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // nine taps flip the slot parity: hand the prefetched (c+1, tap 0) fragments back to slot 0
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wa[0][p] = wa[1][p];
+    }
+    __syncthreads();
   }
   if (!active) return;
 
@@ -358,15 +327,7 @@ int launch_x3(X3Args& a, const TileCfg& t, hipStream_t st) {
   a.tiles_x = (a.W + t.tc - 1) / t.tc;
   a.tiles_y = (a.H + t.tr - 1) / t.tr;
   dim3 grid((unsigned)((long)a.B * a.tiles_x * a.tiles_y), (unsigned)((a.CoT + CT - 1) / CT), 1);
-  constexpr size_t lds_bytes = 2 * 6 * (size_t)PLANE_PIX * 16;
-  static bool attr_set = false;                    // > 64 KiB of LDS needs the opt-in (once per instantiation)
-  if (!attr_set) {
-    hipError_t e0 = hipFuncSetAttribute((const void*)conv_x3_kernel<CT, PG, NT, PLANE_PIX>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e0 != hipSuccess) return (int)e0;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((conv_x3_kernel<CT, PG, NT, PLANE_PIX>), grid, dim3((CT * PG + 4) * 64), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_x3_kernel<CT, PG, NT, PLANE_PIX>), grid, dim3(CT * PG * 64), 0, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -382,7 +343,7 @@ static int pick_ct(int CoT) {
 
 struct Plan { int ct, pg, plane; TileCfg t; long blocks; };
 
-static int g_min_blocks = 256;     // launches with fewer blocks cannot fill the 256 CUs: they stay on the fp32 kernels
+static int g_min_blocks = 384;     // launches with fewer blocks cannot fill 256 CUs x 2 blocks: they stay on the fp32 kernels
 
 static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) {
   if (Cin < 16 || dil < 1 || H < 8 || W < 8) return false;

@@ -56,7 +56,7 @@ def main():
                       (gx.cpu().double() - gref).abs().max().item() / gref.abs().max().item(), code)
         print(f"{cin:4d}->{cout:4d} d{dil} {B}x{H}x{W}: fwd f32 {out['f32'][0]:.2e} x3 {out['x3'][0]:.2e} | dgrad f32 {out['f32'][1]:.2e} "
               f"x3 {out['x3'][1]:.2e}  code {out['x3'][2]}", flush=True)
-    hip.lib().irr_conv_x3_set_min_blocks(256)
+    hip.lib().irr_conv_x3_set_min_blocks(384)
     if "--noperf" in sys.argv:
         return
     print("== speed ==")
