@@ -22,6 +22,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide: v_mfma_f32_32x32x16_bf16, dense
+X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0   # conv_x3: six bf16 MFMA products per fp32 product (exact 3-way split)
+X3_PLANES = {1: 352, 2: 616}
+
+
+def kernel_name(var):
+    """variant code of irr_amd.conv's KernelTimer -> (kernel template instantiation, its MFMA roof in fp32 TFLOP/s)"""
+    if var >= 100000:
+        c = var - 100000
+        return (f"conv_x3_kernel<{c // 1000},{(c // 100) % 10},{(c // 10) % 10},{X3_PLANES.get(c % 10, 0)}>", X3_PEAK_TFLOPS)
+    return (f"conv_fwd_kernel<{var // 100},{(var // 10) % 10},{var % 10}>", FP32_MFMA_PEAK_TFLOPS)
 CONV_GFLOP_PER_PAIR = {(384, 448): 1088.4, (448, 1024): 2902.5}   # SURVEY.md 8(d): 3x forward conv FLOPs
 
 
@@ -141,9 +152,13 @@ def main():
             ach = st["flops"] / st["seconds"] / 1e12
             tot_f = sum(s["flops"] for s in summ.values())
             tot_s = sum(s["seconds"] for s in summ.values())
-            roof = {"bound": "mfma", "kernel": f"conv_fwd_kernel<{var // 100},{(var // 10) % 10},{var % 10}>",
-                    "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            kname, peak = kernel_name(var)
+            roof = {"bound": "mfma", "kernel": kname,
+                    "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "peak_note": ("algorithmic fp32 FLOPs (2*MACs); conv_x3 issues 6 bf16 MFMA products per fp32 product, "
+                                  "so its roof is the dense bf16 MFMA peak 2500 / 6 = 416.7 TFLOP/s" if peak != FP32_MFMA_PEAK_TFLOPS
+                                  else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     "launches": st["calls"], "avg_launch_us": round(st["seconds"] / st["calls"] * 1e6, 2),
                     "flop_per_launch": st["flops"] / st["calls"],
                     "concurrent_lanes": 1 if a.no_async_wgrad else 2,
@@ -151,12 +166,15 @@ def main():
                              "(second HIP stream) during backward; 'exclusive' = the forward-pass launches of the same "
                              "kernel, which run alone") if not a.no_async_wgrad else "single stream",
                     "exclusive": ({"achieved": round(st["fwd_flops"] / st["fwd_seconds"] / 1e12, 2),
-                                   "frac": round(st["fwd_flops"] / st["fwd_seconds"] / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                   "frac": round(st["fwd_flops"] / st["fwd_seconds"] / 1e12 / peak, 4),
                                    "launches": st["fwd_calls"],
                                    "avg_launch_us": round(st["fwd_seconds"] / st["fwd_calls"] * 1e6, 2)}
                                   if st["fwd_calls"] else None),
                     "all_conv_fwd_dgrad": {"achieved": round(tot_f / tot_s / 1e12, 2), "seconds_per_step": round(tot_s / a.steps, 5),
-                                           "flops_per_step": tot_f / a.steps}}
+                                           "flops_per_step": tot_f / a.steps},
+                    "by_kernel": {kernel_name(v)[0]: {"launches": s_["calls"], "ms_per_step": round(s_["seconds"] / a.steps * 1e3, 2),
+                                                      "achieved": round(s_["flops"] / s_["seconds"] / 1e12, 1)}
+                                  for v, s_ in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:6]}}
     if rank == 0 and roof is not None:
         # HBM bytes per launch of that kernel from the committed PMC passes (profiles/r1_hbm_traffic.txt:
         # separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH x2 gfx950 correction); not re-measured here.
@@ -178,6 +196,8 @@ def main():
                           "pairs_per_gpu": a.batch, "global_batch": a.batch * world, "height": a.height, "width": a.width,
                           "parallelism": f"dp{world}", "weights": "MSRA init, torch.manual_seed(0)"},
                "loss": {k: float(v.detach()) for k, v in ld.items()},
+               "conv_math": C.MATH,
+               "step_conv_tflops": round(value / world * gf * 1e9 / 1e12, 1) if gf else None,
                "step_mfma_frac": round(value / world * gf * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4) if gf else None,
                "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:

@@ -1,5 +1,7 @@
 """GPU parity of the fp32-MFMA conv family against torch's CPU convolution (what the reference executes:
 nn.Conv2d + LeakyReLU, models/pwc_modules.py:8-19), forward and all three gradients."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -96,3 +98,106 @@ def test_conv_level4_shape_linearity():
     assert torch.allclose(2 * y1, y2, rtol=1e-5, atol=1e-5)
     yr = F.conv2d(x, w, None, padding=1)
     assert (y1 - yr).abs().max().item() < 2e-3 * yr.abs().max().item()
+
+
+# ---- conv_x3: fp32-faithful convolution on the bf16 matrix pipe (csrc/conv_x3.hip) -------------------------------
+X3_CASES = [  # (Cin, Cout, dil, B, H, W): every block shape (CT=4/3/2/1), NT=7/8 tiles, both LDS planes, ragged edges, channel tails
+    (115, 128, 1, 2, 24, 28), (565, 128, 1, 1, 16, 48), (371, 96, 1, 1, 33, 47), (531, 32, 1, 1, 32, 48),
+    (128, 64, 1, 1, 40, 24), (64, 32, 1, 1, 70, 90), (128, 128, 2, 1, 24, 28), (128, 128, 4, 1, 24, 28),
+    (16, 565, 1, 1, 24, 28), (243, 128, 1, 1, 48, 56), (35, 96, 1, 1, 12, 58),
+]
+
+
+@pytest.fixture
+def x3_everywhere():
+    from irr_amd import conv as C, hip
+    old = hip.lib().irr_conv_x3_set_min_blocks(0)
+    C.set_math("x3")
+    yield
+    hip.lib().irr_conv_x3_set_min_blocks(old)
+    C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
+
+
+@pytest.mark.parametrize("case", X3_CASES, ids=[f"{c[0]}to{c[1]}d{c[2]}_{c[4]}x{c[5]}" for c in X3_CASES])
+def test_conv_x3_is_fp32_faithful(case, x3_everywhere):
+    """Forward, data gradient (transposed pack) and the fused epilogue of conv_x3 against an fp64 convolution:
+    the error must stay in the fp32 class (<= 4x the error of the fp32-MFMA kernel and <= 5e-6 of the output range;
+    a single-bf16 product would be ~4e-3, tf32 ~5e-4)."""
+    from irr_amd import conv as C
+    cin, cout, dil, B, H, W = case
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(B, cin, H, W, generator=g) * torch.exp(torch.randn(B, cin, 1, 1, generator=g))   # per-channel scales
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    gy = torch.randn(B, cout, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=dil, dilation=dil)
+    gref = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=dil, dilation=dil)
+    assert C.x3_code(B, cin, H, W, cout, 3, 1, dil) != 0, "case must be routed to conv_x3"
+    err = {}
+    for m in ("f32", "x3"):
+        C.set_math(m)
+        y = C.conv_forward(x.cuda(), w.cuda(), b.cuda(), 1, dil, False)
+        e_f = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        e_d = None
+        if m == "f32" or C.x3_code(B, cout, H, W, cin, 3, 1, dil):
+            gx = C.conv_dgrad(gy.cuda(), w.cuda(), 1, dil, (H, W))
+            e_d = (gx.cpu().double() - gref).abs().max().item() / gref.abs().max().item()
+        err[m] = (e_f, e_d)
+    assert err["x3"][0] <= max(4 * err["f32"][0], 1e-6) and err["x3"][0] <= 5e-6, err
+    if err["x3"][1] is not None:
+        assert err["x3"][1] <= max(4 * err["f32"][1], 1e-6) and err["x3"][1] <= 5e-6, err
+
+
+def test_conv_x3_block_fwd_bwd_and_epilogues(x3_everywhere):
+    """conv_block autograd (fwd + dgrad through conv_x3, wgrad on the fp32 kernel) and the DenseNet-style epilogues
+    (channel-slice in/out, residual, alpha, accumulate) on the x3 path."""
+    from irr_amd import conv as C
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 80, 32, 48, generator=g)
+    w = torch.randn(64, 80, 3, 3, generator=g) * 0.05
+    b = torch.randn(64, generator=g) * 0.1
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = _ref(xc, wc, bc, 3, 1, 1, True)
+    go = torch.randn(yr.shape, generator=g)
+    yr.backward(go)
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    assert C.x3_code(2, 80, 32, 48, 64, 3, 1, 1) and C.x3_code(2, 64, 32, 48, 80, 3, 1, 1)
+    y = C.conv_block(xd, wd, bd, 1, 1, True)
+    y.backward(go.cuda())
+    tol = dict(rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), **tol)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xc.grad.numpy(), **tol)
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wc.grad.numpy(), rtol=1e-3, atol=2e-4 * max(float(wc.grad.abs().max()), 1.0))
+    # channel-slice input/output + residual + alpha, then accumulate
+    buf = torch.randn(2, 120, 32, 48, generator=g)
+    w2 = torch.randn(40, 80, 3, 3, generator=g) * 0.05
+    b2 = torch.randn(40, generator=g) * 0.1
+    res = torch.randn(2, 40, 32, 48, generator=g)
+    ref = res + 0.1 * _ref(buf[:, 40:], w2, b2, 3, 1, 1, True)
+    d = buf.cuda()
+    C.conv_forward(d[:, 40:], w2.cuda(), b2.cuda(), 1, 1, True, out=d[:, :40], res=res.cuda(), alpha=0.1)
+    np.testing.assert_allclose(d[:, :40].cpu().numpy(), ref.numpy(), **tol)
+    np.testing.assert_allclose(d[:, 40:].cpu().numpy(), buf[:, 40:].numpy())
+    base = torch.randn(2, 40, 32, 48, generator=g)
+    acc = base.cuda()
+    C.conv_forward(d[:, 40:], w2.cuda(), None, 1, 1, False, out=acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), (base + F.conv2d(buf[:, 40:], w2, None, padding=1)).numpy(), **tol)
+
+
+def test_conv_x3_level4_linearity_and_routing():
+    """BASELINE-size property check on the x3 path (bs16 level-4 decoder conv): default routing picks conv_x3,
+    conv(2x) == 2 conv(x) bit-for-bit (power-of-two scaling commutes with the exact split), and the result agrees
+    with the fp32-MFMA kernel to fp32 accuracy."""
+    from irr_amd import conv as C
+    torch.manual_seed(0)
+    x = torch.randn(16, 115, 96, 112, device="cuda")
+    w = torch.randn(128, 115, 3, 3, device="cuda") * 0.03
+    C.set_math("x3")
+    assert C.x3_code(16, 115, 96, 112, 128, 3, 1, 1) != 0
+    y1 = C.conv_forward(x, w, None, 1, 1, False)
+    y2 = C.conv_forward(2 * x, w, None, 1, 1, False)
+    assert torch.equal(2 * y1, y2)
+    C.set_math("f32")
+    yf = C.conv_forward(x, w, None, 1, 1, False)
+    C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
+    assert (y1 - yf).abs().max().item() < 2e-6 * yf.abs().max().item() * 4
