@@ -162,6 +162,14 @@ int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, 
                          int B, int Cin, int H, int W, int Cout, int OH, int OW,
                          int k, int stride, int dil, long x_bs, long gy_bs, void* stream);
 
+/* Weight gradient on the bf16 matrix pipe with the exact 3-way split of conv_x3 (csrc/conv_wgrad_x3.hip): same contract
+ * as irr_conv2d_wgrad_f32 for k = 3, stride = 1, dilation = 1, W % 8 == 0 (gw accumulated, ws = Cout*Cin*9 floats of
+ * scratch, gbias nullable, alpha scales both).  irr_conv2d_wgrad_x3_eligible: non-zero when the problem is accepted
+ * and large enough to pay off; 0 -> use irr_conv2d_wgrad_f32. */
+int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil);
+int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
+                        int B, int Cin, int H, int W, int Cout, long x_bs, long gy_bs, void* stream);
+
 /* ---- tiny-Cout heads (Cout <= 4, stride 1): direct VALU kernels, same contracts as the MFMA entry points -------
  * conv_last 563->2 / 562->1, context tails 32->2 / 32->1, OccUpsampleNetwork.out_convs 32->1
  * (models/pwc_modules.py:161,198,221,239; models/irr_modules.py:44).  w is the plain (Cout,Cin,k,k) tensor. */

@@ -1,0 +1,408 @@
+// fp32-faithful weight gradient of the 3x3 / stride-1 / dilation-1 conv() blocks on the bf16 matrix pipe of gfx950
+// (same exact 3-way bf16 operand split and six-product accumulation as conv_x3.hip):
+//   dW[co][ci][dy][dx] += sum_{b,y,x} gy[b,co,y,x] * x[b,ci,y+dy-1,x+dx-1]
+//
+// GEMM view per tap: M = co, N = ci, K = pixels.  v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE k-values per lane, and
+// NCHW planes are pixel-contiguous, so a lane's fragment is simply one "group" of 8 consecutive pixels of one channel
+// row -- no transpose.  The +-1 column taps are the same group shifted by one pixel (2 bytes): built in registers
+// with five v_alignbit per piece from the group and one neighbour pixel on each side.
+//   * block = MW co-tile waves x NW ci-tile waves (8 waves); wave (m, n) keeps all 9 taps of its 32x32 (co, ci) tile in
+//     144 accumulator registers.
+//   * the pixel axis is walked in UNITS of R rows x KG groups (a column strip of the image); per unit the block stages the
+//     gy patch and the R new x rows (plus one margin group left/right) ONCE: coalesced 32-B runs per lane, exact split
+//     into three bf16 pieces in registers, written to LDS as [piece][channel][row][group] x 16 B with a channel pitch of
+//     16 B x odd (conflict-free channel-strided ds_read_b128).  x rows live in a ring of 2R+2 rows, so each row is staged
+//     once and used for the three vertical taps; out-of-image rows/margins are zeros from the buffer bounds check.
+//   * the next unit's loads are in flight during the MFMAs of the current one (one barrier per unit).
+//   * a block walks several columns with persistent accumulators and flushes once: coalesced fp32 atomics into the
+//     [co][tap][ci] workspace that wgrad_unpack_kernel (conv_wgrad.hip) folds into dW; the bias gradient is summed by
+//     the gy stagers (fixed channel per thread) and added once per block.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t OOB = 0x80000000u;
+
+struct WX3Args {
+  const float* x;
+  const float* gy;
+  float* ws;                     // [Cout][9][Cin] workspace (atomics)
+  float* gbias;                  // nullable
+  float alpha;
+  int B, Cin, H, W, Cout;
+  long x_bs, gy_bs;
+  int nstrips, nchunks_y, rows_per_chunk;      // column = (b, strip, row chunk)
+  long ncols;
+  int cols_per_block;
+};
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float lo_f(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_f(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+__device__ __forceinline__ void split8(const float* v, u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a = v[2 * q], b = v[2 * q + 1];
+    const uint32_t hp = pk_bf16(a, b);
+    const float ra = a - lo_f(hp), rb = b - hi_f(hp);
+    const uint32_t mp = pk_bf16(ra, rb);
+    const float sa = ra - lo_f(mp), sb = rb - hi_f(mp);
+    h[q] = hp;
+    m[q] = mp;
+    l[q] = pk_bf16(sa, sb);
+  }
+}
+
+__device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint32_t alignbit16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }
+
+template <int MW, int NW, int KG, int R>
+__global__ __launch_bounds__(MW* NW * 64) void conv_wgrad_x3_kernel(const WX3Args a) {
+  constexpr int NTHR = MW * NW * 64;
+  constexpr int RING = 2 * R + 2;                          // x rows resident
+  constexpr int XG = KG + 2;                               // groups per staged x row (one margin group on each side)
+  constexpr int XPITCH = RING * XG + 1;                    // 16-B units per input channel (odd: conflict-free channel stride)
+  constexpr int GPITCH = 2 * R * KG + 1;                   // 16-B units per output channel (two unit buffers)
+  constexpr int XPLANE = 32 * NW * XPITCH;                 // 16-B units per piece
+  constexpr int GPLANE = 32 * MW * GPITCH;
+  constexpr int XUNITS = R * XG * 32 * NW;                 // (channel, row, group) staging units per step
+  constexpr int GUNITS = R * KG * 32 * MW;
+  constexpr int XR = (XUNITS + NTHR - 1) / NTHR;
+  constexpr int GR = (GUNITS + NTHR - 1) / NTHR;
+  constexpr int NK = R * KG / 2;                           // MFMA k-steps (16 pixels = two groups) per unit
+  static_assert((R * KG) % 2 == 0, "a unit must hold an even number of 8-pixel groups");
+  extern __shared__ u32x4 lds[];
+  u32x4* const xs = lds;                                   // [3][32*NW][XPITCH]
+  u32x4* const gs = lds + 3 * XPLANE;                      // [3][32*MW][GPITCH]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % MW, wn = wave / MW;
+  const int j = lane & 31, g = lane >> 5;
+  const int ci0 = blockIdx.y * 32 * NW, co0 = blockIdx.z * 32 * MW;
+  const long hw = (long)a.H * a.W;
+
+  const uint32_t x_bytes = 0x80000000u, g_bytes = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)a.gy, (short)0, (int)g_bytes, 0x00020000);
+
+  // ---- staging roles (fixed per thread) ----
+  int xu_ci[XR], xu_rr[XR], xu_grp[XR];
+#pragma unroll
+  for (int r = 0; r < XR; ++r) {
+    const int u = r * NTHR + tid;
+    xu_grp[r] = u % XG;
+    xu_rr[r] = (u / XG) % R;
+    xu_ci[r] = u < XUNITS ? u / (XG * R) : -1;
+  }
+  int gu_co[GR], gu_rr[GR], gu_grp[GR];
+#pragma unroll
+  for (int r = 0; r < GR; ++r) {
+    const int u = r * NTHR + tid;
+    gu_grp[r] = u % KG;
+    gu_rr[r] = (u / KG) % R;
+    gu_co[r] = u < GUNITS ? u / (KG * R) : -1;
+  }
+  float bsum[GR];
+#pragma unroll
+  for (int r = 0; r < GR; ++r) bsum[r] = 0.f;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  f32x4 xraw[XR][2], graw[GR][2];
+
+  // issue the global loads of x rows [row0, row0+R) and (optionally) gy rows [grow0, grow0+R) of column (b, strip c0)
+  auto issue = [&](int b, int c0, int row0, bool with_x, int grow0, bool with_g) {
+#pragma unroll
+    for (int r = 0; r < XR; ++r) {
+      const int yy = row0 + xu_rr[r];
+      const int xx = c0 + (xu_grp[r] - 1) * 8;
+      const int ci = ci0 + xu_ci[r];
+      const bool ok = with_x && xu_ci[r] >= 0 && ci < a.Cin && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+      const uint32_t vo = ok ? (uint32_t)(((long)b * a.x_bs + (long)ci * hw + (long)yy * a.W + xx) * 4) : OOB;
+      xraw[r][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)vo, 0, 0));
+      xraw[r][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(vo + 16), 0, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < GR; ++r) {
+      const int yy = grow0 + gu_rr[r];
+      const int xx = c0 + gu_grp[r] * 8;
+      const int co = co0 + gu_co[r];
+      const bool ok = with_g && gu_co[r] >= 0 && co < a.Cout && yy >= 0 && yy < a.H && xx < a.W;
+      const uint32_t vo = ok ? (uint32_t)(((long)b * a.gy_bs + (long)co * hw + (long)yy * a.W + xx) * 4) : OOB;
+      graw[r][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)vo, 0, 0));
+      graw[r][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)(vo + 16), 0, 0));
+    }
+  };
+  // split the loaded units and publish them: x rows [row0, row0+R) into their ring slots, gy rows into unit buffer gbuf
+  auto publish = [&](int row0, bool with_x, int gbuf, bool with_g) {
+    if (with_x) {
+#pragma unroll
+      for (int r = 0; r < XR; ++r) {
+        if (xu_ci[r] < 0) continue;
+        float v[8] = {xraw[r][0][0], xraw[r][0][1], xraw[r][0][2], xraw[r][0][3], xraw[r][1][0], xraw[r][1][1], xraw[r][1][2], xraw[r][1][3]};
+        u32x4 h, m, l;
+        split8(v, h, m, l);
+        const int slot = (row0 + xu_rr[r] + RING) % RING;          // rows >= -1
+        const int idx = xu_ci[r] * XPITCH + slot * XG + xu_grp[r];
+        xs[idx] = h;
+        xs[idx + XPLANE] = m;
+        xs[idx + 2 * XPLANE] = l;
+      }
+    }
+    if (with_g) {
+#pragma unroll
+      for (int r = 0; r < GR; ++r) {
+        if (gu_co[r] < 0) continue;
+        float v[8] = {graw[r][0][0], graw[r][0][1], graw[r][0][2], graw[r][0][3], graw[r][1][0], graw[r][1][1], graw[r][1][2], graw[r][1][3]};
+        bsum[r] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        u32x4 h, m, l;
+        split8(v, h, m, l);
+        const int idx = gu_co[r] * GPITCH + (gbuf * R + gu_rr[r]) * KG + gu_grp[r];
+        gs[idx] = h;
+        gs[idx + GPLANE] = m;
+        gs[idx + 2 * GPLANE] = l;
+      }
+    }
+  };
+
+  const int a_base = (wm * 32 + j) * GPITCH;               // this lane's gy channel row
+  const int b_base = (wn * 32 + j) * XPITCH;               // this lane's x channel row
+
+  // the 54 MFMAs x NK of one unit: gy rows of unit buffer gbuf against x rows y-1 .. y+R.
+  // Flat software pipeline over stages (ks, dy, B piece q): the LDS reads of stage s+1 are issued ahead of the MFMAs of
+  // stage s; sched_barriers keep the compiler from hoisting more than that (144 of the 256 registers are accumulators).
+  auto compute = [&](int y, int gbuf) {
+    constexpr int NS = NK * 9;
+    u32x4 ob[2];
+    uint32_t lb[2], rb[2];
+    u32x4 af[3];
+    auto read_b = [&](int sel, int st) {
+      const int ks = st / 9, dy = (st % 9) / 3, q = st % 3;
+      const int gi = 2 * ks + g;
+      const int row = gi / KG, grp = gi - row * KG;
+      const int slot = (y + row + dy - 1 + RING) % RING;
+      const int xi = b_base + slot * XG + grp + 1 + q * XPLANE;
+      ob[sel] = xs[xi];
+      lb[sel] = xs[xi - 1][3];
+      rb[sel] = xs[xi + 1][0];
+    };
+    auto read_a = [&](int ks) {
+      const int gi = 2 * ks + g;
+      const int row = gi / KG, grp = gi - row * KG;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[p] = gs[a_base + (gbuf * R + row) * KG + grp + p * GPLANE];
+    };
+    read_a(0);
+    read_b(0, 0);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const int cur = st & 1;
+      const int dy = (st % 9) / 3, q = st % 3;
+      if (st + 1 < NS) read_b(cur ^ 1, st + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4 o = ob[cur];
+      u32x4 fm, fp;                                        // dx = -1 / +1 fragments
+      fm[0] = alignbit16(o[0], lb[cur]);
+      fm[1] = alignbit16(o[1], o[0]);
+      fm[2] = alignbit16(o[2], o[1]);
+      fm[3] = alignbit16(o[3], o[2]);
+      fp[0] = fm[1];
+      fp[1] = fm[2];
+      fp[2] = fm[3];
+      fp[3] = alignbit16(rb[cur], o[3]);
+      // products of weight >= 2^-17: (A piece, B piece) in {(l,h),(m,h),(h,h),(m,m),(h,m),(h,l)}
+#pragma unroll
+      for (int pa = 2; pa >= 0; --pa) {
+        if (pa + q > 2) continue;
+        acc[dy * 3 + 0] = mma(af[pa], fm, acc[dy * 3 + 0]);
+        acc[dy * 3 + 1] = mma(af[pa], o, acc[dy * 3 + 1]);
+        acc[dy * 3 + 2] = mma(af[pa], fp, acc[dy * 3 + 2]);
+      }
+      if (st % 9 == 8 && st + 1 < NS) read_a(st / 9 + 1);   // next k-step's gy fragments (after their last use)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- walk this block's columns ----
+  const long col_begin = (long)blockIdx.x * a.cols_per_block;
+  const long col_end = min(a.ncols, col_begin + a.cols_per_block);
+  for (long col = col_begin; col < col_end; ++col) {
+    long t = col;
+    const int chunk = (int)(t % a.nchunks_y);
+    t /= a.nchunks_y;
+    const int strip = (int)(t % a.nstrips);
+    const int b = (int)(t / a.nstrips);
+    const int c0 = strip * KG * 8;
+    const int ya = chunk * a.rows_per_chunk;
+    const int yb = min(a.H, ya + a.rows_per_chunk);
+    // prologue: x rows ya-1 .. ya+R and the first gy unit
+    __syncthreads();
+    for (int r0 = ya - 1; r0 <= ya + R; r0 += R) {
+      const bool first = r0 == ya - 1;
+      issue(b, c0, r0, true, ya, first);
+      publish(r0, true, 0, first);
+    }
+    __syncthreads();
+    int gbuf = 0;
+    for (int y = ya; y < yb; y += R) {
+      const bool more = y + R < yb;
+      // next unit: x rows y+R+1 .. y+2R (rows up to y+R were staged already), gy rows y+R .. y+2R-1
+      if (more) issue(b, c0, y + R + 1, true, y + R, true);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(y, gbuf);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) publish(y + R + 1, true, gbuf ^ 1, true);
+      __syncthreads();
+      gbuf ^= 1;
+    }
+  }
+
+  // ---- flush: ws[co][tap][ci] += alpha * acc (lanes = ci: coalesced atomics) ----
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      const int ci = ci0 + wn * 32 + j;
+      if (co < a.Cout && ci < a.Cin) unsafeAtomicAdd(a.ws + ((long)co * 9 + t) * a.Cin + ci, a.alpha * acc[t][r]);
+    }
+  }
+  if (a.gbias && blockIdx.y == 0) {
+    // threads with the same gy channel are adjacent (R*KG of them): fold, then one atomic per channel
+#pragma unroll
+    for (int r = 0; r < GR; ++r) {
+      float s = bsum[r];
+      constexpr int PER = R * KG;
+#pragma unroll
+      for (int off = 1; off < PER; off <<= 1) s += __shfl_xor(s, off, 64);
+      const int u = r * NTHR + tid;
+      if (gu_co[r] >= 0 && (u % PER) == 0 && co0 + gu_co[r] < a.Cout) unsafeAtomicAdd(a.gbias + co0 + gu_co[r], a.alpha * s);
+    }
+  }
+}
+
+int g_cu_count = 0;
+int cu_count() {
+  if (!g_cu_count) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_cu_count = p.multiProcessorCount;
+    if (g_cu_count <= 0) g_cu_count = 256;
+  }
+  return g_cu_count;
+}
+
+template <int MW, int NW, int KG, int R>
+int launch_wx3(WX3Args a, hipStream_t st) {
+  constexpr int RING = 2 * R + 2, XG = KG + 2;
+  constexpr size_t lds_bytes = 16 * (3 * (size_t)(32 * NW) * (RING * XG + 1) + 3 * (size_t)(32 * MW) * (2 * R * KG + 1));
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e0 = hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<MW, NW, KG, R>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e0 != hipSuccess) return (int)e0;
+    attr_set = true;
+  }
+  a.nstrips = (a.W + KG * 8 - 1) / (KG * 8);
+  const int gy_ = irr_cdiv(a.Cin, 32 * NW), gz_ = irr_cdiv(a.Cout, 32 * MW);
+  // one block per CU (LDS); about two rounds of blocks over the chip, each block walking >= 1 column
+  const long want = 2L * cu_count() / ((long)gy_ * gz_) > 0 ? 2L * cu_count() / ((long)gy_ * gz_) : 1;
+  int rows = a.H;                                          // split columns vertically only when there are too few of them
+  a.nchunks_y = 1;
+  while ((long)a.B * a.nstrips * a.nchunks_y < want && rows > 8 * R) {
+    a.nchunks_y *= 2;
+    rows = ((a.H + a.nchunks_y - 1) / a.nchunks_y + R - 1) / R * R;
+  }
+  a.rows_per_chunk = rows;
+  a.nchunks_y = (a.H + rows - 1) / rows;
+  a.ncols = (long)a.B * a.nstrips * a.nchunks_y;
+  a.cols_per_block = (int)((a.ncols + want - 1) / want);
+  if (a.cols_per_block < 1) a.cols_per_block = 1;
+  dim3 grid(irr_cdiv(a.ncols, a.cols_per_block), gy_, gz_);
+  hipLaunchKernelGGL((conv_wgrad_x3_kernel<MW, NW, KG, R>), grid, dim3(MW * NW * 64), lds_bytes, st, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+// (KG, R) by image width: strips of KG groups must tile the row without waste
+static int pick_kg(int W) {
+  const int groups = W / 8;
+  if (groups % 4 == 0) return 4;
+  if (groups % 2 == 0) return 2;
+  return 1;
+}
+
+}  // namespace
+
+__global__ void wgrad_unpack_x3_kernel(const float* __restrict__ ws, float* __restrict__ gw, int Cin, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int tap = (int)(i % 9);
+  const long r = i / 9;
+  const int ci = (int)(r % Cin);
+  const long co = r / Cin;
+  gw[i] += ws[(co * 9 + tap) * Cin + ci];
+}
+
+extern "C" int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil) {
+  if (k != 3 || stride != 1 || dil != 1 || B <= 0) return 0;
+  if (W % 8 || W < 32 || H < 8 || Cin < 16 || Cout < 65) return 0;          // Cout <= 64: fp32 halo kernel for now
+  if ((long)B * H * W < 100000 && irr_conv_x3_set_min_blocks(-1) > 0) return 0;   // small levels stay on the fp32 kernels
+  const int kg = pick_kg(W);
+  const int mw = (Cout + 31) / 32 > 3 ? 4 : 3;
+  return mw * 100 + kg * 10 + (4 / kg);
+}
+
+extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
+                                   int Cin, int H, int W, int Cout, long x_bs, long gy_bs, void* stream) {
+  if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (W % 8)) return IRR_EINVAL;
+  const long n = (long)Cout * Cin * 9;
+  hipStream_t st = (hipStream_t)stream;
+  IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, st));
+  WX3Args a;
+  a.ws = ws; a.gbias = gbias; a.alpha = alpha;
+  a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
+  a.x_bs = x_bs; a.gy_bs = gy_bs;
+  const long lim = (1L << 29) - 64;                                        // elements: byte voffsets below the 2 GiB marker
+  const long bsmax = x_bs > gy_bs ? x_bs : gy_bs;
+  long per = bsmax > 0 ? (lim - (long)(Cin > Cout ? Cin : Cout) * H * W) / bsmax : B;
+  if (per < 1) return IRR_EINVAL;
+  if (per > B) per = B;
+  const int kg = pick_kg(W);
+  const int cot = (Cout + 31) / 32;
+  for (int b0 = 0; b0 < B; b0 += (int)per) {
+    a.B = (B - b0) < per ? (B - b0) : (int)per;
+    a.x = x + (long)b0 * x_bs;
+    a.gy = gy + (long)b0 * gy_bs;
+    int rc;
+    if (cot % 4 == 0 || cot > 4 || cot == 1 || cot == 2) {
+      rc = kg == 4 ? launch_wx3<4, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<4, 2, 2, 2>(a, st) : launch_wx3<4, 2, 1, 4>(a, st);
+    } else {
+      rc = kg == 4 ? launch_wx3<3, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<3, 2, 2, 2>(a, st) : launch_wx3<3, 2, 1, 4>(a, st);
+    }
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(wgrad_unpack_x3_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, st, ws, gw, Cin, n);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}

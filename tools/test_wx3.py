@@ -1,0 +1,58 @@
+"""Accuracy (vs fp64) and speed of the bf16x3-split wgrad kernel next to the fp32-MFMA wgrad kernels."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from irr_amd import conv as C, hip  # noqa: E402
+from tools.test_x3 import timeit  # noqa: E402
+
+ACC = [  # cin, cout, B, H, W
+    (115, 128, 2, 24, 32), (40, 128, 1, 16, 48), (371, 96, 1, 12, 56), (64, 128, 2, 8, 40), (35, 96, 1, 20, 64), (565, 128, 1, 8, 112),
+    (128, 128, 2, 16, 16),
+]
+PERF = [("ctx.conv0 L4", 565, 128, 64, 96, 112), ("dense.conv1 L4", 115, 128, 64, 96, 112), ("dense.conv3 L4", 371, 96, 64, 96, 112),
+        ("refine 128->128 L4", 128, 128, 64, 96, 112), ("dense.conv2 L3", 243, 128, 64, 48, 56), ("ctx.conv0 L3", 565, 128, 64, 48, 56),
+        ("128->128 448x1024 L4", 128, 128, 16, 112, 256)]
+
+
+def main():
+    hip.lib().irr_conv_x3_set_min_blocks(0)
+    print("== accuracy: max |err| / max |ref| (fp64 reference) ==")
+    for cin, cout, B, H, W in ACC:
+        g = torch.Generator().manual_seed(cin + cout)
+        x = torch.randn(B, cin, H, W, generator=g)
+        gy = torch.randn(B, cout, H, W, generator=g)
+        ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), gy.double(), padding=1)
+        bref = gy.double().sum(dim=(0, 2, 3))
+        out = {}
+        for m in ("f32", "x3"):
+            C.set_math(m)
+            gw = torch.zeros(cout, cin, 3, 3, device="cuda")
+            gb = torch.zeros(cout, device="cuda")
+            C.conv_wgrad(x.cuda(), gy.cuda(), (cout, cin, 3, 3), 1, 1, gw=gw, gbias=gb, alpha=0.5)
+            out[m] = ((2 * gw.cpu().double() - ref).abs().max().item() / ref.abs().max().item(),
+                      (2 * gb.cpu().double() - bref).abs().max().item() / bref.abs().max().item())
+        el = hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, 3, 1, 1)
+        print(f"{cin:4d}->{cout:4d} {B}x{H}x{W}: gw f32 {out['f32'][0]:.2e} x3 {out['x3'][0]:.2e} | gb f32 {out['f32'][1]:.2e} x3 {out['x3'][1]:.2e}  code {el}", flush=True)
+    hip.lib().irr_conv_x3_set_min_blocks(384)
+    if "--noperf" in sys.argv:
+        return
+    print("== speed ==")
+    for name, cin, cout, B, H, W in PERF:
+        x = torch.randn(B, cin, H, W, device="cuda")
+        gy = torch.randn(B, cout, H, W, device="cuda")
+        gw = torch.zeros(cout, cin, 3, 3, device="cuda")
+        gb = torch.zeros(cout, device="cuda")
+        gf = 2.0 * B * H * W * cout * cin * 9 / 1e9
+        row = f"{name:22s} {gf:8.1f} GF "
+        for m in ("f32", "x3"):
+            C.set_math(m)
+            t = timeit(lambda: C.conv_wgrad(x, gy, (cout, cin, 3, 3), 1, 1, gw=gw, gbias=gb))
+            row += f" {m}: {t:6.2f} ms {gf / t:6.1f} TF"
+        print(row + f"  code {hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, 3, 1, 1)}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
