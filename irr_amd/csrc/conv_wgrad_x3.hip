@@ -354,22 +354,43 @@ static int pick_kg(int W) {
 
 }  // namespace
 
-__global__ void wgrad_unpack_x3_kernel(const float* __restrict__ ws, float* __restrict__ gw, int Cin, long n) {
+// gw[co][ci][tap] += ws[co][tap][ci]            (swapped: the launch ran with the operand roles exchanged, see below,
+//                                                  and produced ws[ci][8-tap][co])
+__global__ void wgrad_unpack_x3_kernel(const float* __restrict__ ws, float* __restrict__ gw, int Cin, int Cout, int swapped,
+                                       long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int tap = (int)(i % 9);
   const long r = i / 9;
   const int ci = (int)(r % Cin);
   const long co = r / Cin;
-  gw[i] += ws[(co * 9 + tap) * Cin + ci];
+  gw[i] += swapped ? ws[((long)ci * 9 + (8 - tap)) * Cout + co] : ws[(co * 9 + tap) * Cin + ci];
+}
+
+// gbias[c] += alpha * sum over (b, pixels) of gy (used when the gy stagers of the main kernel cannot provide it)
+__global__ __launch_bounds__(256) void wx3_bias_kernel(const float* __restrict__ gy, float* __restrict__ gbias, long HW, long gy_bs,
+                                                      float alpha, int chunk) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const long p0 = (long)blockIdx.x * chunk, p1 = min(HW, p0 + chunk);
+  const float* g = gy + (long)b * gy_bs + (long)c * HW;
+  float s = 0.f;
+  for (long p = p0 + threadIdx.x; p < p1; p += 256) s += g[p];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(gbias + c, alpha * (red[0] + red[1] + red[2] + red[3]));
 }
 
 extern "C" int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil) {
   if (k != 3 || stride != 1 || dil != 1 || B <= 0) return 0;
-  if (W % 8 || W < 32 || H < 8 || Cin < 16 || Cout < 65) return 0;          // Cout <= 64: fp32 halo kernel for now
+  if (W % 8 || W < 32 || H < 8 || Cin < 16) return 0;
+  if (Cout <= 32 && Cin < 64) return 0;                                    // 32 -> 32 layers: fp32 halo kernel
   if ((long)B * H * W < 100000 && irr_conv_x3_set_min_blocks(-1) > 0) return 0;   // small levels stay on the fp32 kernels
   const int kg = pick_kg(W);
-  const int mw = (Cout + 31) / 32 > 3 ? 4 : 3;
+  const int cot = (Cout + 31) / 32;
+  const int mw = cot == 1 ? 8 : cot == 2 ? 2 : cot == 3 ? 3 : 4;            // 8: operand roles swapped (see irr_conv2d_wgrad_x3)
   return mw * 100 + kg * 10 + (4 / kg);
 }
 
@@ -379,30 +400,48 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
   const long n = (long)Cout * Cin * 9;
   hipStream_t st = (hipStream_t)stream;
   IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, st));
+  const int kg = pick_kg(W);
+  const int cot = (Cout + 31) / 32;
+  // Cout <= 32: one co-tile cannot feed eight waves.  The correlation is symmetric in its operands,
+  //   dW[co][ci][t] = sum gy[p] x[p + d(t)] = sum x[p'] gy[p' - d(t)] = dW'[ci][co][8 - t],
+  // so the launch runs with the roles exchanged (8 "output-channel" waves over Cin, one "input" tile = Cout) and the
+  // unpack kernel transposes and flips the taps.  The bias gradient then comes from a separate pass over the small gy.
+  const bool swapped = cot == 1;
   WX3Args a;
-  a.ws = ws; a.gbias = gbias; a.alpha = alpha;
-  a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
-  a.x_bs = x_bs; a.gy_bs = gy_bs;
+  a.ws = ws; a.gbias = swapped ? nullptr : gbias; a.alpha = alpha;
+  a.H = H; a.W = W;
+  a.Cin = swapped ? Cout : Cin;
+  a.Cout = swapped ? Cin : Cout;
+  a.x_bs = swapped ? gy_bs : x_bs;
+  a.gy_bs = swapped ? x_bs : gy_bs;
   const long lim = (1L << 29) - 64;                                        // elements: byte voffsets below the 2 GiB marker
   const long bsmax = x_bs > gy_bs ? x_bs : gy_bs;
   long per = bsmax > 0 ? (lim - (long)(Cin > Cout ? Cin : Cout) * H * W) / bsmax : B;
   if (per < 1) return IRR_EINVAL;
   if (per > B) per = B;
-  const int kg = pick_kg(W);
-  const int cot = (Cout + 31) / 32;
   for (int b0 = 0; b0 < B; b0 += (int)per) {
     a.B = (B - b0) < per ? (B - b0) : (int)per;
-    a.x = x + (long)b0 * x_bs;
-    a.gy = gy + (long)b0 * gy_bs;
+    a.x = (swapped ? gy : x) + (long)b0 * a.x_bs;
+    a.gy = (swapped ? x : gy) + (long)b0 * a.gy_bs;
     int rc;
-    if (cot % 4 == 0 || cot > 4 || cot == 1 || cot == 2) {
+    if (swapped) {
+      rc = kg == 4 ? launch_wx3<8, 1, 4, 1>(a, st) : kg == 2 ? launch_wx3<8, 1, 2, 2>(a, st) : launch_wx3<8, 1, 1, 4>(a, st);
+    } else if (cot == 2) {
+      rc = kg == 4 ? launch_wx3<2, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<2, 2, 2, 2>(a, st) : launch_wx3<2, 2, 1, 4>(a, st);
+    } else if (cot % 4 == 0 || cot > 4) {
       rc = kg == 4 ? launch_wx3<4, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<4, 2, 2, 2>(a, st) : launch_wx3<4, 2, 1, 4>(a, st);
     } else {
       rc = kg == 4 ? launch_wx3<3, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<3, 2, 2, 2>(a, st) : launch_wx3<3, 2, 1, 4>(a, st);
     }
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(wgrad_unpack_x3_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, st, ws, gw, Cin, n);
+  hipLaunchKernelGGL(wgrad_unpack_x3_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, st, ws, gw, Cin, Cout, swapped ? 1 : 0, n);
   IRR_LAUNCH_CHECK();
+  if (swapped && gbias) {
+    const int chunk = 8192;
+    dim3 grid(irr_cdiv((long)H * W, chunk), Cout, B);
+    hipLaunchKernelGGL(wx3_bias_kernel, grid, dim3(256), 0, st, gy, gbias, (long)H * W, gy_bs, alpha, chunk);
+    IRR_LAUNCH_CHECK();
+  }
   return 0;
 }

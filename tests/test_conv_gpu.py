@@ -201,3 +201,29 @@ def test_conv_x3_level4_linearity_and_routing():
     yf = C.conv_forward(x, w, None, 1, 1, False)
     C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
     assert (y1 - yf).abs().max().item() < 2e-6 * yf.abs().max().item() * 4
+
+
+WX3_CASES = [  # (Cin, Cout, B, H, W): every block shape (MW=4/3/2 and the swapped 8x1), all three (KG, R) unit shapes, channel tails
+    (115, 128, 2, 24, 32), (40, 128, 1, 16, 48), (371, 96, 1, 12, 56), (64, 128, 2, 8, 40), (35, 96, 1, 20, 64),
+    (565, 128, 1, 8, 112), (467, 64, 1, 16, 48), (64, 64, 2, 12, 56), (531, 32, 1, 16, 48), (64, 9, 2, 12, 56), (300, 32, 1, 8, 64),
+]
+
+
+@pytest.mark.parametrize("case", WX3_CASES, ids=[f"{c[0]}to{c[1]}_{c[3]}x{c[4]}" for c in WX3_CASES])
+def test_conv_wgrad_x3_is_fp32_faithful(case, x3_everywhere):
+    """conv_wgrad_x3 (weight + bias gradient, alpha, accumulate-into-gw) against an fp64 reference: error in the fp32 class."""
+    from irr_amd import conv as C, hip
+    cin, cout, B, H, W = case
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    gy = torch.randn(B, cout, H, W, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), gy.double(), padding=1)
+    bref = gy.double().sum(dim=(0, 2, 3))
+    assert hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, 3, 1, 1) != 0
+    base = torch.randn(cout, cin, 3, 3, generator=g)
+    gw = base.clone().cuda()
+    gb = torch.zeros(cout, device="cuda")
+    C.conv_wgrad(x.cuda(), gy.cuda(), (cout, cin, 3, 3), 1, 1, gw=gw, gbias=gb, alpha=0.5)
+    e_w = ((gw.cpu() - base).double() * 2 - ref).abs().max().item() / ref.abs().max().item()
+    e_b = (gb.cpu().double() * 2 - bref).abs().max().item() / bref.abs().max().item()
+    assert e_w <= 3e-6 and e_b <= 3e-6, (e_w, e_b)
