@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): refreshes every artefact under gpurun_out/prof/ that profiles/ is built from.
+#   bash tools/profile_round.sh <tag>
+# 1. bench.py default (two-lane) with the CPU baseline          -> <tag>_bench.json
+# 2. rocprofv3 --kernel-trace --stats, default and single-stream -> <tag>_kernel_stats{,_serial}.txt (+ the JSON line of the same run)
+# 3. two separate PMC passes (FETCH_SIZE, WRITE_SIZE)            -> <tag>_hbm_traffic.txt, hbm_traffic.json
+TAG=${1:-r1}
+OUT=gpurun_out/prof
+mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python bench.py --no-async-wgrad --no-cpu-baseline > $OUT/${TAG}_bench_serial.json 2>> $OUT/${TAG}_bench.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 bench.py --no-cpu-baseline --steps 5 > $OUT/${TAG}_bench_under_rocprof.json 2>> $OUT/${TAG}_bench.err
+python tools/rocpd_stats.py $(find $OUT/kt -name "*.db" | head -1) 50 > $OUT/${TAG}_kernel_stats.txt
+rm -rf $OUT/kt
+rocprofv3 --kernel-trace --stats -d $OUT/kts -o kts -- python3 bench.py --no-cpu-baseline --no-async-wgrad --steps 5 > $OUT/${TAG}_bench_serial_under_rocprof.json 2>> $OUT/${TAG}_bench.err
+python tools/rocpd_stats.py $(find $OUT/kts -name "*.db" | head -1) 50 > $OUT/${TAG}_kernel_stats_serial.txt
+rm -rf $OUT/kts
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pf -o pf -- python3 bench.py --no-cpu-baseline --no-async-wgrad --no-kernel-timer --steps 2 --warmup 1 > /dev/null 2>> $OUT/${TAG}_bench.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pw -o pw -- python3 bench.py --no-cpu-baseline --no-async-wgrad --no-kernel-timer --steps 2 --warmup 1 > /dev/null 2>> $OUT/${TAG}_bench.err
+F=$(find $OUT/pf -name "*.db" | head -1); W=$(find $OUT/pw -name "*.db" | head -1)
+python tools/rocpd_traffic.py $F $W > $OUT/${TAG}_hbm_traffic.txt
+python tools/rocpd_traffic_json.py $F $W > $OUT/hbm_traffic.json
+rm -rf $OUT/pf $OUT/pw
+ls -la $OUT

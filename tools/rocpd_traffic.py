@@ -25,7 +25,7 @@ def agg(path, counter):
 
 f = agg(sys.argv[1], "FETCH_SIZE")
 w = agg(sys.argv[2], "WRITE_SIZE")
-print(f"{'kernel':60s} {'launches':>8s} {'avg_us':>9s} {'fetch_MB/launch(x2 corr)':>26s} {'write_MB/launch':>16s} {'GB/s (corr)':>12s}")
+print(f"{'kernel':60s} {'launches':>8s} {'avg_us':>9s} {'fetch_MB/launch(x2 corr)':>26s} {'write_MB/launch':>16s} {'TB/s (corr)':>12s}")
 for k in sorted(f, key=lambda k: -f[k][2])[:30]:
     n = f[k][0]
     fe = f[k][1] / n * 1024 * 2 / 1e6
