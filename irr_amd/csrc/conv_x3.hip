@@ -256,6 +256,222 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
   }
 }
 
+static int g_min_blocks = 384;     // launches with fewer blocks cannot fill 256 CUs x 2 blocks: they stay on the fp32 kernels
+
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming variant for the 32-channel layers (OccUpsampleNetwork at 1/2 and full resolution, models/irr_modules.py:30-56:
+// seven 32 -> 32 convs per call, 41 % of all conv activation traffic).  With K = 9 * 32 the MFMA work of a tile
+// (2.9 us) is SHORTER than its HBM time (76-108 KiB per 256-pixel tile = 3.9-5.5 us at 5 TB/s / 256 CUs), so the
+// kernel is organised around keeping loads in flight: PERSISTENT blocks of 4 consumer + 4 producer waves walk the
+// tiles; the producers stage the complete 32-channel halo patch of tile n+1 (both 16-channel chunks, split to bf16x3)
+// into the second LDS buffer and already have tile n+2's global loads in flight while the consumers run the
+// 18 x 12 MFMAs of tile n and write it out (epilogue operands -- residual / accumulate / mask -- are prefetched at the
+// start of the tile).  One s_barrier per tile.  Tile = 8 rows x 32 columns; Cout <= 32, 16 < Cin <= 32, dilation 1.
+struct X3SArgs {
+  const float* x;
+  const u32x4* wq;
+  const float* bias;
+  const float* res;
+  float* y;
+  int B, Cin, H, W, Cout;
+  int tiles_x, tiles_y;
+  long ntiles;
+  long x_bs, y_bs, res_bs;
+  int lrelu, accumulate;
+  float alpha;
+  const float* mask;
+  long mask_bs;
+  int nmask;
+};
+
+__global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
+  constexpr int PLANE_PIX = 352;                           // >= 10 x 34 halo patch
+  constexpr int CHUNK = 6 * PLANE_PIX;                     // 16-B units per chunk slot: [piece][g][pixel]
+  constexpr int NR = 3;                                    // staging rounds per chunk (680 units / 256 producer threads)
+  constexpr int LW = 34, NPIX = 10 * 34;
+  constexpr int WUNITS = 18 * 3 * 64;                      // the complete pre-split weight set: [step][piece][lane] x 16 B
+  extern __shared__ u32x4 lds[];
+  u32x4* const wl = lds;                                   // weights (54 KiB), loaded once per block
+  u32x4* const xl = lds + WUNITS;                          // two chunk slots
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long hw = (long)a.H * a.W;
+  const long t_begin = blockIdx.x, t_step = gridDim.x;
+
+  // The consumers must not have ANY vector-memory load inside their MFMA loop: loads return in order, so a weight
+  // fragment fetched from global memory would queue behind the tile's output stores and epilogue-operand loads
+  // (HBM round trips).  The weights therefore live in LDS for the lifetime of the (persistent) block.
+  for (int u = tid; u < WUNITS; u += 512) wl[u] = a.wq[u];
+  __syncthreads();
+
+  if (wave >= 4) {
+    // ================= producers =================
+    const int ptid = tid - 256;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)0x80000000u, 0x00020000);
+    int sly[NR], slx[NR], sgg[NR], swidx[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int u = r * 256 + ptid;
+      const int gg = u >= NPIX ? 1 : 0;
+      const int pix = u - gg * NPIX;
+      sgg[r] = gg;
+      sly[r] = pix / LW;
+      slx[r] = pix - sly[r] * LW;
+      swidx[r] = u < 2 * NPIX ? gg * PLANE_PIX + pix : -1;
+    }
+    const uint32_t hw4 = (uint32_t)(hw * 4);
+    const uint32_t c1off = (uint32_t)(a.Cin - 16) * hw4;   // second chunk = channels [Cin-16, Cin) (duplicates: zero weights)
+    float raw[2][NR][8];
+    auto issue_chunk = [&](long t, int c) {
+      const int tx = (int)(t % a.tiles_x);
+      const long t2 = t / a.tiles_x;
+      const int ty = (int)(t2 % a.tiles_y);
+      const int b = (int)(t2 / a.tiles_y);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int iy = ty * 8 - 1 + sly[r], ix = tx * 32 - 1 + slx[r];
+        const bool ok = swidx[r] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const uint32_t vo = ok ? (uint32_t)(((long)b * a.x_bs + (long)sgg[r] * 8 * hw + (long)iy * a.W + ix) * 4) : OOB;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          raw[c][r][e] = (X3_ABL == 6) ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)vo, (int)((c ? c1off : 0u) + e * hw4), 0));
+      }
+    };
+    if (t_begin < a.ntiles) {
+      issue_chunk(t_begin, 0);
+      issue_chunk(t_begin, 1);
+    }
+    for (long t = t_begin; t < a.ntiles; t += t_step) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {                         // chunk q = 2n + c lives in slot c (q & 1)
+        u32x4* buf = xl + c * CHUNK;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          u32x4 h, m, l;
+          split8(raw[c][r], h, m, l);
+          if (swidx[r] >= 0) {
+            buf[swidx[r]] = h;
+            buf[swidx[r] + 2 * PLANE_PIX] = m;
+            buf[swidx[r] + 4 * PLANE_PIX] = l;
+          }
+        }
+        if (t + t_step < a.ntiles) issue_chunk(t + t_step, c);   // same chunk of the next tile: one tile of flight time
+        __syncthreads();                                    // barrier #q: chunk q is published (slot q&1 of chunk q-2 was free)
+      }
+    }
+    return;
+  }
+
+  // ================= consumers: wave = pixel group (64 pixels = 2 rows of the tile), one 32-channel co-tile =================
+  const int pg = wave;
+  const int j = lane & 31, g = lane >> 5;
+  const int row0 = pg * 2;                                 // sub-tile s = tile row row0 + s, column j
+  const int xidx0 = g * PLANE_PIX + row0 * LW + j;
+  const long ohw = hw;
+  const uint32_t ohw4 = (uint32_t)(hw * 4);
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, (int)0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, (short)0, (int)0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)a.mask, (short)0, (int)0x80000000u, 0x00020000);
+  float bv[16];                                            // bias of this lane's 16 output channels
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = (r & 3) + 8 * (r >> 2) + 4 * g;
+    bv[r] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+  }
+  for (long t = t_begin; t < a.ntiles; t += t_step) {
+    const int tx = (int)(t % a.tiles_x);
+    const long t2 = t / a.tiles_x;
+    const int ty = (int)(t2 % a.tiles_y);
+    const int b = (int)(t2 / a.tiles_y);
+    // epilogue operands first (branch-free buffer loads; absent operands / invalid positions read 0 through the
+    // out-of-range voffset): their latency hides behind the MFMAs of the tile
+    float rv[2][16], dv[2][16], mv[2][16];
+    long pofs[2];
+    bool pval[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int oy = ty * 8 + row0 + s, ox = tx * 32 + j;
+      pval[s] = oy < a.H && ox < a.W;
+      pofs[s] = (long)oy * a.W + ox;
+      const uint32_t vr = (uint32_t)(((long)b * a.res_bs + pofs[s] + 4L * g * ohw) * 4);
+      const uint32_t vd = (uint32_t)(((long)b * a.y_bs + pofs[s] + 4L * g * ohw) * 4);
+      const uint32_t vm = (uint32_t)(((long)b * a.mask_bs + pofs[s] + 4L * g * ohw) * 4);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int crow = (r & 3) + 8 * (r >> 2);
+        const bool ok = pval[s] && crow + 4 * g < a.Cout;
+        const uint32_t so = (uint32_t)crow * ohw4;
+        rv[s][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)((ok && a.res) ? vr : OOB), (int)so, 0));
+        dv[s][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (int)((ok && a.accumulate) ? vd : OOB), (int)so, 0));
+        mv[s][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)((ok && a.mask && crow + 4 * g < a.nmask) ? vm : OOB), (int)so, 0));
+      }
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      __syncthreads();                                      // barrier #q: chunk q = 2n + c is in slot c
+      const u32x4* buf = xl + c * CHUNK;
+      u32x4 xb[2][2][3], wa[2][3];
+      auto read_step = [&](int sel, int tap) {
+        const int base = xidx0 + (tap / 3) * LW + (tap % 3);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) xb[sel][s][p] = buf[base + s * LW + 2 * p * PLANE_PIX];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wa[sel][p] = wl[((c * 9 + tap) * 3 + p) * 64 + lane];
+      };
+      read_step(0, 0);
+#pragma unroll
+      for (int tap = 0; tap < (X3_ABL == 5 ? 1 : 9); ++tap) {
+        const int cur = tap & 1;
+        if (tap + 1 < 9) read_step(cur ^ 1, tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = mma(wa[cur][2], xb[cur][0][0], acc0);        // lo * hi
+        acc1 = mma(wa[cur][2], xb[cur][1][0], acc1);
+        acc0 = mma(wa[cur][0], xb[cur][0][2], acc0);        // hi * lo
+        acc1 = mma(wa[cur][0], xb[cur][1][2], acc1);
+        acc0 = mma(wa[cur][1], xb[cur][0][1], acc0);        // mid * mid
+        acc1 = mma(wa[cur][1], xb[cur][1][1], acc1);
+        acc0 = mma(wa[cur][1], xb[cur][0][0], acc0);        // mid * hi
+        acc1 = mma(wa[cur][1], xb[cur][1][0], acc1);
+        acc0 = mma(wa[cur][0], xb[cur][0][1], acc0);        // hi * mid
+        acc1 = mma(wa[cur][0], xb[cur][1][1], acc1);
+        acc0 = mma(wa[cur][0], xb[cur][0][0], acc0);        // hi * hi
+        acc1 = mma(wa[cur][0], xb[cur][1][0], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // epilogue (branch-free: invalid positions / channels are dropped by the out-of-range voffset of the buffer store)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const uint32_t vd = (uint32_t)(((long)b * a.y_bs + pofs[s] + 4L * g * ohw) * 4);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int crow = (r & 3) + 8 * (r >> 2);
+        const bool ok = pval[s] && crow + 4 * g < a.Cout;
+        float v = (s ? acc1[r] : acc0[r]) + bv[r];
+        if (a.lrelu) v = irr_lrelu(v);
+        v = rv[s][r] + a.alpha * v;                 // rv = 0 without a residual operand
+        v += dv[s][r];                              // dv = 0 unless accumulating
+        if (a.mask && crow + 4 * g < a.nmask) v *= irr_lrelu_grad(mv[s][r]);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ry, (int)((ok && (X3_ABL != 7 || v == 123.456f)) ? vd : OOB), (int)((uint32_t)crow * ohw4), 0);
+      }
+    }
+  }
+}
+
+static bool x3s_ok(int B, int Cin, int H, int W, int Cout, int dil) {
+  if (dil != 1 || Cout > 32 || Cin <= 16 || Cin > 32) return false;
+  const long tiles = (long)B * ((H + 7) / 8) * ((W + 31) / 32);
+  const double eff = (double)H * W / ((double)((H + 7) / 8) * ((W + 31) / 32) * 256);
+  return eff >= 0.8 && (tiles >= 2048 || g_min_blocks == 0);
+}
+
 // ---- weight packing: wq[(((chunk*9 + tap)*3 + piece)*CoT + cot)*64 + lane] = 8 bf16 (k-group g = lane>>5, row i = lane&31) ----
 // mode 0: w is (Cout, Cin, 3, 3)                    -> forward
 // mode 1: w is (Cin, Cout, 3, 3) = original layout, used transposed + flipped -> stride-1 data gradient
@@ -343,11 +559,9 @@ static int pick_ct(int CoT) {
 
 struct Plan { int ct, pg, plane; TileCfg t; long blocks; };
 
-static int g_min_blocks = 384;     // launches with fewer blocks cannot fill 256 CUs x 2 blocks: they stay on the fp32 kernels
-
 static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) {
   if (Cin < 16 || dil < 1 || H < 8 || W < 8) return false;
-  if (Cin < 64 && g_min_blocks > 0) return false;       // two or three chunks: prologue/epilogue dominate, fp32 kernel wins
+  if (Cin < 64 && g_min_blocks > 0) return false;       // two or three chunks: prologue/epilogue dominate (see conv_x3s_kernel)
   const int CoT = (Cout + 31) / 32;
   p->ct = pick_ct(CoT);
   static const int nts78[2] = {8, 7};
@@ -413,6 +627,7 @@ extern "C" int irr_conv_pack_weights_x3_sub(const float* w, void* wq, int w_cin,
 
 extern "C" int irr_conv2d_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil) {
   if (k != 3 || stride != 1 || B <= 0) return 0;
+  if (x3s_ok(B, Cin, H, W, Cout, dil)) return 9001;                       // streaming 32-channel kernel
   Plan p;
   if (!make_plan(B, Cin, H, W, Cout, dil, &p)) return 0;
   if (p.blocks < g_min_blocks) return 0;            // tiny pyramid levels stay on the fp32 split-K kernel
@@ -423,6 +638,38 @@ extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bi
                                  int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
                                  float alpha, int accumulate, const float* mask, long mask_bs, int nmask, void* stream) {
   if (!x || !wq || !y || B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1) return IRR_EINVAL;
+  if (x3s_ok(B, Cin, H, W, Cout, dil)) {
+    X3SArgs s;
+    s.wq = (const u32x4*)wq; s.bias = bias;
+    s.Cin = Cin; s.H = H; s.W = W; s.Cout = Cout;
+    s.tiles_x = (W + 31) / 32; s.tiles_y = (H + 7) / 8;
+    s.x_bs = x_bs; s.y_bs = y_bs; s.res_bs = res_bs;
+    s.lrelu = lrelu; s.accumulate = accumulate; s.alpha = alpha;
+    s.mask_bs = mask_bs; s.nmask = nmask;
+    constexpr size_t lds_bytes = (18 * 3 * 64 + 2 * 6 * 352) * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      attr_set = true;
+    }
+    const long lim = (1L << 29) - (long)(Cin + 16) * H * W - 64;
+    if (lim <= 0) return IRR_EINVAL;
+    long per = x_bs > 0 ? lim / x_bs : B;
+    if (per < 1) per = 1;
+    if (per > B) per = B;
+    for (int b0 = 0; b0 < B; b0 += (int)per) {
+      s.B = (B - b0) < per ? (B - b0) : (int)per;
+      s.x = x + (long)b0 * x_bs;
+      s.y = y + (long)b0 * y_bs;
+      s.res = res ? res + (long)b0 * res_bs : nullptr;
+      s.mask = mask ? mask + (long)b0 * mask_bs : nullptr;
+      s.ntiles = (long)s.B * s.tiles_x * s.tiles_y;
+      const long nblk = s.ntiles < 256 ? s.ntiles : 256;             // persistent: one block per CU
+      hipLaunchKernelGGL(conv_x3s_kernel, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
+      IRR_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   Plan p;
   if (!make_plan(B, Cin, H, W, Cout, dil, &p)) return IRR_EINVAL;
   X3Args a;

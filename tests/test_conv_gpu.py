@@ -227,3 +227,40 @@ def test_conv_wgrad_x3_is_fp32_faithful(case, x3_everywhere):
     e_w = ((gw.cpu() - base).double() * 2 - ref).abs().max().item() / ref.abs().max().item()
     e_b = (gb.cpu().double() * 2 - bref).abs().max().item() / bref.abs().max().item()
     assert e_w <= 3e-6 and e_b <= 3e-6, (e_w, e_b)
+
+
+X3S_CASES = [(32, 32, 2, 24, 64), (32, 32, 1, 70, 90), (24, 32, 1, 16, 32), (32, 9, 2, 16, 96)]
+
+
+@pytest.mark.parametrize("case", X3S_CASES, ids=[f"{c[0]}to{c[1]}_{c[3]}x{c[4]}" for c in X3S_CASES])
+def test_conv_x3_streaming_kernel_epilogues(case, x3_everywhere):
+    """conv_x3s_kernel (persistent producer/consumer kernel of the 32-channel layers): bias+LeakyReLU, residual+alpha,
+    accumulate, and the data-gradient launch with residual + alpha + accumulate + LeakyReLU'-mask, against fp64."""
+    from irr_amd import conv as C
+    cin, cout, B, H, W = case
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, H, W, generator=g)
+    base = torch.randn(B, cout, H, W, generator=g)
+    assert C.x3_code(B, cin, H, W, cout, 3, 1, 1) == 9001
+    conv = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    tol = 2e-6 * float(conv.abs().max())
+    y = C.conv_forward(x.cuda(), w.cuda(), b.cuda(), 1, 1, True)
+    assert (y.cpu().double() - F.leaky_relu(conv, 0.1)).abs().max().item() <= tol
+    y = C.conv_forward(x.cuda(), w.cuda(), b.cuda(), 1, 1, False, res=res.cuda(), alpha=0.1)
+    assert (y.cpu().double() - (res.double() + 0.1 * conv)).abs().max().item() <= tol
+    acc = base.clone().cuda()
+    C.conv_forward(x.cuda(), w.cuda(), None, 1, 1, False, out=acc, accumulate=True)
+    assert (acc.cpu().double() - (base.double() + F.conv2d(x.double(), w.double(), None, padding=1))).abs().max().item() <= tol
+    if C.x3_code(B, cout, H, W, cin, 3, 1, 1) == 9001:
+        gy = torch.randn(B, cout, H, W, generator=g)
+        g0 = torch.randn(B, cin, H, W, generator=g)
+        r2 = torch.randn(B, cin, H, W, generator=g)
+        m2 = torch.randn(B, cin, H, W, generator=g)
+        gx = g0.clone().cuda()
+        C.conv_dgrad(gy.cuda(), w.cuda(), 1, 1, (H, W), gx=gx, accumulate=True, res=r2.cuda(), alpha=0.1, mask=m2.cuda(), nmask=cin)
+        ref = (g0.double() + r2.double() + 0.1 * torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=1)) * \
+            torch.where(m2 > 0, 1.0, 0.1).double()
+        assert (gx.cpu().double() - ref).abs().max().item() <= 2e-6 * float(ref.abs().max())
