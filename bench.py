@@ -29,6 +29,8 @@ X3_PLANES = {1: 352, 2: 616}
 
 def kernel_name(var):
     """variant code of irr_amd.conv's KernelTimer -> (kernel template instantiation, its MFMA roof in fp32 TFLOP/s)"""
+    if var == 109001:
+        return ("conv_x3s_kernel", X3_PEAK_TFLOPS)
     if var >= 100000:
         c = var - 100000
         return (f"conv_x3_kernel<{c // 1000},{(c // 100) % 10},{(c // 10) % 10},{X3_PLANES.get(c % 10, 0)}>", X3_PEAK_TFLOPS)

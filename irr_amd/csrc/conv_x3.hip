@@ -34,6 +34,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t OOB = 0x80000000u;     // voffset marker: beyond num_records -> the load returns 0, touches nothing
@@ -287,12 +288,12 @@ struct X3SArgs {
 __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
   constexpr int PLANE_PIX = 352;                           // >= 10 x 34 halo patch
   constexpr int CHUNK = 6 * PLANE_PIX;                     // 16-B units per chunk slot: [piece][g][pixel]
-  constexpr int NR = 3;                                    // staging rounds per chunk (680 units / 256 producer threads)
-  constexpr int LW = 34, NPIX = 10 * 34;
+  constexpr int LW = 34;
   constexpr int WUNITS = 18 * 3 * 64;                      // the complete pre-split weight set: [step][piece][lane] x 16 B
   extern __shared__ u32x4 lds[];
   u32x4* const wl = lds;                                   // weights (54 KiB), loaded once per block
-  u32x4* const xl = lds + WUNITS;                          // two chunk slots
+  u32x4* const xl = lds + WUNITS;                          // two chunk slots (66 KiB)
+  float* const ol = (float*)(lds + WUNITS + 2 * CHUNK);    // accumulators of the finished tile: [32 co][256 px] fp32 (32 KiB)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -300,120 +301,148 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
   const long hw = (long)a.H * a.W;
   const long t_begin = blockIdx.x, t_step = gridDim.x;
 
-  // The consumers must not have ANY vector-memory load inside their MFMA loop: loads return in order, so a weight
-  // fragment fetched from global memory would queue behind the tile's output stores and epilogue-operand loads
-  // (HBM round trips).  The weights therefore live in LDS for the lifetime of the (persistent) block.
+  // The MFMA waves touch no global memory at all: weights live in LDS for the lifetime of the (persistent) block, and
+  // finished accumulators are handed to the producer waves through LDS, which run the epilogue (bias, LeakyReLU,
+  // residual, accumulate, mask, store) of tile n while the MFMA waves are already on tile n+1.
   for (int u = tid; u < WUNITS; u += 512) wl[u] = a.wq[u];
   __syncthreads();
 
   if (wave >= 4) {
-    // ================= producers =================
+    // ================= producers (+ epilogue) =================
     const int ptid = tid - 256;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)0x80000000u, 0x00020000);
-    int sly[NR], slx[NR], sgg[NR], swidx[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const int u = r * 256 + ptid;
-      const int gg = u >= NPIX ? 1 : 0;
-      const int pix = u - gg * NPIX;
-      sgg[r] = gg;
-      sly[r] = pix / LW;
-      slx[r] = pix - sly[r] * LW;
-      swidx[r] = u < 2 * NPIX ? gg * PLANE_PIX + pix : -1;
-    }
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, (int)0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, (short)0, (int)0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)a.mask, (short)0, (int)0x80000000u, 0x00020000);
+    // Staging unit = (k-group gg, patch row ly, aligned pixel quad q): 8 channels x 4 pixels as eight 16-B loads (the
+    // vector-memory INSTRUCTION rate, not bandwidth, limited the dword version of this kernel).  The loaded window is
+    // columns x0-4 .. x0+35 (ten aligned quads; only x0-1 and x0+32 of the two margin quads are used), so every
+    // quad is entirely inside or entirely outside the image.  200 units per chunk, one per producer thread.
+    const int su_gg = ptid / 100, su_rest = ptid % 100;
+    const int su_ly = su_rest / 10, su_q = su_rest % 10;
+    const bool su_act = ptid < 200;
     const uint32_t hw4 = (uint32_t)(hw * 4);
     const uint32_t c1off = (uint32_t)(a.Cin - 16) * hw4;   // second chunk = channels [Cin-16, Cin) (duplicates: zero weights)
-    float raw[2][NR][8];
+    f32x4 raw[2][8];
     auto issue_chunk = [&](long t, int c) {
       const int tx = (int)(t % a.tiles_x);
       const long t2 = t / a.tiles_x;
       const int ty = (int)(t2 % a.tiles_y);
       const int b = (int)(t2 / a.tiles_y);
+      const int iy = ty * 8 - 1 + su_ly, ix = tx * 32 - 4 + su_q * 4;
+      const bool ok = su_act && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const uint32_t vo = ok ? (uint32_t)(((long)b * a.x_bs + (long)su_gg * 8 * hw + (long)iy * a.W + ix) * 4) : OOB;
 #pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const int iy = ty * 8 - 1 + sly[r], ix = tx * 32 - 1 + slx[r];
-        const bool ok = swidx[r] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        const uint32_t vo = ok ? (uint32_t)(((long)b * a.x_bs + (long)sgg[r] * 8 * hw + (long)iy * a.W + ix) * 4) : OOB;
+      for (int e = 0; e < 8; ++e)
+        raw[c][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)vo, (int)((c ? c1off : 0u) + e * hw4), 0));
+    };
+    auto write_chunk = [&](int c) {
+      u32x4* buf = xl + c * CHUNK + su_gg * PLANE_PIX + su_ly * LW;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          raw[c][r][e] = (X3_ABL == 6) ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)vo, (int)((c ? c1off : 0u) + e * hw4), 0));
+      for (int px = 0; px < 4; ++px) {
+        const int lx = su_q * 4 + px - 3;                    // patch column of this pixel
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = raw[c][e][px];
+        u32x4 h, m, l;
+        split8(v, h, m, l);
+        if (su_act && lx >= 0 && lx < LW) {
+          buf[lx] = h;
+          buf[lx + 2 * PLANE_PIX] = m;
+          buf[lx + 4 * PLANE_PIX] = l;
+        }
+      }
+    };
+    // Epilogue of one tile: this thread owns an aligned quad of pixels (row eq_row, columns 4*eq_q ..) for 8 channels
+    // (co = eq_c8*8 ..).  Two halves: the operand loads are issued at the START of the phase (they fly while the chunk is
+    // split and written), the arithmetic and the 16-B stores come at its end -- no load ever waits behind a store.
+    const int eq_q = ptid & 7, eq_row = (ptid >> 3) & 7, eq_c8 = ptid >> 6;
+    float bias_r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias_r[e] = (a.bias && eq_c8 * 8 + e < a.Cout) ? a.bias[eq_c8 * 8 + e] : 0.f;
+    f32x4 erv[8], edv[8], emv[8];
+    uint32_t evd = OOB;
+    auto epilogue_loads = [&](long t) {
+      const int tx = (int)(t % a.tiles_x);
+      const long t2 = t / a.tiles_x;
+      const int ty = (int)(t2 % a.tiles_y);
+      const int b = (int)(t2 / a.tiles_y);
+      const int oy = ty * 8 + eq_row, ox = tx * 32 + eq_q * 4;
+      const bool pv = oy < a.H && ox < a.W;
+      const long pofs = (long)oy * a.W + ox + (long)eq_c8 * 8 * hw;
+      const uint32_t vr = (pv && a.res) ? (uint32_t)(((long)b * a.res_bs + pofs) * 4) : OOB;
+      evd = pv ? (uint32_t)(((long)b * a.y_bs + pofs) * 4) : OOB;
+      const uint32_t vm = (pv && a.mask) ? (uint32_t)(((long)b * a.mask_bs + pofs) * 4) : OOB;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t so = (uint32_t)e * hw4;
+        const int co = eq_c8 * 8 + e;
+        const bool cok = co < a.Cout;
+        erv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)(cok ? vr : OOB), (int)so, 0));
+        edv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)((cok && a.accumulate) ? evd : OOB), (int)so, 0));
+        emv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rmask, (int)((cok && co < a.nmask) ? vm : OOB), (int)so, 0));
+      }
+    };
+    auto epilogue_finish = [&]() {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int co = eq_c8 * 8 + e;
+        const f32x4 acc4 = *(const f32x4*)(ol + co * 256 + eq_row * 32 + eq_q * 4);
+        f32x4 o;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          float v = acc4[px] + bias_r[e];
+          if (a.lrelu) v = irr_lrelu(v);
+          v = erv[e][px] + a.alpha * v;             // erv = 0 without a residual operand
+          v += edv[e][px];                          // edv = 0 unless accumulating
+          if (a.mask && co < a.nmask) v *= irr_lrelu_grad(emv[e][px]);
+          o[px] = v;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, (int)((co < a.Cout && X3_ABL != 7) ? evd : OOB),
+                                               (int)((uint32_t)e * hw4), 0);
       }
     };
     if (t_begin < a.ntiles) {
       issue_chunk(t_begin, 0);
       issue_chunk(t_begin, 1);
     }
+    long tprev = -1;
     for (long t = t_begin; t < a.ntiles; t += t_step) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {                         // chunk q = 2n + c lives in slot c (q & 1)
-        u32x4* buf = xl + c * CHUNK;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          u32x4 h, m, l;
-          split8(raw[c][r], h, m, l);
-          if (swidx[r] >= 0) {
-            buf[swidx[r]] = h;
-            buf[swidx[r] + 2 * PLANE_PIX] = m;
-            buf[swidx[r] + 4 * PLANE_PIX] = l;
-          }
-        }
-        if (t + t_step < a.ntiles) issue_chunk(t + t_step, c);   // same chunk of the next tile: one tile of flight time
-        __syncthreads();                                    // barrier #q: chunk q is published (slot q&1 of chunk q-2 was free)
-      }
+      // phase after barrier #(2n-1): the MFMA waves are on (n-1, chunk 1); slot 0 is free
+      write_chunk(0);
+      if (t + t_step < a.ntiles) issue_chunk(t + t_step, 0);
+      __syncthreads();                                      // barrier #2n: (n, chunk 0) published; accumulators of tile n-1 published
+      // phase: MFMA waves on (n, chunk 0); slot 1 is free; epilogue of tile n-1 out of the accumulator stage
+      if (tprev >= 0) epilogue_loads(tprev);
+      write_chunk(1);
+      if (t + t_step < a.ntiles) issue_chunk(t + t_step, 1);
+      if (tprev >= 0) epilogue_finish();
+      __syncthreads();                                      // barrier #2n+1: (n, chunk 1) published; accumulator stage free again
+      tprev = t;
+    }
+    __syncthreads();                                        // final barrier: accumulators of the last tile published
+    if (tprev >= 0) {
+      epilogue_loads(tprev);
+      epilogue_finish();
     }
     return;
   }
 
-  // ================= consumers: wave = pixel group (64 pixels = 2 rows of the tile), one 32-channel co-tile =================
+  // ================= MFMA waves: wave = pixel group (64 pixels = 2 rows of the tile), one 32-channel co-tile =================
   const int pg = wave;
   const int j = lane & 31, g = lane >> 5;
   const int row0 = pg * 2;                                 // sub-tile s = tile row row0 + s, column j
   const int xidx0 = g * PLANE_PIX + row0 * LW + j;
-  const long ohw = hw;
-  const uint32_t ohw4 = (uint32_t)(hw * 4);
-  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, (int)0x80000000u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, (short)0, (int)0x80000000u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)a.mask, (short)0, (int)0x80000000u, 0x00020000);
-  float bv[16];                                            // bias of this lane's 16 output channels
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = (r & 3) + 8 * (r >> 2) + 4 * g;
-    bv[r] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
-  }
   for (long t = t_begin; t < a.ntiles; t += t_step) {
-    const int tx = (int)(t % a.tiles_x);
-    const long t2 = t / a.tiles_x;
-    const int ty = (int)(t2 % a.tiles_y);
-    const int b = (int)(t2 / a.tiles_y);
-    // epilogue operands first (branch-free buffer loads; absent operands / invalid positions read 0 through the
-    // out-of-range voffset): their latency hides behind the MFMAs of the tile
-    float rv[2][16], dv[2][16], mv[2][16];
-    long pofs[2];
-    bool pval[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int oy = ty * 8 + row0 + s, ox = tx * 32 + j;
-      pval[s] = oy < a.H && ox < a.W;
-      pofs[s] = (long)oy * a.W + ox;
-      const uint32_t vr = (uint32_t)(((long)b * a.res_bs + pofs[s] + 4L * g * ohw) * 4);
-      const uint32_t vd = (uint32_t)(((long)b * a.y_bs + pofs[s] + 4L * g * ohw) * 4);
-      const uint32_t vm = (uint32_t)(((long)b * a.mask_bs + pofs[s] + 4L * g * ohw) * 4);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int crow = (r & 3) + 8 * (r >> 2);
-        const bool ok = pval[s] && crow + 4 * g < a.Cout;
-        const uint32_t so = (uint32_t)crow * ohw4;
-        rv[s][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)((ok && a.res) ? vr : OOB), (int)so, 0));
-        dv[s][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (int)((ok && a.accumulate) ? vd : OOB), (int)so, 0));
-        mv[s][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)((ok && a.mask && crow + 4 * g < a.nmask) ? vm : OOB), (int)so, 0));
-      }
-    }
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      __syncthreads();                                      // barrier #q: chunk q = 2n + c is in slot c
+      __syncthreads();                                      // barrier #2n+c: chunk c of tile n is in slot c
+      if (c == 1) {
+        // (the accumulator stage was released by the barrier that just passed: tile n-1's epilogue is done)
+      }
       const u32x4* buf = xl + c * CHUNK;
       u32x4 xb[2][2][3], wa[2][3];
       auto read_step = [&](int sel, int tap) {
@@ -446,27 +475,20 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // epilogue (branch-free: invalid positions / channels are dropped by the out-of-range voffset of the buffer store)
+    // hand the accumulators to the epilogue waves: D[i][jj], i = (r&3) + 8*(r>>2) + 4*g (channel), jj = column
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const uint32_t vd = (uint32_t)(((long)b * a.y_bs + pofs[s] + 4L * g * ohw) * 4);
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int crow = (r & 3) + 8 * (r >> 2);
-        const bool ok = pval[s] && crow + 4 * g < a.Cout;
-        float v = (s ? acc1[r] : acc0[r]) + bv[r];
-        if (a.lrelu) v = irr_lrelu(v);
-        v = rv[s][r] + a.alpha * v;                 // rv = 0 without a residual operand
-        v += dv[s][r];                              // dv = 0 unless accumulating
-        if (a.mask && crow + 4 * g < a.nmask) v *= irr_lrelu_grad(mv[s][r]);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ry, (int)((ok && (X3_ABL != 7 || v == 123.456f)) ? vd : OOB), (int)((uint32_t)crow * ohw4), 0);
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * g;
+        ol[co * 256 + (row0 + s) * 32 + j] = s ? acc1[r] : acc0[r];
       }
-    }
   }
+  __syncthreads();                                          // final barrier (pairs with the producers')
 }
 
 static bool x3s_ok(int B, int Cin, int H, int W, int Cout, int dil) {
-  if (dil != 1 || Cout > 32 || Cin <= 16 || Cin > 32) return false;
+  if (dil != 1 || Cout > 32 || Cin <= 16 || Cin > 32 || (W & 3)) return false;
   const long tiles = (long)B * ((H + 7) / 8) * ((W + 31) / 32);
   const double eff = (double)H * W / ((double)((H + 7) / 8) * ((W + 31) / 32) * 256);
   return eff >= 0.8 && (tiles >= 2048 || g_min_blocks == 0);
@@ -646,7 +668,7 @@ extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bi
     s.x_bs = x_bs; s.y_bs = y_bs; s.res_bs = res_bs;
     s.lrelu = lrelu; s.accumulate = accumulate; s.alpha = alpha;
     s.mask_bs = mask_bs; s.nmask = nmask;
-    constexpr size_t lds_bytes = (18 * 3 * 64 + 2 * 6 * 352) * 16;
+    constexpr size_t lds_bytes = (18 * 3 * 64 + 2 * 6 * 352) * 16 + 32 * 256 * 4;
     static bool attr_set = false;
     if (!attr_set) {
       IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

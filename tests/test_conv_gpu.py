@@ -229,7 +229,7 @@ def test_conv_wgrad_x3_is_fp32_faithful(case, x3_everywhere):
     assert e_w <= 3e-6 and e_b <= 3e-6, (e_w, e_b)
 
 
-X3S_CASES = [(32, 32, 2, 24, 64), (32, 32, 1, 70, 90), (24, 32, 1, 16, 32), (32, 9, 2, 16, 96)]
+X3S_CASES = [(32, 32, 2, 24, 64), (32, 32, 1, 70, 92), (24, 32, 1, 16, 32), (32, 9, 2, 16, 96)]
 
 
 @pytest.mark.parametrize("case", X3S_CASES, ids=[f"{c[0]}to{c[1]}_{c[3]}x{c[4]}" for c in X3S_CASES])
