@@ -70,9 +70,11 @@ __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
 
 __device__ __forceinline__ uint32_t alignbit16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }
 
-template <int MW, int NW, int KG, int R>
-__global__ __launch_bounds__(MW* NW * 64) void conv_wgrad_x3_kernel(const WX3Args a) {
-  constexpr int NTHR = MW * NW * 64;
+// KW > 1 (the 32 -> 32 layers: a single (co, ci) tile): KW wave groups share the staged unit and split its k-steps;
+// their accumulators are folded through LDS before the flush.
+template <int MW, int NW, int KG, int R, int KW = 1>
+__global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const WX3Args a) {
+  constexpr int NTHR = MW * NW * KW * 64;
   constexpr int RING = 2 * R + 2;                          // x rows resident
   constexpr int XG = KG + 2;                               // groups per staged x row (one margin group on each side)
   constexpr int XPITCH = RING * XG + 1;                    // 16-B units per input channel (odd: conflict-free channel stride)
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(MW* NW * 64) void conv_wgrad_x3_kernel(const WX3Arg
   constexpr int GR = (GUNITS + NTHR - 1) / NTHR;
   constexpr int NK = R * KG / 2;                           // MFMA k-steps (16 pixels = two groups) per unit
   static_assert((R * KG) % 2 == 0, "a unit must hold an even number of 8-pixel groups");
+  static_assert(NK % KW == 0, "the k-steps of a unit must divide evenly among the wave groups");
   extern __shared__ u32x4 lds[];
   u32x4* const xs = lds;                                   // [3][32*NW][XPITCH]
   u32x4* const gs = lds + 3 * XPLANE;                      // [3][32*MW][GPITCH]
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(MW* NW * 64) void conv_wgrad_x3_kernel(const WX3Arg
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave % MW, wn = wave / MW;
+  const int wm = wave % MW, wn = (wave / MW) % NW, wk = wave / (MW * NW);
   const int j = lane & 31, g = lane >> 5;
   const int ci0 = blockIdx.y * 32 * NW, co0 = blockIdx.z * 32 * MW;
   const long hw = (long)a.H * a.W;
@@ -192,12 +195,12 @@ __global__ __launch_bounds__(MW* NW * 64) void conv_wgrad_x3_kernel(const WX3Arg
   // Flat software pipeline over stages (ks, dy, B piece q): the LDS reads of stage s+1 are issued ahead of the MFMAs of
   // stage s; sched_barriers keep the compiler from hoisting more than that (144 of the 256 registers are accumulators).
   auto compute = [&](int y, int gbuf) {
-    constexpr int NS = NK * 9;
+    constexpr int NS = (NK / KW) * 9;                      // this wave's k-steps: wk, wk + KW, ...
     u32x4 ob[2];
     uint32_t lb[2], rb[2];
     u32x4 af[3];
     auto read_b = [&](int sel, int st) {
-      const int ks = st / 9, dy = (st % 9) / 3, q = st % 3;
+      const int ks = wk + KW * (st / 9), dy = (st % 9) / 3, q = st % 3;
       const int gi = 2 * ks + g;
       const int row = gi / KG, grp = gi - row * KG;
       const int slot = (y + row + dy - 1 + RING) % RING;
@@ -206,7 +209,8 @@ __global__ __launch_bounds__(MW* NW * 64) void conv_wgrad_x3_kernel(const WX3Arg
       lb[sel] = xs[xi - 1][3];
       rb[sel] = xs[xi + 1][0];
     };
-    auto read_a = [&](int ks) {
+    auto read_a = [&](int ki) {
+      const int ks = wk + KW * ki;
       const int gi = 2 * ks + g;
       const int row = gi / KG, grp = gi - row * KG;
 #pragma unroll
@@ -277,9 +281,35 @@ __global__ __launch_bounds__(MW* NW * 64) void conv_wgrad_x3_kernel(const WX3Arg
     }
   }
 
+  if (KW > 1) {
+    // fold the wave groups' accumulators: the upper half of the active groups parks its tiles in LDS (free after the
+    // last unit), the lower half adds them; log2(KW) rounds, then group 0 flushes
+    float* red = (float*)lds;                              // [group][tap][r][lane]
+#pragma unroll
+    for (int half = KW / 2; half >= 1; half >>= 1) {
+      __syncthreads();
+      if (wk >= half && wk < 2 * half) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(((wk - half) * MW * NW + wn * MW + wm) * 144 + t * 16 + r) * 64 + lane] = acc[t][r];
+      }
+      __syncthreads();
+      if (wk < half) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] += red[((wk * MW * NW + wn * MW + wm) * 144 + t * 16 + r) * 64 + lane];
+      }
+    }
+    if (wk > 0) {
+      // (bias partial sums below are per thread and do not depend on wk)
+    }
+  }
   // ---- flush: ws[co][tap][ci] += alpha * acc (lanes = ci: coalesced atomics) ----
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
+    if (KW > 1 && wk > 0) break;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
@@ -312,13 +342,15 @@ int cu_count() {
   return g_cu_count;
 }
 
-template <int MW, int NW, int KG, int R>
+template <int MW, int NW, int KG, int R, int KW = 1>
 int launch_wx3(WX3Args a, hipStream_t st) {
   constexpr int RING = 2 * R + 2, XG = KG + 2;
-  constexpr size_t lds_bytes = 16 * (3 * (size_t)(32 * NW) * (RING * XG + 1) + 3 * (size_t)(32 * MW) * (2 * R * KG + 1));
+  constexpr size_t lds_stage = 16 * (3 * (size_t)(32 * NW) * (RING * XG + 1) + 3 * (size_t)(32 * MW) * (2 * R * KG + 1));
+  constexpr size_t lds_red = KW > 1 ? (size_t)(KW / 2) * MW * NW * 144 * 64 * 4 : 0;
+  constexpr size_t lds_bytes = lds_stage > lds_red ? lds_stage : lds_red;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e0 = hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<MW, NW, KG, R>,
+    hipError_t e0 = hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<MW, NW, KG, R, KW>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e0 != hipSuccess) return (int)e0;
     attr_set = true;
@@ -339,7 +371,7 @@ int launch_wx3(WX3Args a, hipStream_t st) {
   a.cols_per_block = (int)((a.ncols + want - 1) / want);
   if (a.cols_per_block < 1) a.cols_per_block = 1;
   dim3 grid(irr_cdiv(a.ncols, a.cols_per_block), gy_, gz_);
-  hipLaunchKernelGGL((conv_wgrad_x3_kernel<MW, NW, KG, R>), grid, dim3(MW * NW * 64), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_wgrad_x3_kernel<MW, NW, KG, R, KW>), grid, dim3(MW * NW * KW * 64), lds_bytes, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -386,10 +418,11 @@ __global__ __launch_bounds__(256) void wx3_bias_kernel(const float* __restrict__
 extern "C" int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil) {
   if (k != 3 || stride != 1 || dil != 1 || B <= 0) return 0;
   if (W % 8 || W < 32 || H < 8 || Cin < 16) return 0;
-  if (Cout <= 32 && Cin < 64) return 0;                                    // 32 -> 32 layers: fp32 halo kernel
+  if (Cout <= 32 && Cin < 64 && (Cin > 32 || W % 32)) return 0;            // (32 -> 32 layers: K split over 8 wave groups)
   if ((long)B * H * W < 100000 && irr_conv_x3_set_min_blocks(-1) > 0) return 0;   // small levels stay on the fp32 kernels
   const int kg = pick_kg(W);
   const int cot = (Cout + 31) / 32;
+  if (cot == 1 && Cin <= 32) return 1144;                                  // <1,1,4,4,KW=8>
   const int mw = cot == 1 ? 8 : cot == 2 ? 2 : cot == 3 ? 3 : 4;            // 8: operand roles swapped (see irr_conv2d_wgrad_x3)
   return mw * 100 + kg * 10 + (4 / kg);
 }
@@ -406,7 +439,8 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
   //   dW[co][ci][t] = sum gy[p] x[p + d(t)] = sum x[p'] gy[p' - d(t)] = dW'[ci][co][8 - t],
   // so the launch runs with the roles exchanged (8 "output-channel" waves over Cin, one "input" tile = Cout) and the
   // unpack kernel transposes and flips the taps.  The bias gradient then comes from a separate pass over the small gy.
-  const bool swapped = cot == 1;
+  const bool ksplit = cot == 1 && Cin <= 32;               // one (co, ci) tile: eight wave groups split the pixels
+  const bool swapped = cot == 1 && !ksplit;
   WX3Args a;
   a.ws = ws; a.gbias = swapped ? nullptr : gbias; a.alpha = alpha;
   a.H = H; a.W = W;
@@ -424,7 +458,9 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
     a.x = (swapped ? gy : x) + (long)b0 * a.x_bs;
     a.gy = (swapped ? x : gy) + (long)b0 * a.gy_bs;
     int rc;
-    if (swapped) {
+    if (ksplit) {
+      rc = launch_wx3<1, 1, 4, 4, 8>(a, st);
+    } else if (swapped) {
       rc = kg == 4 ? launch_wx3<8, 1, 4, 1>(a, st) : kg == 2 ? launch_wx3<8, 1, 2, 2>(a, st) : launch_wx3<8, 1, 1, 4>(a, st);
     } else if (cot == 2) {
       rc = kg == 4 ? launch_wx3<2, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<2, 2, 2, 2>(a, st) : launch_wx3<2, 2, 1, 4>(a, st);
