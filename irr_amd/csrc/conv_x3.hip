@@ -575,8 +575,9 @@ static int pick_ct(int CoT) {
   if (CoT == 1) return 1;
   if (CoT == 2) return 2;
   if (CoT % 4 == 0) return 4;
+  if (CoT >= 7) return 4;            // 4 waves = one per SIMD; a partly idle last group costs less than 3-wave blocks
   if (CoT % 3 == 0) return 3;
-  return (CoT % 4 == 3 || CoT > 8) ? 4 : 3;
+  return 4;
 }
 
 struct Plan { int ct, pg, plane; TileCfg t; long blocks; };
