@@ -14,6 +14,10 @@ from .losses import MultiScaleEPE_PWC_Bi_Occ_upsample  # noqa: E402,F401
 from . import ddp, optim, train  # noqa: E402,F401
 
 from . import pwcnet as _pwcnet  # noqa: E402
+from .pwcnet_variants import (PWCNet_bi, PWCNet_occ, PWCNet_occ_bi, PWCNet_irr, PWCNet_irr_bi,  # noqa: E402,F401
+                              PWCNet_irr_occ, PWCNet_irr_occ_bi)                                # models/__init__.py:28-34
+from .losses import (MultiScaleEPE_PWC, MultiScaleEPE_PWC_Bi, MultiScaleEPE_PWC_Occ, MultiScaleEPE_PWC_Bi_Occ,  # noqa: E402,F401
+                     MultiScaleEPE_PWC_Bi_Occ_upsample_Sintel, MultiScaleEPE_PWC_Bi_Occ_upsample_KITTI)
 
 PWCNet_baseline = _pwcnet.PWCNet       # models/__init__.py:27 `PWCNet = pwcnet.PWCNet` (ablation baseline, config 0)
 IRR_PWC = PWCNet          # models/__init__.py:35 rebinds the module name to the class

@@ -170,3 +170,174 @@ class MultiScaleEPE_PWC_Bi_Occ_upsample(nn.Module):
             loss_dict["epe"] = torch.linalg.vector_norm(tgt - output_dict["flow"], ord=2, dim=1, keepdim=True).mean()
             loss_dict["F1"] = fbeta_score(target_dict["target_occ1"], torch.round(self.occ_activ(output_dict["occ"])), 1)
         return loss_dict
+
+
+# ----------------------------------------------------------------------------------------------
+# Losses of the PWC-Net ablation ladder and the fine-tuning stages.  The per-pixel reductions
+# reuse the HIP kernels above; the Sintel / KITTI variants add a robust (Charbonnier-type) EPE and a BCE term that are
+# written with device-side torch elementwise ops (fine-tuning losses, not on the measured path).
+# ----------------------------------------------------------------------------------------------
+PWC_LEVEL_WEIGHTS = [0.32, 0.08, 0.02, 0.01, 0.005]                      # losses.py:351
+
+
+def _eval_epe(output_dict, target_dict):
+    return torch.linalg.vector_norm(target_dict["target1"] - output_dict["flow"], ord=2, dim=1, keepdim=True).mean()
+
+
+class _PoolCache:
+    """avg-pooled targets per (tensor, level size): every level size is pooled once per step."""
+
+    def __init__(self, div):
+        self.div, self.store = div, {}
+
+    def __call__(self, src, like, is_flow):
+        key = (id(src), like.shape[2], like.shape[3])
+        if key not in self.store:
+            self.store[key] = avg_pool_to(src, like.shape[2], like.shape[3], self.div if is_flow else 1.0)
+        return self.store[key]
+
+
+class MultiScaleEPE_PWC(nn.Module):
+    """losses.py:344-371 (models/pwcnet.py, pwcnet_irr.py)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self._args, self._batch_size, self._weights = args, args.batch_size, list(PWC_LEVEL_WEIGHTS)
+
+    def forward(self, output_dict, target_dict):
+        if not self.training:
+            return {"epe": _eval_epe(output_dict, target_dict)}
+        pool = _PoolCache(float(self._args.model_div_flow))
+        terms = [_EpeSum.apply(o, pool(target_dict["target1"], o, True), self._weights[i]) for i, o in enumerate(output_dict['flow'])]
+        return {"total_loss": torch.cat(terms).sum() / self._batch_size}
+
+
+class MultiScaleEPE_PWC_Bi(nn.Module):
+    """losses.py:374-402 (pwcnet_bi.py, pwcnet_irr_bi.py)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self._args, self._batch_size, self._weights = args, args.batch_size, list(PWC_LEVEL_WEIGHTS)
+
+    def forward(self, output_dict, target_dict):
+        if not self.training:
+            return {"epe": _eval_epe(output_dict, target_dict)}
+        pool = _PoolCache(float(self._args.model_div_flow))
+        terms = []
+        for i, (of, ob) in enumerate(output_dict['flow']):
+            terms.append(_EpeSum.apply(of, pool(target_dict["target1"], of, True), self._weights[i]))
+            terms.append(_EpeSum.apply(ob, pool(target_dict["target2"], ob, True), self._weights[i]))
+        return {"total_loss": torch.cat(terms).sum() / (2 * self._batch_size)}
+
+
+class MultiScaleEPE_PWC_Occ(nn.Module):
+    """losses.py:405-454 (pwcnet_occ.py, pwcnet_irr_occ.py)."""
+
+    def __init__(self, args, reduce_fn=None):
+        super().__init__()
+        self._args, self._batch_size, self._weights = args, args.batch_size, list(PWC_LEVEL_WEIGHTS)
+        self.occ_activ = nn.Sigmoid()
+        self._reduce_fn = reduce_fn
+
+    def forward(self, output_dict, target_dict):
+        if not self.training:
+            return {"epe": _eval_epe(output_dict, target_dict),
+                    "F1": fbeta_score(target_dict["target_occ1"], torch.round(self.occ_activ(output_dict["occ"])), 1)}
+        pool = _PoolCache(float(self._args.model_div_flow))
+        f_terms = [_EpeSum.apply(o, pool(target_dict["target1"], o, True), self._weights[i]) for i, o in enumerate(output_dict['flow'])]
+        o_terms = [_F1BalLoss.apply(o, pool(target_dict["target_occ1"], o, False), self._weights[i]) for i, o in enumerate(output_dict['occ'])]
+        return balance_and_total(torch.cat(f_terms).sum(), torch.cat(o_terms).sum(), self._batch_size, self._reduce_fn)
+
+
+class MultiScaleEPE_PWC_Bi_Occ(nn.Module):
+    """losses.py:457-512 (pwcnet_occ_bi.py, pwcnet_irr_occ_bi.py)."""
+
+    def __init__(self, args, reduce_fn=None):
+        super().__init__()
+        self._args, self._batch_size, self._weights = args, args.batch_size, list(PWC_LEVEL_WEIGHTS)
+        self.occ_activ = nn.Sigmoid()
+        self._reduce_fn = reduce_fn
+
+    def forward(self, output_dict, target_dict):
+        if not self.training:
+            return {"epe": _eval_epe(output_dict, target_dict),
+                    "F1": fbeta_score(target_dict["target_occ1"], torch.round(self.occ_activ(output_dict["occ"])), 1)}
+        pool = _PoolCache(float(self._args.model_div_flow))
+        f_terms, o_terms = [], []
+        for i, (of, ob) in enumerate(output_dict['flow']):
+            f_terms.append(_EpeSum.apply(of, pool(target_dict["target1"], of, True), self._weights[i]))
+            f_terms.append(_EpeSum.apply(ob, pool(target_dict["target2"], ob, True), self._weights[i]))
+        for i, (of, ob) in enumerate(output_dict['occ']):
+            o_terms.append(_F1BalLoss.apply(of, pool(target_dict["target_occ1"], of, False), self._weights[i]))
+            o_terms.append(_F1BalLoss.apply(ob, pool(target_dict["target_occ2"], ob, False), self._weights[i]))
+        return balance_and_total(torch.cat(f_terms).sum(), torch.cat(o_terms).sum(), 2 * self._batch_size, self._reduce_fn)
+
+
+def _robust_epe_char(flow, tgt):
+    """(||tgt - flow||_2 + 0.01) ** 0.4 per pixel (losses.py:12-14)."""
+    return torch.pow(torch.linalg.vector_norm(tgt - flow, ord=2, dim=1, keepdim=True) + 0.01, 0.4)
+
+
+class MultiScaleEPE_PWC_Bi_Occ_upsample_Sintel(nn.Module):
+    """losses.py:579-638: Sintel fine-tuning -- only the forward direction is supervised (robust EPE + summed BCE on the
+    occlusion probability); the backward-direction outputs take no gradient."""
+
+    def __init__(self, args, reduce_fn=None):
+        super().__init__()
+        self._args, self._batch_size, self._weights = args, args.batch_size, list(LEVEL_WEIGHTS)
+        self.occ_activ = nn.Sigmoid()
+        self._reduce_fn = reduce_fn
+
+    def forward(self, output_dict, target_dict):
+        if not self.training:
+            return {"epe": _eval_epe(output_dict, target_dict),
+                    "F1": fbeta_score(target_dict["target_occ1"], torch.round(self.occ_activ(output_dict["occ"])), 1)}
+        pool = _PoolCache(float(self._args.model_div_flow))
+        flow_loss, occ_loss = 0, 0
+        for ii, output_ii in enumerate(output_dict['flow']):
+            loss_ii = 0
+            for jj in range(len(output_ii) // 2):
+                o = output_ii[2 * jj]
+                loss_ii = loss_ii + _robust_epe_char(o, pool(target_dict["target1"], o, True)).sum()
+            flow_loss = flow_loss + self._weights[ii] * loss_ii / len(output_ii) * 2
+        for ii, output_ii in enumerate(output_dict['occ']):
+            loss_ii = 0
+            for jj in range(len(output_ii) // 2):
+                o = output_ii[2 * jj]
+                loss_ii = loss_ii + torch.nn.functional.binary_cross_entropy(self.occ_activ(o), pool(target_dict["target_occ1"], o, False),
+                                                                             reduction='sum')
+            occ_loss = occ_loss + self._weights[ii] * loss_ii / len(output_ii) * 2
+        return balance_and_total(flow_loss, occ_loss, self._batch_size, self._reduce_fn)
+
+
+class MultiScaleEPE_PWC_Bi_Occ_upsample_KITTI(nn.Module):
+    """losses.py:640-699: KITTI fine-tuning -- sparse ground truth: every forward output is upsampled to full resolution,
+    the robust EPE is masked by ``input_valid`` and normalised per sample by h*w / #valid; no occlusion term."""
+
+    def __init__(self, args):
+        super().__init__()
+        self._args, self._batch_size = args, args.batch_size
+        self._weights = [0.001, 0.001, 0.001, 0.002, 0.004, 0.004, 0.004]
+        self.occ_activ = nn.Sigmoid()
+
+    def forward(self, output_dict, target_dict):
+        from . import functional as Fn
+        valid = target_dict["input_valid"]
+        b, _, h, w = target_dict["target1"].shape
+        if not self.training:
+            gt_mag = torch.linalg.vector_norm(target_dict["target1"], ord=2, dim=1, keepdim=True) + 1e-8
+            epe = torch.linalg.vector_norm(target_dict["target1"] - output_dict["flow"], ord=2, dim=1, keepdim=True) * valid
+            nvalid = valid.reshape(b, -1).sum(1)
+            outlier = (epe > 3).float() * ((epe / gt_mag) > 0.05).float() * valid
+            return {"epe": (epe.reshape(b, -1).sum(1) / nvalid).mean(), "outlier": (outlier.reshape(b, -1).sum(1) / nvalid).mean()}
+        tgt = float(self._args.model_div_flow) * target_dict["target1"]
+        norm_const = (h * w) / valid.reshape(b, -1).sum(1)                       # per sample
+        flow_loss = 0
+        for ii, output_ii in enumerate(output_dict['flow']):
+            loss_ii = 0
+            for jj in range(len(output_ii) // 2):
+                up = Fn.resize_bilinear_ac(output_ii[2 * jj], h, w)
+                e = _robust_epe_char(up, tgt) * valid
+                loss_ii = loss_ii + (e.reshape(b, -1).sum(1) * norm_const).sum()
+            flow_loss = flow_loss + self._weights[ii] * loss_ii / len(output_ii) * 2
+        return {"flow_loss": flow_loss / self._batch_size, "total_loss": flow_loss / self._batch_size}

@@ -365,6 +365,85 @@ def gen_augment(out_dir):
     np.savez_compressed(os.path.join(out_dir, "augment.npz"), **d)
 
 
+VARIANTS = [("PWCNet_bi", "MultiScaleEPE_PWC_Bi"), ("PWCNet_occ", "MultiScaleEPE_PWC_Occ"), ("PWCNet_occ_bi", "MultiScaleEPE_PWC_Bi_Occ"),
+            ("PWCNet_irr", "MultiScaleEPE_PWC"), ("PWCNet_irr_bi", "MultiScaleEPE_PWC_Bi"), ("PWCNet_irr_occ", "MultiScaleEPE_PWC_Occ"),
+            ("PWCNet_irr_occ_bi", "MultiScaleEPE_PWC_Bi_Occ")]
+
+
+def _rescale_pure(flow, div_flow, width_im, height_im, to_local=True):
+    """autograd-legal twin of rescale_flow for the ablation models, where every call site rebinds the name."""
+    if to_local:
+        u, v = float(flow.size(3) / width_im / div_flow), float(flow.size(2) / height_im / div_flow)
+    else:
+        u, v = float(width_im * div_flow / flow.size(3)), float(height_im * div_flow / flow.size(2))
+    return flow * torch.tensor([u, v]).view(1, 2, 1, 1)
+
+
+def variant_batch(B=1, H=128, W=192, seed=4321):
+    g = torch.Generator().manual_seed(seed)
+    return {"input1": torch.rand(B, 3, H, W, generator=g), "input2": torch.rand(B, 3, H, W, generator=g),
+            "target1": 5 * torch.randn(B, 2, H, W, generator=g), "target2": 5 * torch.randn(B, 2, H, W, generator=g),
+            "target_occ1": (torch.rand(B, 1, H, W, generator=g) < 0.2).float(),
+            "target_occ2": (torch.rand(B, 1, H, W, generator=g) < 0.2).float(),
+            "input_valid": (torch.rand(B, 1, H, W, generator=g) < 0.6).float()}
+
+
+def gen_variants(out_dir):
+    """the seven pwcnet_* ablation models (reference MSRA init under seed 0, robust-mask mode):
+    eval outputs (every second pixel), training losses with the matching loss class and the global gradient norm;
+    plus the Sintel / KITTI fine-tuning losses on IRR_PWC training outputs."""
+    args = types.SimpleNamespace(batch_size=1, model_div_flow=0.05)
+    batch = variant_batch()
+    d = {}
+    set_mode(False, True)
+    for mname, lname in VARIANTS:
+        modname = "models." + mname.replace("PWCNet", "pwcnet")
+        mod = sys.modules[modname]
+        orig = getattr(mod, "rescale_flow", None)
+        if orig is not None:
+            mod.rescale_flow = _rescale_pure
+        torch.manual_seed(0)
+        m = getattr(models, mname)(args)
+        sd = m.state_dict()
+        d[f"{mname}_keys"] = np.array(list(sd.keys()))
+        d[f"{mname}_init"] = np.array([float(sum(v.double().sum() for v in sd.values())), float(sum(v.double().abs().sum() for v in sd.values()))])
+        m.eval()
+        with torch.no_grad():
+            out = m(batch)
+        d[f"{mname}_flow"] = npf(out["flow"][:, :, ::2, ::2])
+        d[f"{mname}_flow_stats"] = np.array([float(out["flow"].mean()), float(out["flow"].abs().mean())])
+        if "occ" in out:
+            d[f"{mname}_occ"] = npf(out["occ"][:, :, ::2, ::2])
+        m.train()
+        loss = getattr(losses, lname)(args).train()
+        ld = loss(m(batch), batch)
+        ld["total_loss"].backward()
+        gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+        d[f"{mname}_losses"] = np.array([float(ld.get("flow_loss", ld["total_loss"])), float(ld.get("occ_loss", 0.0)), float(ld["total_loss"]), gn])
+        print(mname, d[f"{mname}_flow_stats"], d[f"{mname}_losses"], flush=True)
+        if orig is not None:
+            mod.rescale_flow = orig
+    # fine-tuning losses on IRR_PWC training outputs
+    set_mode(True, True)
+    torch.manual_seed(0)
+    m = models.IRR_PWC(args).train()
+    for lname in ("MultiScaleEPE_PWC_Bi_Occ_upsample_Sintel", "MultiScaleEPE_PWC_Bi_Occ_upsample_KITTI"):
+        m.zero_grad()
+        ld = getattr(losses, lname)(args).train()(m(batch), batch)
+        ld["total_loss"].backward()
+        gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+        d[f"{lname}_losses"] = np.array([float(ld["flow_loss"]), float(ld.get("occ_loss", 0.0)), float(ld["total_loss"]), gn])
+        print(lname, d[f"{lname}_losses"], flush=True)
+    # KITTI eval metrics on a synthetic prediction
+    g = torch.Generator().manual_seed(9)
+    pred = {"flow": batch["target1"] + 3 * torch.randn(1, 2, 128, 192, generator=g), "occ": torch.randn(1, 1, 128, 192, generator=g)}
+    le = losses.MultiScaleEPE_PWC_Bi_Occ_upsample_KITTI(args).eval()(pred, batch)
+    d["kitti_eval"] = np.array([float(le["epe"]), float(le["outlier"])])
+    d["kitti_eval_pred_flow"] = npf(pred["flow"])
+    set_mode(False, False)
+    np.savez_compressed(os.path.join(out_dir, "variants.npz"), **d)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
@@ -372,7 +451,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
-    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "pwcnet": gen_pwcnet_plumbing, "noise": gen_noise_floor, "augment": gen_augment}
+    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "pwcnet": gen_pwcnet_plumbing, "noise": gen_noise_floor, "augment": gen_augment, "variants": gen_variants}
     for k, fn in steps.items():
         if a.only and k not in a.only.split(","):
             continue
