@@ -67,3 +67,28 @@ class TrainStep:
 
 def make_adam(params, lr: float = 1e-4, weight_decay: float = 4e-4) -> torch.optim.Optimizer:
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)
+
+
+class EvalStep:
+    """EvaluationEpoch._step (runtime.py:345-383): move input*/target* tensors to the device, optional augmentation,
+    forward under ``no_grad`` in eval mode -> (loss_dict, output_dict, batch_size).  ``save`` (optional, an args object
+    with ``save`` and the ``save_result_*`` switches) makes every step also write its outputs like
+    EvaluationEpoch.run does (runtime.py:423-424)."""
+
+    def __init__(self, model_and_loss: ModelAndLoss, augmentation=None, device="cuda", save=None):
+        self.mal, self.augmentation, self.device, self.save = model_and_loss, augmentation, device, save
+
+    @torch.no_grad()
+    def __call__(self, example_dict):
+        self.mal.eval()
+        for key, value in list(example_dict.items()):
+            if ("input" in key or "target" in key) and torch.is_tensor(value):
+                example_dict[key] = value.to(self.device)
+        if self.augmentation is not None:
+            example_dict = self.augmentation(example_dict)
+        batch_size = example_dict["input1"].size(0)
+        loss_dict, output_dict = self.mal(example_dict)
+        if self.save is not None:
+            from .io import save_outputs
+            save_outputs(self.save, example_dict, output_dict)
+        return loss_dict, output_dict, batch_size

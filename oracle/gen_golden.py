@@ -444,6 +444,21 @@ def gen_variants(out_dir):
     np.savez_compressed(os.path.join(out_dir, "variants.npz"), **d)
 
 
+def gen_flowvis(out_dir):
+    """Middlebury colour coding of utils/flow.py (pure numpy).  The module also imports pypng, which
+    is absent here and only used by its PNG writer: an EMPTY placeholder module satisfies that import; no function of
+    it is called."""
+    if "png" not in sys.modules:
+        sys.modules["png"] = types.ModuleType("png")
+    import utils.flow as uf
+    g = torch.Generator().manual_seed(21)
+    flow = (6 * torch.randn(2, 24, 32, generator=g)).numpy().astype(np.float32)
+    flow[:, 3, 4] = 0.0
+    flow[0, 5, 6] = 2e7                                        # "unknown" marker
+    d = {"flow": flow.copy(), "rgb": uf.flow_to_png_middlebury(flow.copy()), "wheel": uf.make_color_wheel()}
+    np.savez_compressed(os.path.join(out_dir, "flowvis.npz"), **d)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
@@ -451,7 +466,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
-    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "pwcnet": gen_pwcnet_plumbing, "noise": gen_noise_floor, "augment": gen_augment, "variants": gen_variants}
+    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "pwcnet": gen_pwcnet_plumbing, "noise": gen_noise_floor, "augment": gen_augment, "variants": gen_variants, "flowvis": gen_flowvis}
     for k, fn in steps.items():
         if a.only and k not in a.only.split(","):
             continue

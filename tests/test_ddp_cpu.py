@@ -58,7 +58,8 @@ def _worker(rank, world, port, q):
         ld = _loss(model, mine, ddp.reduce_losses())
         ld["total_loss"].backward()
         arena.sync()
-    q.put((rank, arena.flat.clone(), float(ld["total_loss"].detach())))
+    # plain lists, not tensors: a tensor travels by file-descriptor passing and is lost if this process exits first
+    q.put((rank, arena.flat.tolist(), float(ld["total_loss"].detach())))
     dist.destroy_process_group()
 
 
@@ -71,6 +72,7 @@ def test_two_rank_gloo_matches_single_process():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=100) for _ in range(2)], key=lambda t: t[0])
+    res = [(r, torch.tensor(flat), loss) for r, flat, loss in res]
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
