@@ -584,8 +584,8 @@ struct Plan { int ct, pg, plane; TileCfg t; long blocks; };
 
 static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) {
   if (Cin < 16 || dil < 1 || H < 8 || W < 8) return false;
-  if (Cin < 64 && g_min_blocks > 0) return false;       // two or three chunks: prologue/epilogue dominate (see conv_x3s_kernel)
   const int CoT = (Cout + 31) / 32;
+  if (Cin < 64 && CoT == 1 && g_min_blocks > 0) return false;   // two or three chunks AND one co-tile: see conv_x3s_kernel
   p->ct = pick_ct(CoT);
   static const int nts78[2] = {8, 7};
   static const int nts4[1] = {4};
@@ -606,6 +606,16 @@ static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) 
   }
   if (!ok) return false;
   p->blocks = (long)B * ((H + p->t.tr - 1) / p->t.tr) * ((W + p->t.tc - 1) / p->t.tc) * ((CoT + p->ct - 1) / p->ct);
+  if (p->blocks < g_min_blocks && p->ct >= 2) {
+    // small pyramid levels: half-size tiles (NT = 4) double the number of blocks
+    TileCfg t4;
+    const int plane4 = p->ct == 2 ? 616 : 352;
+    if (pick_tile(H, W, dil, p->pg, plane4, nts4, 1, &t4)) {
+      const long b4 = (long)B * ((H + t4.tr - 1) / t4.tr) * ((W + t4.tc - 1) / t4.tc) * ((CoT + p->ct - 1) / p->ct);
+      const double e4 = (double)H * W / ((double)((H + t4.tr - 1) / t4.tr) * ((W + t4.tc - 1) / t4.tc) * t4.tr * t4.tc);
+      if (b4 > p->blocks && e4 >= 0.70) { p->t = t4; p->plane = plane4; p->blocks = b4; }
+    }
+  }
   // padded work must stay close to the real work, and the launch must fill the chip
   const double eff = (double)H * W / ((double)((H + p->t.tr - 1) / p->t.tr) * ((W + p->t.tc - 1) / p->t.tc) * p->t.tr * p->t.tc);
   if (eff < 0.70) return false;
@@ -729,6 +739,9 @@ extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bi
       case 2282: rc = launch_x3<2, 2, 8, 616>(a, p.t, st); break;
       case 2272: rc = launch_x3<2, 2, 7, 616>(a, p.t, st); break;
       case 1442: rc = launch_x3<1, 4, 4, 616>(a, p.t, st); break;
+      case 4141: rc = launch_x3<4, 1, 4, 352>(a, p.t, st); break;
+      case 3141: rc = launch_x3<3, 1, 4, 352>(a, p.t, st); break;
+      case 2242: rc = launch_x3<2, 2, 4, 616>(a, p.t, st); break;
       default: return IRR_EINVAL;
     }
     if (rc) return rc;

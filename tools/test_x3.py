@@ -20,6 +20,8 @@ PERF = [  # name, cin, cout, dil, B, H, W
     ("refine 128->64 L4", 128, 64, 1, 64, 96, 112), ("ctx d2 L4", 128, 128, 2, 64, 96, 112), ("ctx d4 L4", 128, 128, 4, 64, 96, 112),
     ("occup 32->32 L6", 32, 32, 1, 32, 384, 448), ("occup 32->32 L5", 32, 32, 1, 64, 192, 224),
     ("dense.conv2 L3", 243, 128, 1, 64, 48, 56), ("dgrad ctx0 L4", 128, 565, 1, 64, 96, 112),
+    ("dense.conv2 L2", 243, 128, 1, 64, 24, 28), ("ctx.conv0 L2", 565, 128, 1, 64, 24, 28), ("dense.conv4 L2", 467, 64, 1, 64, 24, 28), ("refine 32->64 L4", 32, 64, 1, 64, 96, 112),
+    ("refine 64->32 dgrad L4", 64, 32, 1, 64, 96, 112),
 ]
 
 
