@@ -179,6 +179,13 @@ int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const float* bias
 int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                                  int B, int Cin, int H, int W, int Cout, int k, int dil,
                                  long x_bs, long gy_bs, void* stream);
+/* Stride-1 data gradient of the Cout <= 2 heads (3x3, dilation d): gx[b,ci] (+)= conv_transpose(gy, w)[b,ci], then
+ * gx[:, :nmask] *= LeakyReLU'(mask) (mask nullable).  w is the plain (Cout, Cin, 3, 3) tensor.  HBM-bound VALU kernel;
+ * replaces the MFMA launch with K = 9*Cout of irr_conv2d_fwd_f32 (transposed pack) for these layers. */
+int irr_conv2d_smallco_dgrad_f32(const float* gy, const float* w, float* gx, const float* mask,
+                                 int B, int Cin, int H, int W, int Cout, int dil,
+                                 long gy_bs, long gx_bs, long mask_bs, int nmask, int accumulate, void* stream);
+
 
 /* gpre = gy * (y>0 ? 1 : 0.1) (if lrelu) ; gbias[co] += sum gpre (gbias nullable, accumulated).
  * gpre may alias gy. */

@@ -228,6 +228,12 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
             gx[:, :nmask] *= torch.where(mask[:, :nmask] > 0, 1.0, 0.1)
         return gx
     margs = (hip.ptr(mask), hip.bs(mask), int(nmask)) if (mask is not None and nmask > 0) else (None, 0, 0)
+    if stride == 1 and cout <= 2 and k == 3 and res is None and alpha == 1.0:
+        # tiny-Cout heads: a pure HBM stream over the Cin-channel gradient buffer (VALU kernel, csrc/conv_small.hip)
+        wc = weight.detach().contiguous()
+        hip.call("irr_conv2d_smallco_dgrad_f32", hip.ptr(gy), hip.ptr(wc), hip.ptr(gx), margs[0], B, cin, H, W, cout, dil,
+                 hip.bs(gy), hip.bs(gx), margs[1], margs[2], int(accumulate), hip.stream())
+        return gx
     if stride == 1 and cout == 1:
         # the MFMA kernel consumes input channels in pairs: give the single-channel gradient a zero partner
         gy = torch.cat([gy, torch.zeros_like(gy)], dim=1)

@@ -159,6 +159,76 @@ int fwd_dispatch(int NC, dim3 grid, hipStream_t st, const float* x, const float*
 
 }  // namespace
 
+namespace {
+
+// Data gradient of the tiny-Cout heads (stride 1): gx[b,ci,p] (+)= sum_{co<NC} sum_t gy[b,co,p - d(t)] * w[co][ci][t], then
+// optionally *= LeakyReLU'(mask) for ci < nmask.  The MFMA kernels would run this with K = 9*NC <= 36 (94 % padding); it
+// is a pure HBM stream over the Cin-channel gradient buffer (563 channels for conv_last).  A lane owns one pixel, keeps
+// the 9*NC neighbourhood values of gy in registers for its whole channel range and streams over ci with wave-uniform
+// (scalar) weight loads.
+template <int NC>
+__global__ __launch_bounds__(256) void conv_smallco_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                                float* __restrict__ gx, const float* __restrict__ mask, int Cin,
+                                                                int H, int W, int dil, long gy_bs, long gx_bs, long mask_bs,
+                                                                int nmask, int accumulate, int ci_per_block) {
+  const long hw = (long)H * W;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * ci_per_block;
+  const int c1 = min(Cin, c0 + ci_per_block);
+  const bool pv = p < hw;
+  const long pp = pv ? p : 0;
+  const int oy = (int)(pp / W), ox = (int)(pp - (long)oy * W);
+  float g[NC][9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    // gx[p] takes gy[p - d(t)]: the tap that maps p - d(t) onto p
+    const int iy = oy + dil - (t / 3) * dil, ix = ox + dil - (t % 3) * dil;
+    const bool ok = pv && iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) g[c][t] = ok ? gy[(long)b * gy_bs + (long)c * hw + (long)iy * W + ix] : 0.f;
+  }
+  for (int ci = c0; ci < c1; ++ci) {
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float* wc = w + ((long)c * Cin + ci) * 9;          // wave-uniform -> scalar loads
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v = fmaf(wc[t], g[c][t], v);
+    }
+    if (!pv) continue;
+    float* dst = gx + (long)b * gx_bs + (long)ci * hw + p;
+    if (accumulate) v += *dst;
+    if (mask && ci < nmask) v *= irr_lrelu_grad(mask[(long)b * mask_bs + (long)ci * hw + p]);
+    *dst = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int irr_conv2d_smallco_dgrad_f32(const float* gy, const float* w, float* gx, const float* mask, int B, int Cin,
+                                            int H, int W, int Cout, int dil, long gy_bs, long gx_bs, long mask_bs, int nmask,
+                                            int accumulate, void* stream) {
+  if (!gy || !w || !gx || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 1 || Cout > 2 || dil < 1 || B > 65535) return IRR_EINVAL;
+  const long hw = (long)H * W;
+  const int pblocks = irr_cdiv(hw, 256);
+  // enough blocks to fill the chip; every block re-reads the (tiny) gy neighbourhood once
+  int split = (int)((4096 + (long)pblocks * B - 1) / ((long)pblocks * B));
+  if (split < 1) split = 1;
+  if (split > Cin) split = Cin;
+  const int cpb = (Cin + split - 1) / split;
+  dim3 grid(pblocks, irr_cdiv(Cin, cpb), B);
+  hipStream_t st = (hipStream_t)stream;
+  if (Cout == 1)
+    hipLaunchKernelGGL((conv_smallco_dgrad_kernel<1>), grid, dim3(256), 0, st, gy, w, gx, mask, Cin, H, W, dil, gy_bs, gx_bs, mask_bs,
+                       nmask, accumulate, cpb);
+  else
+    hipLaunchKernelGGL((conv_smallco_dgrad_kernel<2>), grid, dim3(256), 0, st, gy, w, gx, mask, Cin, H, W, dil, gy_bs, gx_bs, mask_bs,
+                       nmask, accumulate, cpb);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const float* bias, const float* res, float* y,
                                           int B, int Cin, int H, int W, int Cout, int k, int dil, long x_bs, long y_bs,
                                           long res_bs, int lrelu, float alpha, int accumulate, void* stream) {

@@ -265,3 +265,25 @@ def test_conv_x3_streaming_kernel_epilogues(case, x3_everywhere):
         ref = (g0.double() + r2.double() + 0.1 * torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=1)) * \
             torch.where(m2 > 0, 1.0, 0.1).double()
         assert (gx.cpu().double() - ref).abs().max().item() <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("cout,dil", [(2, 1), (1, 1), (2, 2), (1, 4)])
+def test_conv_smallco_dgrad_accumulate_mask(cout, dil):
+    """irr_conv2d_smallco_dgrad_f32 (the conv_last / context-tail data gradient): plain, and accumulate + LeakyReLU'-mask
+    into a channel slice of a larger gradient buffer (the DenseNet use, conv._DenseEstimatorFn.backward)."""
+    from irr_amd import conv as C
+    g = torch.Generator().manual_seed(40 + cout + dil)
+    B, cin, H, W = 2, 37, 19, 23
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    gy = torch.randn(B, cout, H, W, generator=g)
+    ref = torch.nn.grad.conv2d_input((B, cin, H, W), w.double(), gy.double(), padding=dil, dilation=dil)
+    gx = C.conv_dgrad(gy.cuda(), w.cuda(), 1, dil, (H, W))
+    np.testing.assert_allclose(gx.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    big = torch.randn(B, cin + 5, H, W, generator=g)
+    msk = torch.randn(B, cin + 5, H, W, generator=g)
+    G = big.clone().cuda()
+    C.conv_dgrad(gy.cuda(), w.cuda(), 1, dil, (H, W), gx=G[:, :cin], accumulate=True, mask=msk.cuda()[:, :cin], nmask=11)
+    want = big.double().clone()
+    want[:, :cin] += ref
+    want[:, :11] *= torch.where(msk[:, :11] > 0, 1.0, 0.1).double()
+    np.testing.assert_allclose(G.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
