@@ -383,15 +383,19 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
         emv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rmask, (int)((cok && co < a.nmask) ? vm : OOB), (int)so, 0));
       }
     };
+    f32x4 eacc[8];                                           // the finished tile's accumulators, copied out of the LDS stage
+    auto epilogue_grab = [&]() {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) eacc[e] = *(const f32x4*)(ol + (eq_c8 * 8 + e) * 256 + eq_row * 32 + eq_q * 4);
+    };
     auto epilogue_finish = [&]() {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int co = eq_c8 * 8 + e;
-        const f32x4 acc4 = *(const f32x4*)(ol + co * 256 + eq_row * 32 + eq_q * 4);
         f32x4 o;
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
-          float v = acc4[px] + bias_r[e];
+          float v = eacc[e][px] + bias_r[e];
           if (a.lrelu) v = irr_lrelu(v);
           v = erv[e][px] + a.alpha * v;             // erv = 0 without a residual operand
           v += edv[e][px];                          // edv = 0 unless accumulating
@@ -406,23 +410,33 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
       issue_chunk(t_begin, 0);
       issue_chunk(t_begin, 1);
     }
+    // The two phases of a tile are balanced against the MFMA waves' two chunk phases: the epilogue of tile n-1 is
+    // split into operand loads + accumulator copy (phase of chunk 0) and arithmetic + stores (phase of chunk 1).
     long tprev = -1;
+    bool pending = false;
     for (long t = t_begin; t < a.ntiles; t += t_step) {
       // phase after barrier #(2n-1): the MFMA waves are on (n-1, chunk 1); slot 0 is free
+      if (pending) epilogue_finish();                       // tile n-2: operands and accumulators are in registers
+      pending = false;
       write_chunk(0);
       if (t + t_step < a.ntiles) issue_chunk(t + t_step, 0);
       __syncthreads();                                      // barrier #2n: (n, chunk 0) published; accumulators of tile n-1 published
-      // phase: MFMA waves on (n, chunk 0); slot 1 is free; epilogue of tile n-1 out of the accumulator stage
-      if (tprev >= 0) epilogue_loads(tprev);
+      // phase: MFMA waves on (n, chunk 0); slot 1 is free; the accumulator stage holds tile n-1 until barrier #2n+1
+      if (tprev >= 0) {
+        epilogue_loads(tprev);
+        epilogue_grab();
+        pending = true;
+      }
       write_chunk(1);
       if (t + t_step < a.ntiles) issue_chunk(t + t_step, 1);
-      if (tprev >= 0) epilogue_finish();
       __syncthreads();                                      // barrier #2n+1: (n, chunk 1) published; accumulator stage free again
       tprev = t;
     }
+    if (pending) epilogue_finish();
     __syncthreads();                                        // final barrier: accumulators of the last tile published
     if (tprev >= 0) {
       epilogue_loads(tprev);
+      epilogue_grab();
       epilogue_finish();
     }
     return;

@@ -1,5 +1,5 @@
 #!/bin/bash
-for abl in 0 8 9 5; do
+for abl in 0 5 6 7; do
   echo "== X3_ABL=$abl"
   IRR_X3_ABL=$abl python -m irr_amd.build --force > /dev/null 2>&1
   python - <<'PY'
