@@ -169,6 +169,9 @@ int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, 
 int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil);
 int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                         int B, int Cin, int H, int W, int Cout, long x_bs, long gy_bs, void* stream);
+/* the dilated layers of the context networks (dil in {2,4,8,16}, accepted when irr_conv2d_wgrad_x3_eligible says so) */
+int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
+                            int B, int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs, void* stream);
 
 /* ---- tiny-Cout heads (Cout <= 4, stride 1): direct VALU kernels, same contracts as the MFMA entry points -------
  * conv_last 563->2 / 562->1, context tails 32->2 / 32->1, OccUpsampleNetwork.out_convs 32->1

@@ -299,7 +299,11 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
         hip.call("irr_conv2d_smallco_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W, cout, k, dil,
                  hip.bs(x), hip.bs(gy), hip.stream())
         return gw
-    if MATH == "x3" and hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, k, stride, dil):
+    if MATH == "x3" and dil > 1 and hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, k, stride, dil):
+        hip.call("irr_conv2d_wgrad_x3_dil", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
+                 cout, dil, hip.bs(x), hip.bs(gy), hip.stream())
+        return gw
+    if MATH == "x3" and dil == 1 and hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, k, stride, dil):
         hip.call("irr_conv2d_wgrad_x3", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
                  cout, hip.bs(x), hip.bs(gy), hip.stream())
         return gw

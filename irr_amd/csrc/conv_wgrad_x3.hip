@@ -72,11 +72,15 @@ __device__ __forceinline__ uint32_t alignbit16(uint32_t hi, uint32_t lo) { retur
 
 // KW > 1 (the 32 -> 32 layers: a single (co, ci) tile): KW wave groups share the staged unit and split its k-steps;
 // their accumulators are folded through LDS before the flush.
-template <int MW, int NW, int KG, int R, int KW = 1>
+// DIL > 1 (dilated context-network layers): the three vertical taps are DIL rows apart, so a column additionally fixes a
+// row residue and walks rows res, res + DIL, res + 2 DIL, ...: in that walk the taps are again neighbouring rows and the
+// ring works unchanged.  The +-DIL column taps are whole dwords (DIL = 2, 4) or whole groups (8, 16) of the neighbours.
+template <int MW, int NW, int KG, int R, int KW = 1, int DIL = 1>
 __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const WX3Args a) {
   constexpr int NTHR = MW * NW * KW * 64;
   constexpr int RING = 2 * R + 2;                          // x rows resident
-  constexpr int XG = KG + 2;                               // groups per staged x row (one margin group on each side)
+  constexpr int MG = DIL > 8 ? DIL / 8 : 1;                // margin groups on each side of a staged x row
+  constexpr int XG = KG + 2 * MG;                          // groups per staged x row
   constexpr int XPITCH = RING * XG + 1;                    // 16-B units per input channel (odd: conflict-free channel stride)
   constexpr int GPITCH = 2 * R * KG + 1;                   // 16-B units per output channel (two unit buffers)
   constexpr int XPLANE = 32 * NW * XPITCH;                 // 16-B units per piece
@@ -134,11 +138,13 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   f32x4 xraw[XR][2], graw[GR][2];
 
   // issue the global loads of x rows [row0, row0+R) and (optionally) gy rows [grow0, grow0+R) of column (b, strip c0)
-  auto issue = [&](int b, int c0, int row0, bool with_x, int grow0, bool with_g) {
+  // (row0 / grow0 count rows of the residue walk: image row = res + DIL * k)
+  auto issue = [&](int b, int c0, int res, int row0, bool with_x, int grow0, bool with_g) {
 #pragma unroll
     for (int r = 0; r < XR; ++r) {
-      const int yy = row0 + xu_rr[r];
-      const int xx = c0 + (xu_grp[r] - 1) * 8;
+      const int kk = row0 + xu_rr[r];
+      const int yy = kk < 0 ? -1 : res + DIL * kk;
+      const int xx = c0 + (xu_grp[r] - MG) * 8;
       const int ci = ci0 + xu_ci[r];
       const bool ok = with_x && xu_ci[r] >= 0 && ci < a.Cin && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
       const uint32_t vo = ok ? (uint32_t)(((long)b * a.x_bs + (long)ci * hw + (long)yy * a.W + xx) * 4) : OOB;
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     }
 #pragma unroll
     for (int r = 0; r < GR; ++r) {
-      const int yy = grow0 + gu_rr[r];
+      const int yy = res + DIL * (grow0 + gu_rr[r]);
       const int xx = c0 + gu_grp[r] * 8;
       const int co = co0 + gu_co[r];
       const bool ok = with_g && gu_co[r] >= 0 && co < a.Cout && yy >= 0 && yy < a.H && xx < a.W;
@@ -196,18 +202,27 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   // stage s; sched_barriers keep the compiler from hoisting more than that (144 of the 256 registers are accumulators).
   auto compute = [&](int y, int gbuf) {
     constexpr int NS = (NK / KW) * 9;                      // this wave's k-steps: wk, wk + KW, ...
-    u32x4 ob[2];
-    uint32_t lb[2], rb[2];
+    u32x4 ob[2], lb[2], rb[2];                             // the group and its left / right neighbours (DIL <= 2: one dword each)
     u32x4 af[3];
     auto read_b = [&](int sel, int st) {
       const int ks = wk + KW * (st / 9), dy = (st % 9) / 3, q = st % 3;
       const int gi = 2 * ks + g;
       const int row = gi / KG, grp = gi - row * KG;
       const int slot = (y + row + dy - 1 + RING) % RING;
-      const int xi = b_base + slot * XG + grp + 1 + q * XPLANE;
+      const int xi = b_base + slot * XG + grp + MG + q * XPLANE;
       ob[sel] = xs[xi];
-      lb[sel] = xs[xi - 1][3];
-      rb[sel] = xs[xi + 1][0];
+      if (DIL <= 2) {
+        lb[sel][3] = xs[xi - 1][3];
+        rb[sel][0] = xs[xi + 1][0];
+      } else if (DIL == 4) {
+        lb[sel][2] = xs[xi - 1][2];
+        lb[sel][3] = xs[xi - 1][3];
+        rb[sel][0] = xs[xi + 1][0];
+        rb[sel][1] = xs[xi + 1][1];
+      } else {
+        lb[sel] = xs[xi - MG];
+        rb[sel] = xs[xi + MG];
+      }
     };
     auto read_a = [&](int ki) {
       const int ks = wk + KW * ki;
@@ -225,15 +240,26 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       if (st + 1 < NS) read_b(cur ^ 1, st + 1);
       __builtin_amdgcn_sched_barrier(0);
       const u32x4 o = ob[cur];
-      u32x4 fm, fp;                                        // dx = -1 / +1 fragments
-      fm[0] = alignbit16(o[0], lb[cur]);
-      fm[1] = alignbit16(o[1], o[0]);
-      fm[2] = alignbit16(o[2], o[1]);
-      fm[3] = alignbit16(o[3], o[2]);
-      fp[0] = fm[1];
-      fp[1] = fm[2];
-      fp[2] = fm[3];
-      fp[3] = alignbit16(rb[cur], o[3]);
+      u32x4 fm, fp;                                        // dx = -DIL / +DIL fragments
+      if (DIL == 1) {
+        fm[0] = alignbit16(o[0], lb[cur][3]);
+        fm[1] = alignbit16(o[1], o[0]);
+        fm[2] = alignbit16(o[2], o[1]);
+        fm[3] = alignbit16(o[3], o[2]);
+        fp[0] = fm[1];
+        fp[1] = fm[2];
+        fp[2] = fm[3];
+        fp[3] = alignbit16(rb[cur][0], o[3]);
+      } else if (DIL == 2) {                               // two pixels = one dword
+        fm = u32x4{lb[cur][3], o[0], o[1], o[2]};
+        fp = u32x4{o[1], o[2], o[3], rb[cur][0]};
+      } else if (DIL == 4) {
+        fm = u32x4{lb[cur][2], lb[cur][3], o[0], o[1]};
+        fp = u32x4{o[2], o[3], rb[cur][0], rb[cur][1]};
+      } else {                                             // 8 / 16 pixels = one / two whole groups
+        fm = lb[cur];
+        fp = rb[cur];
+      }
       // products of weight >= 2^-17: (A piece, B piece) in {(l,h),(m,h),(h,h),(m,m),(h,m),(h,l)}
 #pragma unroll
       for (int pa = 2; pa >= 0; --pa) {
@@ -254,16 +280,19 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     long t = col;
     const int chunk = (int)(t % a.nchunks_y);
     t /= a.nchunks_y;
+    const int res = (int)(t % DIL);
+    t /= DIL;
     const int strip = (int)(t % a.nstrips);
     const int b = (int)(t / a.nstrips);
     const int c0 = strip * KG * 8;
+    const int hk = (a.H - res + DIL - 1) / DIL;              // rows of this residue walk
     const int ya = chunk * a.rows_per_chunk;
-    const int yb = min(a.H, ya + a.rows_per_chunk);
+    const int yb = min(hk, ya + a.rows_per_chunk);
     // prologue: x rows ya-1 .. ya+R and the first gy unit
     __syncthreads();
     for (int r0 = ya - 1; r0 <= ya + R; r0 += R) {
       const bool first = r0 == ya - 1;
-      issue(b, c0, r0, true, ya, first);
+      issue(b, c0, res, r0, true, ya, first);
       publish(r0, true, 0, first);
     }
     __syncthreads();
@@ -271,7 +300,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     for (int y = ya; y < yb; y += R) {
       const bool more = y + R < yb;
       // next unit: x rows y+R+1 .. y+2R (rows up to y+R were staged already), gy rows y+R .. y+2R-1
-      if (more) issue(b, c0, y + R + 1, true, y + R, true);
+      if (more) issue(b, c0, res, y + R + 1, true, y + R, true);
       __builtin_amdgcn_sched_barrier(0);
       compute(y, gbuf);
       __builtin_amdgcn_sched_barrier(0);
@@ -342,15 +371,16 @@ int cu_count() {
   return g_cu_count;
 }
 
-template <int MW, int NW, int KG, int R, int KW = 1>
+template <int MW, int NW, int KG, int R, int KW = 1, int DIL = 1>
 int launch_wx3(WX3Args a, hipStream_t st) {
-  constexpr int RING = 2 * R + 2, XG = KG + 2;
+  constexpr int RING = 2 * R + 2, XG = KG + 2 * (DIL > 8 ? DIL / 8 : 1);
   constexpr size_t lds_stage = 16 * (3 * (size_t)(32 * NW) * (RING * XG + 1) + 3 * (size_t)(32 * MW) * (2 * R * KG + 1));
   constexpr size_t lds_red = KW > 1 ? (size_t)(KW / 2) * MW * NW * 144 * 64 * 4 : 0;
   constexpr size_t lds_bytes = lds_stage > lds_red ? lds_stage : lds_red;
+  static_assert(lds_bytes <= 160 * 1024, "unit does not fit the 160 KiB LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e0 = hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<MW, NW, KG, R, KW>,
+    hipError_t e0 = hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<MW, NW, KG, R, KW, DIL>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e0 != hipSuccess) return (int)e0;
     attr_set = true;
@@ -359,19 +389,20 @@ int launch_wx3(WX3Args a, hipStream_t st) {
   const int gy_ = irr_cdiv(a.Cin, 32 * NW), gz_ = irr_cdiv(a.Cout, 32 * MW);
   // one block per CU (LDS); about two rounds of blocks over the chip, each block walking >= 1 column
   const long want = 2L * cu_count() / ((long)gy_ * gz_) > 0 ? 2L * cu_count() / ((long)gy_ * gz_) : 1;
-  int rows = a.H;                                          // split columns vertically only when there are too few of them
+  const int hk = (a.H + DIL - 1) / DIL;                     // rows of the longest residue walk
+  int rows = hk;                                           // split columns vertically only when there are too few of them
   a.nchunks_y = 1;
-  while ((long)a.B * a.nstrips * a.nchunks_y < want && rows > 8 * R) {
+  while ((long)a.B * a.nstrips * DIL * a.nchunks_y < want && rows > 8 * R) {
     a.nchunks_y *= 2;
-    rows = ((a.H + a.nchunks_y - 1) / a.nchunks_y + R - 1) / R * R;
+    rows = ((hk + a.nchunks_y - 1) / a.nchunks_y + R - 1) / R * R;
   }
   a.rows_per_chunk = rows;
-  a.nchunks_y = (a.H + rows - 1) / rows;
-  a.ncols = (long)a.B * a.nstrips * a.nchunks_y;
+  a.nchunks_y = (hk + rows - 1) / rows;
+  a.ncols = (long)a.B * a.nstrips * DIL * a.nchunks_y;
   a.cols_per_block = (int)((a.ncols + want - 1) / want);
   if (a.cols_per_block < 1) a.cols_per_block = 1;
   dim3 grid(irr_cdiv(a.ncols, a.cols_per_block), gy_, gz_);
-  hipLaunchKernelGGL((conv_wgrad_x3_kernel<MW, NW, KG, R, KW>), grid, dim3(MW * NW * KW * 64), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_wgrad_x3_kernel<MW, NW, KG, R, KW, DIL>), grid, dim3(MW * NW * KW * 64), lds_bytes, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -415,8 +446,19 @@ __global__ __launch_bounds__(256) void wx3_bias_kernel(const float* __restrict__
   if (threadIdx.x == 0) unsafeAtomicAdd(gbias + c, alpha * (red[0] + red[1] + red[2] + red[3]));
 }
 
+// dilated layers: only the block shapes the context networks need (128 -> 128 d2/d4, 128 -> 96 d8, 96 -> 64 d16)
+static bool dil_ok(int Cout, int W, int dil) {
+  const int cot = (Cout + 31) / 32, kg = pick_kg(W);
+  if (dil == 2 || dil == 4) return cot == 4;
+  if (dil == 8) return cot == 3;
+  if (dil == 16) return cot == 2 && kg != 1;               // (the (1,4) unit with two margin groups exceeds the LDS)
+  return false;
+}
+
 extern "C" int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil) {
-  if (k != 3 || stride != 1 || dil != 1 || B <= 0) return 0;
+  if (k != 3 || stride != 1 || B <= 0) return 0;
+  if (dil != 1 && !(W % 8 == 0 && W >= 32 && Cin >= 64 && dil_ok(Cout, W, dil))) return 0;
+  if (dil != 1) return 5000 + dil;
   if (W % 8 || W < 32 || H < 8 || Cin < 16) return 0;
   if (Cout <= 32 && Cin < 64 && (Cin > 32 || W % 32)) return 0;            // (32 -> 32 layers: K split over 8 wave groups)
   if ((long)B * H * W < 100000 && irr_conv_x3_set_min_blocks(-1) > 0) return 0;   // small levels stay on the fp32 kernels
@@ -425,6 +467,47 @@ extern "C" int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Co
   if (cot == 1 && Cin <= 32) return 1144;                                  // <1,1,4,4,KW=8>
   const int mw = cot == 1 ? 8 : cot == 2 ? 2 : cot == 3 ? 3 : 4;            // 8: operand roles swapped (see irr_conv2d_wgrad_x3)
   return mw * 100 + kg * 10 + (4 / kg);
+}
+
+template <int MW, int DIL>
+static int launch_dil(const WX3Args& a, int kg, hipStream_t st) {
+  if (kg == 4) return launch_wx3<MW, 2, 4, 1, 1, DIL>(a, st);
+  if (kg == 2) return launch_wx3<MW, 2, 2, 2, 1, DIL>(a, st);
+  if constexpr (DIL <= 8) return launch_wx3<MW, 2, 1, 4, 1, DIL>(a, st);
+  return IRR_EINVAL;
+}
+
+extern "C" int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
+                                       int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs, void* stream) {
+  if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (W % 8) || !dil_ok(Cout, W, dil)) return IRR_EINVAL;
+  const long n = (long)Cout * Cin * 9;
+  hipStream_t st = (hipStream_t)stream;
+  IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, st));
+  WX3Args a;
+  a.ws = ws; a.gbias = gbias; a.alpha = alpha;
+  a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.x_bs = x_bs; a.gy_bs = gy_bs;
+  const long lim = (1L << 29) - 64;
+  const long bsmax = x_bs > gy_bs ? x_bs : gy_bs;
+  long per = bsmax > 0 ? (lim - (long)(Cin > Cout ? Cin : Cout) * H * W) / bsmax : B;
+  if (per < 1) return IRR_EINVAL;
+  if (per > B) per = B;
+  const int kg = pick_kg(W);
+  for (int b0 = 0; b0 < B; b0 += (int)per) {
+    a.B = (B - b0) < per ? (B - b0) : (int)per;
+    a.x = x + (long)b0 * x_bs;
+    a.gy = gy + (long)b0 * gy_bs;
+    int rc;
+    switch (dil) {
+      case 2: rc = launch_dil<4, 2>(a, kg, st); break;
+      case 4: rc = launch_dil<4, 4>(a, kg, st); break;
+      case 8: rc = launch_dil<3, 8>(a, kg, st); break;
+      default: rc = launch_dil<2, 16>(a, kg, st); break;
+    }
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(wgrad_unpack_x3_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, st, ws, gw, Cin, Cout, 0, n);
+  IRR_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,

@@ -287,3 +287,25 @@ def test_conv_smallco_dgrad_accumulate_mask(cout, dil):
     want[:, :cin] += ref
     want[:, :11] *= torch.where(msk[:, :11] > 0, 1.0, 0.1).double()
     np.testing.assert_allclose(G.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+
+
+WX3_DIL_CASES = [(128, 128, 1, 24, 32, 2), (128, 128, 2, 19, 48, 4), (128, 96, 1, 40, 56, 8), (96, 64, 1, 50, 48, 16),
+                 (128, 128, 1, 20, 56, 2), (128, 128, 1, 33, 64, 4), (128, 96, 2, 24, 64, 8), (96, 64, 2, 40, 64, 16)]
+
+
+@pytest.mark.parametrize("case", WX3_DIL_CASES, ids=[f"{c[0]}to{c[1]}d{c[5]}_{c[3]}x{c[4]}" for c in WX3_DIL_CASES])
+def test_conv_wgrad_x3_dilated(case, x3_everywhere):
+    """The dilated context-network layers on conv_wgrad_x3_kernel<..., DIL> (row-residue walk, dword / group shifted taps)."""
+    from irr_amd import conv as C, hip
+    cin, cout, B, H, W, dil = case
+    g = torch.Generator().manual_seed(cin + cout + dil)
+    x = torch.randn(B, cin, H, W, generator=g)
+    gy = torch.randn(B, cout, H, W, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), gy.double(), padding=dil, dilation=dil)
+    bref = gy.double().sum(dim=(0, 2, 3))
+    assert hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, 3, 1, dil) == 5000 + dil
+    gw = torch.zeros(cout, cin, 3, 3, device="cuda")
+    gb = torch.zeros(cout, device="cuda")
+    C.conv_wgrad(x.cuda(), gy.cuda(), (cout, cin, 3, 3), 1, dil, gw=gw, gbias=gb)
+    assert (gw.cpu().double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+    assert (gb.cpu().double() - bref).abs().max().item() <= 3e-6 * bref.abs().max().item()
