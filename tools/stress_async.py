@@ -40,7 +40,10 @@ def grads(async_lane):
             arena.disable_async_wgrad()
 
 
+m.branch_streams = False
 ref = grads(False)
+m.branch_streams = os.environ.get("IRR_BRANCH_STREAMS", "0") != "0"
+print("branch streams:", m.branch_streams)
 for mode in (False, True):
     bad = {}
     for it in range(N):
