@@ -148,8 +148,9 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       const int ci = ci0 + xu_ci[r];
       const bool ok = with_x && xu_ci[r] >= 0 && ci < a.Cin && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
       const uint32_t vo = ok ? (uint32_t)(((long)b * a.x_bs + (long)ci * hw + (long)yy * a.W + xx) * 4) : OOB;
+      // (W % 4 == 0: a group may straddle the end of the row -- its second half then reads zeros)
       xraw[r][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)vo, 0, 0));
-      xraw[r][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(vo + 16), 0, 0));
+      xraw[r][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)((ok && xx + 4 < a.W) ? vo + 16 : OOB), 0, 0));
     }
 #pragma unroll
     for (int r = 0; r < GR; ++r) {
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       const bool ok = with_g && gu_co[r] >= 0 && co < a.Cout && yy >= 0 && yy < a.H && xx < a.W;
       const uint32_t vo = ok ? (uint32_t)(((long)b * a.gy_bs + (long)co * hw + (long)yy * a.W + xx) * 4) : OOB;
       graw[r][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)vo, 0, 0));
-      graw[r][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)(vo + 16), 0, 0));
+      graw[r][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)((ok && xx + 4 < a.W) ? vo + 16 : OOB), 0, 0));
     }
   };
   // split the loaded units and publish them: x rows [row0, row0+R) into their ring slots, gy rows into unit buffer gbuf
@@ -409,7 +410,7 @@ int launch_wx3(WX3Args a, hipStream_t st) {
 
 // (KG, R) by image width: strips of KG groups must tile the row without waste
 static int pick_kg(int W) {
-  const int groups = W / 8;
+  const int groups = (W + 7) / 8;                          // W % 8 == 4: the last group of a row is half empty
   if (groups % 4 == 0) return 4;
   if (groups % 2 == 0) return 2;
   return 1;
@@ -458,10 +459,11 @@ static bool dil_ok(int Cout, int W, int dil) {
 extern "C" int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil) {
   if (k != 3 || stride != 1 || B <= 0) return 0;
   if (dil != 1 && !(W % 8 == 0 && W >= 32 && Cin >= 64 && dil_ok(Cout, W, dil))) return 0;
+  if (W % 4) return 0;
   if (dil != 1) return 5000 + dil;
-  if (W % 8 || W < 32 || H < 8 || Cin < 16) return 0;
+  if (W < 24 || H < 8 || Cin < 16) return 0;
   if (Cout <= 32 && Cin < 64 && (Cin > 32 || W % 32)) return 0;            // (32 -> 32 layers: K split over 8 wave groups)
-  if ((long)B * H * W < 100000 && irr_conv_x3_set_min_blocks(-1) > 0) return 0;   // small levels stay on the fp32 kernels
+  if ((long)B * H * W < 40000 && irr_conv_x3_set_min_blocks(-1) > 0) return 0;    // small levels stay on the fp32 kernels
   const int kg = pick_kg(W);
   const int cot = (Cout + 31) / 32;
   if (cot == 1 && Cin <= 32) return 1144;                                  // <1,1,4,4,KW=8>
@@ -512,7 +514,7 @@ extern "C" int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* g
 
 extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
                                    int Cin, int H, int W, int Cout, long x_bs, long gy_bs, void* stream) {
-  if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (W % 8)) return IRR_EINVAL;
+  if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (W % 4)) return IRR_EINVAL;
   const long n = (long)Cout * Cin * 9;
   hipStream_t st = (hipStream_t)stream;
   IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, st));
