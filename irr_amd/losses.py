@@ -140,14 +140,26 @@ class MultiScaleEPE_PWC_Bi_Occ_upsample(nn.Module):
             div = float(self._args.model_div_flow)
             t_flo = (target_dict["target1"], target_dict["target2"])           # div_flow folded into the pooling kernel
             t_occ = (target_dict["target_occ1"], target_dict["target_occ2"])
+            # target pyramid: every level is pooled from the next finer one that was already built (a mean of equal-sized
+            # block means is the block mean), so the full-resolution targets are read once instead of once per level
+            sizes = sorted({(o.shape[2], o.shape[3]) for lvl in list(output_flo) + list(output_occ) for o in lvl}, reverse=True)
             pooled = {}
+            for kind, srcs, scale in (("f", t_flo, div), ("o", t_occ, 1.0)):
+                for idx in (0, 1):
+                    cur, cur_hw = srcs[idx], tuple(srcs[idx].shape[2:])
+                    first = True
+                    for hw_ in sizes:
+                        if hw_ == cur_hw and first and scale == 1.0:
+                            pooled[(kind, idx) + hw_] = cur
+                            continue
+                        if cur_hw[0] % hw_[0] or cur_hw[1] % hw_[1] or cur_hw[0] // hw_[0] != cur_hw[1] // hw_[1]:
+                            cur, cur_hw, first = srcs[idx], tuple(srcs[idx].shape[2:]), True       # not nested: pool from the source
+                        cur = avg_pool_to(cur, hw_[0], hw_[1], scale if first else 1.0)
+                        cur_hw, first = hw_, False
+                        pooled[(kind, idx) + hw_] = cur
 
             def pool(kind, idx, like):
-                key = (kind, idx, like.shape[2], like.shape[3])
-                if key not in pooled:
-                    src = t_flo[idx] if kind == "f" else t_occ[idx]
-                    pooled[key] = avg_pool_to(src, like.shape[2], like.shape[3], div if kind == "f" else 1.0)
-                return pooled[key]
+                return pooled[(kind, idx, like.shape[2], like.shape[3])]
 
             flow_terms, occ_terms = [], []
             for ii, output_ii in enumerate(output_flo):
