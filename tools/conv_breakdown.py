@@ -20,7 +20,7 @@ step(batch)
 recs = []
 orig = hip.call
 def traced(name, *a):
-    if name in ("irr_conv2d_fwd_f32", "irr_conv2d_wgrad_f32", "irr_conv2d_fwd_x3", "irr_conv2d_wgrad_x3"):
+    if name in ("irr_conv2d_fwd_f32", "irr_conv2d_wgrad_f32", "irr_conv2d_fwd_x3", "irr_conv2d_wgrad_x3", "irr_conv2d_wgrad_x3_dil"):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record(); orig(name, *a); e.record()
         if name == "irr_conv2d_fwd_x3":
@@ -31,6 +31,10 @@ def traced(name, *a):
             Bn, cin, H, W, cout, oh, ow, k = a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12]
             key = ("fwd/dgrad", cin, cout, oh, ow, k, a[14])
             fl = 2.0 * Bn * oh * ow * cout * cin * k * k
+        elif name == "irr_conv2d_wgrad_x3_dil":  # (x, gy, gw, ws, gbias, alpha, B, Cin, H, W, Cout, dil, ...)
+            Bn, cin, H, W, cout, dil = a[6], a[7], a[8], a[9], a[10], a[11]
+            key = ("x3 wgrad", cin, cout, H, W, 3, dil)
+            fl = 2.0 * Bn * H * W * cout * cin * 9
         elif name == "irr_conv2d_wgrad_x3":      # (x, gy, gw, ws, gbias, alpha, B, Cin, H, W, Cout, ...)
             Bn, cin, H, W, cout = a[6], a[7], a[8], a[9], a[10]
             key = ("x3 wgrad", cin, cout, H, W, 3, 1)
