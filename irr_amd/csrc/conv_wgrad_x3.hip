@@ -461,7 +461,7 @@ extern "C" int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Co
   if (dil != 1 && !(W % 8 == 0 && W >= 32 && Cin >= 64 && dil_ok(Cout, W, dil))) return 0;
   if (W % 4) return 0;
   if (dil != 1) return 5000 + dil;
-  if (W < 24 || H < 8 || Cin < 16) return 0;
+  if (W < 24 || H < 8 || Cin < 8) return 0;
   if (Cout <= 32 && Cin < 64 && (Cin > 32 || W % 32)) return 0;            // (32 -> 32 layers: K split over 8 wave groups)
   if ((long)B * H * W < 40000 && irr_conv_x3_set_min_blocks(-1) > 0) return 0;    // small levels stay on the fp32 kernels
   const int kg = pick_kg(W);

@@ -208,6 +208,7 @@ WX3_CASES = [  # (Cin, Cout, B, H, W): every block shape (MW=4/3/2 and the swapp
     (565, 128, 1, 8, 112), (467, 64, 1, 16, 48), (64, 64, 2, 12, 56), (531, 32, 1, 16, 48), (64, 9, 2, 12, 56), (300, 32, 1, 8, 64),
     (32, 32, 2, 24, 64), (32, 9, 1, 16, 96), (24, 32, 2, 20, 32),          # one (co, ci) tile: pixels split over eight wave groups
     (243, 128, 2, 24, 28), (64, 64, 1, 12, 44), (371, 96, 1, 10, 36), (531, 32, 1, 24, 28),   # W % 8 == 4: half-empty last group
+    (11, 32, 2, 16, 64),                                                                    # OccUpsampleNetwork.init_conv
 ]
 
 

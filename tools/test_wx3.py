@@ -10,7 +10,7 @@ from tools.test_x3 import timeit  # noqa: E402
 
 ACC = [  # cin, cout, B, H, W
     (115, 128, 2, 24, 32), (40, 128, 1, 16, 48), (371, 96, 1, 12, 56), (64, 128, 2, 8, 40), (35, 96, 1, 20, 64), (565, 128, 1, 8, 112),
-    (128, 128, 2, 16, 16), (467, 64, 1, 16, 48), (64, 64, 2, 12, 56), (531, 32, 1, 16, 48), (64, 9, 2, 12, 56), (300, 32, 1, 8, 64), (32, 32, 2, 24, 64), (32, 9, 1, 16, 96), (24, 32, 2, 20, 32), (243, 128, 2, 24, 28), (64, 64, 1, 12, 44), (371, 96, 1, 10, 36), (531, 32, 1, 24, 28),
+    (128, 128, 2, 16, 16), (467, 64, 1, 16, 48), (64, 64, 2, 12, 56), (531, 32, 1, 16, 48), (64, 9, 2, 12, 56), (300, 32, 1, 8, 64), (32, 32, 2, 24, 64), (32, 9, 1, 16, 96), (24, 32, 2, 20, 32), (243, 128, 2, 24, 28), (11, 32, 2, 16, 64), (64, 64, 1, 12, 44), (371, 96, 1, 10, 36), (531, 32, 1, 24, 28),
 ]
 ACC_DIL = [(128, 128, 1, 24, 32, 2), (128, 128, 2, 19, 48, 4), (128, 96, 1, 40, 56, 8), (96, 64, 1, 50, 48, 16), (128, 128, 1, 20, 56, 2),
            (128, 128, 1, 33, 64, 4), (128, 96, 2, 24, 64, 8), (96, 64, 2, 40, 64, 16)]
@@ -20,7 +20,7 @@ PERF = [("ctx.conv0 L4", 565, 128, 64, 96, 112), ("dense.conv1 L4", 115, 128, 64
         ("refine 128->128 L4", 128, 128, 64, 96, 112), ("dense.conv2 L3", 243, 128, 64, 48, 56), ("ctx.conv0 L3", 565, 128, 64, 48, 56),
         ("128->128 448x1024 L4", 128, 128, 16, 112, 256), ("dense.conv4 L4", 467, 64, 64, 96, 112), ("refine 128->64 L4", 128, 64, 64, 96, 112),
         ("refine 64->64 L4", 64, 64, 64, 96, 112), ("dense.conv5 L4", 531, 32, 64, 96, 112), ("refine 64->32 L4", 64, 32, 64, 96, 112),
-        ("dense.conv5 L3", 531, 32, 64, 48, 56), ("occup 32->32 L6", 32, 32, 64, 384, 448), ("occup 32->32 L5", 32, 32, 64, 192, 224), ("dense.conv2 L2", 243, 128, 64, 24, 28), ("ctx.conv0 L2", 565, 128, 64, 24, 28), ("dense.conv4 L2", 467, 64, 64, 24, 28)]
+        ("dense.conv5 L3", 531, 32, 64, 48, 56), ("occup 32->32 L6", 32, 32, 64, 384, 448), ("occup 32->32 L5", 32, 32, 64, 192, 224), ("occup init 11->32 L6", 11, 32, 64, 384, 448), ("dense.conv2 L2", 243, 128, 64, 24, 28), ("ctx.conv0 L2", 565, 128, 64, 24, 28), ("dense.conv4 L2", 467, 64, 64, 24, 28)]
 
 
 def main():
