@@ -4,6 +4,7 @@
 // observation (v)); here every lane owns one output pixel (coalesced along x), weights are wave-uniform scalar
 // loads, and the 3x3 neighbourhood reads hit L1.  Same epilogue contract as irr_conv2d_fwd_f32.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -127,6 +128,162 @@ __global__ __launch_bounds__(256) void conv_smallco_wgrad_kernel(const float* __
   }
 }
 
+// ---- 4-pixel variants (3x3, dilation 1, W % 4 == 0): a lane owns four consecutive pixels of a row and slides the 3x3
+// window over a 3 x 6 register patch (one 16-B load + two edge dwords per row), i.e. 2.25 load instructions per pixel and
+// channel instead of 9: these layers stream over 562/563-channel buffers and were instruction-bound, not HBM-bound.
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void load_patch6(const float* __restrict__ row, bool rok, int x0, int W, float* v) {
+  // v[0..5] = row[x0-1 .. x0+4], zeros outside the row / for an invalid row
+  if (rok) {
+    const f32x4s m = *(const f32x4s*)(row + x0);
+    v[1] = m[0]; v[2] = m[1]; v[3] = m[2]; v[4] = m[3];
+    v[0] = x0 > 0 ? row[x0 - 1] : 0.f;
+    v[5] = x0 + 4 < W ? row[x0 + 4] : 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = 0.f;
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(64) void conv_smallco_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, const float* __restrict__ res,
+                                                               float* __restrict__ y, int Cin, int H, int W, long x_bs, long y_bs,
+                                                               long res_bs, int lrelu, float alpha, int accumulate) {
+  const long hw = (long)H * W;
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;          // quad index
+  if (q * 4 >= hw) return;
+  const int b = blockIdx.y;
+  const long p = q * 4;
+  const int oy = (int)(p / W), x0 = (int)(p - (long)oy * W);
+  float acc[NC][4];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[c][i] = 0.f;
+  const float* xb = x + (long)b * x_bs;
+#pragma unroll 2
+  for (int ci = 0; ci < Cin; ++ci) {
+    const float* xc = xb + (long)ci * hw;
+    float v[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = oy - 1 + r;
+      load_patch6(xc + (long)iy * W, iy >= 0 && iy < H, x0, W, v[r]);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float* wc = w + ((long)c * Cin + ci) * 9;                   // wave-uniform -> scalar loads
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const float ww = wc[r * 3 + t];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[c][i] = fmaf(ww, v[r][i + t], acc[c][i]);
+        }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float bsv = bias ? bias[c] : 0.f;
+    float* dst = y + (long)b * y_bs + (long)c * hw + p;
+    f32x4s o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float vv = acc[c][i] + bsv;
+      if (lrelu) vv = irr_lrelu(vv);
+      o[i] = vv;
+    }
+    if (res) {
+      const f32x4s rr = *(const f32x4s*)(res + (long)b * res_bs + (long)c * hw + p);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = rr[i] + alpha * o[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] *= alpha;
+    }
+    if (accumulate) {
+      const f32x4s d0 = *(const f32x4s*)dst;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] += d0[i];
+    }
+    *(f32x4s*)dst = o;
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void conv_smallco_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                 float* __restrict__ ws, float* __restrict__ gbias, float alpha,
+                                                                 int Cin, int H, int W, long x_bs, long gy_bs,
+                                                                 int quads_per_block) {
+  const long hw = (long)H * W;
+  const long nq = hw / 4;
+  const int ci = blockIdx.y, b = blockIdx.z;
+  const long q0 = (long)blockIdx.x * quads_per_block;
+  const long q1 = min(nq, q0 + quads_per_block);
+  const float* xc = x + (long)b * x_bs + (long)ci * hw;
+  const float* gb = gy + (long)b * gy_bs;
+  float acc[NC][9];
+  float bsum[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    bsum[c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+  }
+  for (long q = q0 + threadIdx.x; q < q1; q += 256) {
+    const long p = q * 4;
+    const int oy = (int)(p / W), x0 = (int)(p - (long)oy * W);
+    float g[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const f32x4s gg = *(const f32x4s*)(gb + (long)c * hw + p);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { g[c][i] = gg[i]; bsum[c] += gg[i]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = oy - 1 + r;
+      float v[6];
+      load_patch6(xc + (long)iy * W, iy >= 0 && iy < H, x0, W, v);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[c][r * 3 + t] = fmaf(g[c][i], v[i + t], acc[c][r * 3 + t]);
+    }
+  }
+  __shared__ float red[4][NC * 9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (gbias && ci == 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float sb = bsum[c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sb += __shfl_down(sb, o, 64);
+      if (lane == 0) unsafeAtomicAdd(gbias + c, alpha * sb);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float sv = acc[c][t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sv += __shfl_down(sv, o, 64);
+      if (lane == 0) red[wv][c * 9 + t] = sv;
+    }
+  __syncthreads();
+  if (threadIdx.x < NC * 9) {
+    const int c = threadIdx.x / 9, t = threadIdx.x - c * 9;
+    const float sv = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    unsafeAtomicAdd(ws + ((long)c * 9 + t) * Cin + ci, alpha * sv);
+  }
+}
+
 __global__ __launch_bounds__(256) void smallco_unpack_kernel(const float* __restrict__ ws, float* __restrict__ gw, int Cin,
                                                             int KK, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,6 +391,18 @@ extern "C" int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const 
                                           long res_bs, int lrelu, float alpha, int accumulate, void* stream) {
   if (!x || !w || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 1 || Cout > 4 || B > 65535) return IRR_EINVAL;
   if ((k != 1 && k != 3) || dil < 1) return IRR_EINVAL;
+  if (k == 3 && dil == 1 && (W & 3) == 0 && Cout <= 2 && ((x_bs | y_bs | res_bs) & 3) == 0 && !getenv("IRR_SMALLCO_SCALAR")) {
+    dim3 grid4(irr_cdiv((long)H * W / 4, 64), B, 1);             // one wave per block: enough blocks to hide the channel-loop latency
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout == 1)
+      hipLaunchKernelGGL((conv_smallco_fwd4_kernel<1>), grid4, dim3(64), 0, st, x, w, bias, res, y, Cin, H, W, x_bs, y_bs, res_bs,
+                         lrelu, alpha, accumulate);
+    else
+      hipLaunchKernelGGL((conv_smallco_fwd4_kernel<2>), grid4, dim3(64), 0, st, x, w, bias, res, y, Cin, H, W, x_bs, y_bs, res_bs,
+                         lrelu, alpha, accumulate);
+    IRR_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid(irr_cdiv((long)H * W, 256), B, 1);
   return k == 3 ? fwd_dispatch<3>(Cout, grid, (hipStream_t)stream, x, w, bias, res, y, B, Cin, H, W, dil, x_bs, y_bs, res_bs,
                                   lrelu, alpha, accumulate)
@@ -255,6 +424,18 @@ extern "C" int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, flo
   if (chunks < 1) chunks = 1;
   long ppb = (hw + chunks - 1) / chunks;
   if (ppb < 1024) ppb = 1024;
+  if (k == 3 && dil == 1 && (W & 3) == 0 && Cout <= 2 && ((x_bs | gy_bs) & 3) == 0 && !getenv("IRR_SMALLCO_SCALAR")) {
+    const long qpb = (ppb + 3) / 4;
+    dim3 grid4(irr_cdiv(hw / 4, qpb), Cin, B);
+    if (Cout == 1)
+      hipLaunchKernelGGL((conv_smallco_wgrad4_kernel<1>), grid4, dim3(256), 0, st, x, gy, ws, gbias, alpha, Cin, H, W, x_bs, gy_bs, (int)qpb);
+    else
+      hipLaunchKernelGGL((conv_smallco_wgrad4_kernel<2>), grid4, dim3(256), 0, st, x, gy, ws, gbias, alpha, Cin, H, W, x_bs, gy_bs, (int)qpb);
+    IRR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(smallco_unpack_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, st, ws, gw, Cin, 9, n);
+    IRR_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid(irr_cdiv(hw, ppb), Cin, B);
 #define IRR_SMALL_WG(N, K)                                                                                        \
   hipLaunchKernelGGL((conv_smallco_wgrad_kernel<N, K>), grid, dim3(256), 0, st, x, gy, ws, gbias, alpha, B, Cin, H, W, \

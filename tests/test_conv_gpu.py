@@ -311,3 +311,34 @@ def test_conv_wgrad_x3_dilated(case, x3_everywhere):
     C.conv_wgrad(x.cuda(), gy.cuda(), (cout, cin, 3, 3), 1, dil, gw=gw, gbias=gb)
     assert (gw.cpu().double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
     assert (gb.cpu().double() - bref).abs().max().item() <= 3e-6 * bref.abs().max().item()
+
+
+@pytest.mark.parametrize("cout", [1, 2])
+def test_conv_smallco_quad_kernels(cout):
+    """4-pixel small-Cout kernels (W % 4 == 0): forward with bias / residual / alpha / accumulate on channel-slice views, and
+    the weight + bias gradient, against torch on the host."""
+    from irr_amd import conv as C
+    g = torch.Generator().manual_seed(70 + cout)
+    B, cin, H, W = 2, 45, 14, 36
+    big = torch.randn(B, cin + 7, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, H, W, generator=g)
+    x = big[:, 7:]
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xd = big.cuda()[:, 7:]
+    y = C.conv_forward(xd, w.cuda(), b.cuda(), 1, 1, False, res=res.cuda(), alpha=0.5)
+    np.testing.assert_allclose(y.cpu().numpy(), (res.double() + 0.5 * ref).numpy(), rtol=1e-5, atol=1e-5)
+    y = C.conv_forward(xd, w.cuda(), b.cuda(), 1, 1, True)
+    np.testing.assert_allclose(y.cpu().numpy(), F.leaky_relu(ref, 0.1).numpy(), rtol=1e-5, atol=1e-5)
+    base = torch.randn(B, cout, H, W, generator=g)
+    acc = base.clone().cuda()
+    C.conv_forward(xd, w.cuda(), None, 1, 1, False, out=acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), (base.double() + F.conv2d(x.double(), w.double(), None, padding=1)).numpy(), rtol=1e-5, atol=1e-5)
+    gy = torch.randn(B, cout, H, W, generator=g)
+    gw = torch.zeros(cout, cin, 3, 3, device="cuda")
+    gb = torch.zeros(cout, device="cuda")
+    C.conv_wgrad(xd, gy.cuda(), (cout, cin, 3, 3), 1, 1, gw=gw, gbias=gb, alpha=2.0)
+    wref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), gy.double(), padding=1)
+    np.testing.assert_allclose(gw.cpu().numpy(), 2 * wref.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gb.cpu().numpy(), 2 * gy.double().sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-4)
