@@ -699,9 +699,13 @@ extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bi
       IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       attr_set = true;
     }
-    const long lim = (1L << 29) - (long)(Cin + 16) * H * W - 64;
+    // every operand is addressed through 32-bit byte voffsets below the 2 GiB out-of-range marker
+    long bsmax = x_bs > y_bs ? x_bs : y_bs;
+    if (res && res_bs > bsmax) bsmax = res_bs;
+    if (mask && mask_bs > bsmax) bsmax = mask_bs;
+    const long lim = (1L << 29) - (long)(Cin + 48) * H * W - 64;
     if (lim <= 0) return IRR_EINVAL;
-    long per = x_bs > 0 ? lim / x_bs : B;
+    long per = bsmax > 0 ? lim / bsmax : B;
     if (per < 1) per = 1;
     if (per > B) per = B;
     for (int b0 = 0; b0 < B; b0 += (int)per) {
