@@ -19,6 +19,10 @@
 //     the gy stagers (fixed channel per thread) and added once per block.
 #include "common.h"
 
+#ifndef WX3_ABL
+#define WX3_ABL 0      // ablation builds (timing only): 1 = no operand split (VALU) in the staging path
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -171,7 +175,11 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
         if (xu_ci[r] < 0) continue;
         float v[8] = {xraw[r][0][0], xraw[r][0][1], xraw[r][0][2], xraw[r][0][3], xraw[r][1][0], xraw[r][1][1], xraw[r][1][2], xraw[r][1][3]};
         u32x4 h, m, l;
+#if WX3_ABL == 1
+        h = __builtin_bit_cast(u32x4, xraw[r][0]); m = __builtin_bit_cast(u32x4, xraw[r][1]); l = h; (void)v;
+#else
         split8(v, h, m, l);
+#endif
         const int slot = (row0 + xu_rr[r] + RING) % RING;          // rows >= -1
         const int idx = xu_ci[r] * XPITCH + slot * XG + xu_grp[r];
         xs[idx] = h;
@@ -186,7 +194,11 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
         float v[8] = {graw[r][0][0], graw[r][0][1], graw[r][0][2], graw[r][0][3], graw[r][1][0], graw[r][1][1], graw[r][1][2], graw[r][1][3]};
         bsum[r] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         u32x4 h, m, l;
+#if WX3_ABL == 1
+        h = __builtin_bit_cast(u32x4, graw[r][0]); m = __builtin_bit_cast(u32x4, graw[r][1]); l = h;
+#else
         split8(v, h, m, l);
+#endif
         const int idx = gu_co[r] * GPITCH + (gbuf * R + gu_rr[r]) * KG + gu_grp[r];
         gs[idx] = h;
         gs[idx + GPLANE] = m;
