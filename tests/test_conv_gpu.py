@@ -342,3 +342,38 @@ def test_conv_smallco_quad_kernels(cout):
     wref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), gy.double(), padding=1)
     np.testing.assert_allclose(gw.cpu().numpy(), 2 * wref.numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(gb.cpu().numpy(), 2 * gy.double().sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_x3_family_baseline_size_properties():
+    """Size-independent properties at BASELINE configs[2] layer sizes (bs32 -> 2B = 64 samples), where a host reference
+    is too slow: (i) weight gradient of a level-4 decoder layer: linear in gy and additive over the batch; (ii) the
+    streaming 32-channel kernel at full resolution: conv(2x) == 2 conv(x) bit for bit, and equal to the fp32-MFMA kernel
+    to fp32 accuracy."""
+    from irr_amd import conv as C, hip
+    C.set_math("x3")
+    torch.manual_seed(1)
+    B, cin, cout, H, W = 64, 128, 128, 96, 112
+    x = torch.randn(B, cin, H, W, device="cuda")
+    gy = torch.randn(B, cout, H, W, device="cuda")
+    assert hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, 3, 1, 1) != 0
+
+    def wg(xx, gg):
+        gw = torch.zeros(cout, cin, 3, 3, device="cuda")
+        C.conv_wgrad(xx, gg, (cout, cin, 3, 3), 1, 1, gw=gw)
+        return gw
+    full = wg(x, gy)
+    scale = full.abs().max().item()
+    assert (wg(x, 2 * gy) - 2 * full).abs().max().item() <= 2e-6 * scale * 2
+    halves = wg(x[:32], gy[:32]) + wg(x[32:], gy[32:])
+    assert (halves - full).abs().max().item() <= 4e-6 * scale
+    del x, gy
+    x = torch.randn(16, 32, 384, 448, device="cuda")
+    w = torch.randn(32, 32, 3, 3, device="cuda") * 0.05
+    assert C.x3_code(16, 32, 384, 448, 32, 3, 1, 1) == 9001
+    y1 = C.conv_forward(x, w, None, 1, 1, False)
+    y2 = C.conv_forward(2 * x, w, None, 1, 1, False)
+    assert torch.equal(2 * y1, y2)
+    C.set_math("f32")
+    yf = C.conv_forward(x, w, None, 1, 1, False)
+    C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
+    assert (y1 - yf).abs().max().item() <= 4e-6 * yf.abs().max().item()
