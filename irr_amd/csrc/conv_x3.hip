@@ -23,6 +23,7 @@
 //     (chunk, tap, piece, co-tile) is exactly the A fragment; prefetched one tap ahead.
 //   * epilogue identical to conv_fwd.hip (bias, LeakyReLU, residual/scale, "+=", LeakyReLU'-mask).
 #include "common.h"
+#include <stdlib.h>
 
 #ifndef X3_ABL
 #define X3_ABL 0     // ablation builds (timing only, results wrong): 1 = no weight loads in the loop, 2 = no LDS reads in the loop,
@@ -612,7 +613,9 @@ static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) 
   } else if (p->ct == 2) {
     p->pg = 2;
     p->plane = 616;
-    ok = pick_tile(H, W, dil, 2, 616, nts78, 2, &p->t);
+    // (measured at 96x112: quarter-size sub-tile sets, 3 blocks per CU, beat NT = 8 by 17-21 % for the 64-channel layers)
+    ok = pick_tile(H, W, dil, 2, 616, nts4, 1, &p->t);
+    if (!ok) ok = pick_tile(H, W, dil, 2, 616, nts78, 2, &p->t);
   } else {
     p->pg = 4;
     p->plane = 616;
@@ -620,14 +623,14 @@ static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) 
   }
   if (!ok) return false;
   p->blocks = (long)B * ((H + p->t.tr - 1) / p->t.tr) * ((W + p->t.tc - 1) / p->t.tc) * ((CoT + p->ct - 1) / p->ct);
-  if (p->blocks < g_min_blocks && p->ct >= 2) {
+  if ((p->blocks < g_min_blocks || getenv("IRR_X3_FORCE_NT4")) && p->ct >= 2) {
     // small pyramid levels: half-size tiles (NT = 4) double the number of blocks
     TileCfg t4;
     const int plane4 = p->ct == 2 ? 616 : 352;
     if (pick_tile(H, W, dil, p->pg, plane4, nts4, 1, &t4)) {
       const long b4 = (long)B * ((H + t4.tr - 1) / t4.tr) * ((W + t4.tc - 1) / t4.tc) * ((CoT + p->ct - 1) / p->ct);
       const double e4 = (double)H * W / ((double)((H + t4.tr - 1) / t4.tr) * ((W + t4.tc - 1) / t4.tc) * t4.tr * t4.tc);
-      if (b4 > p->blocks && e4 >= 0.70) { p->t = t4; p->plane = plane4; p->blocks = b4; }
+      if ((b4 > p->blocks || getenv("IRR_X3_FORCE_NT4")) && e4 >= 0.70) { p->t = t4; p->plane = plane4; p->blocks = b4; }
     }
   }
   // padded work must stay close to the real work, and the launch must fill the chip

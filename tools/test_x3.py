@@ -17,7 +17,7 @@ ACC = [  # cin, cout, dil, B, H, W
 PERF = [  # name, cin, cout, dil, B, H, W
     ("ctx.conv0 L4", 565, 128, 1, 64, 96, 112), ("dense.conv1 L4", 115, 128, 1, 64, 96, 112),
     ("dense.conv3 L4", 371, 96, 1, 64, 96, 112), ("dense.conv5 L4", 531, 32, 1, 64, 96, 112),
-    ("refine 128->64 L4", 128, 64, 1, 64, 96, 112), ("ctx d2 L4", 128, 128, 2, 64, 96, 112), ("ctx d4 L4", 128, 128, 4, 64, 96, 112),
+    ("refine 128->64 L4", 128, 64, 1, 64, 96, 112), ("dense.conv4 L4", 467, 64, 1, 64, 96, 112), ("refine 64->64 L4", 64, 64, 1, 64, 96, 112), ("dense.conv4 L3", 467, 64, 1, 64, 48, 56), ("ctx d2 L4", 128, 128, 2, 64, 96, 112), ("ctx d4 L4", 128, 128, 4, 64, 96, 112),
     ("occup 32->32 L6", 32, 32, 1, 32, 384, 448), ("occup 32->32 L5", 32, 32, 1, 64, 192, 224),
     ("dense.conv2 L3", 243, 128, 1, 64, 48, 56), ("dgrad ctx0 L4", 128, 565, 1, 64, 96, 112),
     ("dense.conv2 L2", 243, 128, 1, 64, 24, 28), ("ctx.conv0 L2", 565, 128, 1, 64, 24, 28), ("dense.conv4 L2", 467, 64, 1, 64, 24, 28), ("refine 32->64 L4", 32, 64, 1, 64, 96, 112),
