@@ -618,8 +618,13 @@ static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) 
     if (!ok) ok = pick_tile(H, W, dil, 2, 616, nts78, 2, &p->t);
   } else {
     p->pg = 4;
-    p->plane = 616;
-    ok = pick_tile(H, W, dil, 4, 616, nts4, 1, &p->t);
+    static const int nts2[1] = {2};
+    p->plane = 352;                                       // 256-pixel tiles, four blocks per CU (+4 ... +18 % over NT = 4)
+    ok = pick_tile(H, W, dil, 4, 352, nts2, 1, &p->t);
+    if (!ok) {
+      p->plane = 616;
+      ok = pick_tile(H, W, dil, 4, 616, nts4, 1, &p->t);
+    }
   }
   if (!ok) return false;
   p->blocks = (long)B * ((H + p->t.tr - 1) / p->t.tr) * ((W + p->t.tc - 1) / p->t.tc) * ((CoT + p->ct - 1) / p->ct);
@@ -760,6 +765,7 @@ extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bi
       case 2282: rc = launch_x3<2, 2, 8, 616>(a, p.t, st); break;
       case 2272: rc = launch_x3<2, 2, 7, 616>(a, p.t, st); break;
       case 1442: rc = launch_x3<1, 4, 4, 616>(a, p.t, st); break;
+      case 1421: rc = launch_x3<1, 4, 2, 352>(a, p.t, st); break;
       case 4141: rc = launch_x3<4, 1, 4, 352>(a, p.t, st); break;
       case 3141: rc = launch_x3<3, 1, 4, 352>(a, p.t, st); break;
       case 2242: rc = launch_x3<2, 2, 4, 616>(a, p.t, st); break;
