@@ -1,4 +1,6 @@
-"""conv() blocks of IRR-PWC on the fp32-MFMA kernels of libirr_hip.so.
+"""conv() blocks of IRR-PWC on the MFMA kernels of libirr_hip.so: the fp32-faithful bf16x3-split family (conv_x3 /
+conv_x3s / conv_wgrad_x3) wherever its ``*_eligible`` predicates accept the problem, the fp32-MFMA family
+elsewhere (``IRR_CONV_MATH=f32`` forces the latter everywhere).
 
 Mirrors the reference helper ``conv(in_planes, out_planes, kernel_size, stride, dilation, isReLU)``
 (models/pwc_modules.py:8-19, models/irr_modules.py:7-18): Conv2d with "same" padding and bias,
