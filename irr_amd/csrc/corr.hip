@@ -13,6 +13,7 @@
 //     all, the channel sum is a private FMA chain; HBM sees f1, f2 once and the output once;
 //   * both gradients are gathers with the same LDS tile (no atomics, deterministic).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -77,6 +78,88 @@ __global__ __launch_bounds__(256) void corr81_fwd_kernel(const float* __restrict
   }
 }
 
+// ---- forward, quad variant (W % 4 == 0) ----------------------------------------------------------------------------
+// The kernel above issues one LDS read per FMA (81 per channel and pixel) and is LDS-bound at ~2 TB/s.  Here a lane owns
+// FOUR consecutive pixels of a row and THREE of the nine vertical displacements (108 accumulators): per channel it reads
+// its f1 quad once and, per vertical displacement, the 12-float window of the staged f2 row as three aligned
+// ds_read_b128 -- 9 LDS instructions per 108 FMAs -- so the VALU, not the LDS, is the limit and the kernel sits close to
+// its HBM time (f1, f2 read once, the 81-plane output written once as 16-B stores).  Block = 16 x 16 pixels = 64 quads x
+// 3 displacement groups = 192 threads; f2 tile rows have a pitch of 48 floats (conflict-free for the 4-row x 4-quad
+// lane groups of ds_read_b128).
+constexpr int QP = 48;            // LDS row pitch (floats) of the quad variant
+constexpr int QC = 8;             // channels per LDS stage
+
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(192) void corr81_fwd4_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                         float* __restrict__ out, int C, int H, int W, long f1_bs,
+                                                         long f2_bs, long out_bs, int fuse_lrelu) {
+  __shared__ __attribute__((aligned(16))) float tile[QC][TP][QP];
+  const int tid = threadIdx.x;
+  const int grp = tid / 64;                       // vertical displacements 3*grp .. 3*grp + 2
+  const int t64 = tid - grp * 64;
+  const int q = t64 & 3, ty = t64 >> 2;           // quad column (4 pixels), tile row
+  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS, b = blockIdx.z;
+  const int x = x0 + 4 * q, y = y0 + ty;
+  const bool inside = (x < W) && (y < H);         // W % 4 == 0: a quad is inside or outside as a whole
+  const long plane = (long)H * W;
+  const float* f1b = f1 + (long)b * f1_bs;
+  const float* f2b = f2 + (long)b * f2_bs;
+
+  float acc[3][4][9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int d = 0; d < 9; ++d) acc[r][i][d] = 0.f;
+
+  for (int c0 = 0; c0 < C; c0 += QC) {
+    __syncthreads();
+    for (int i = tid; i < QC * TP * TP; i += 192) {
+      const int c = i / (TP * TP);
+      const int r = i - c * (TP * TP);
+      const int sy = r / TP, sx = r - sy * TP;
+      const int yy = y0 - HALO + sy, xx = x0 - HALO + sx;
+      float v = 0.f;
+      if (c0 + c < C && yy >= 0 && yy < H && xx >= 0 && xx < W) v = f2b[(long)(c0 + c) * plane + (long)yy * W + xx];
+      tile[c][sy][sx] = v;
+    }
+    __syncthreads();
+    const int cn = min(QC, C - c0);
+    for (int c = 0; c < cn; ++c) {
+      f32x4c a = {0.f, 0.f, 0.f, 0.f};
+      if (inside) a = *(const f32x4c*)(f1b + (long)(c0 + c) * plane + (long)y * W + x);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float* row = &tile[c][ty + 3 * grp + r][4 * q];
+        const f32x4c w0 = *(const f32x4c*)(row), w1 = *(const f32x4c*)(row + 4), w2 = *(const f32x4c*)(row + 8);
+        const float wv[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int d = 0; d < 9; ++d) acc[r][i][d] = fmaf(a[i], wv[i + d], acc[r][i][d]);
+      }
+    }
+  }
+  if (!inside) return;
+  float* o = out + (long)b * out_bs + (long)y * W + x;
+  const float cf = (float)C;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int d = 0; d < 9; ++d) {
+      f32x4c v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float t = acc[r][i][d] / cf;             // mean over channels (torch.mean = sum / C)
+        if (fuse_lrelu) t = irr_lrelu(t);
+        v[i] = t;
+      }
+      *(f32x4c*)(o + (long)((3 * grp + r) * 9 + d) * plane) = v;
+    }
+}
+
 // SECOND == false: g1[c,p] = (1/C) sum_d g[d][p]     * f2[c][p+d]   (tile = f2, shift +d)
 // SECOND == true : g2[c,p] = (1/C) sum_d g[d][p-d]   * f1[c][p-d]   (tile = f1, shift -d)
 template <bool SECOND>
@@ -139,6 +222,12 @@ extern "C" int irr_corr81_fwd_f32(const float* f1, const float* f2, float* out, 
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !f1 || !f2 || !out) return IRR_EINVAL;
   if (B > 65535) return IRR_EINVAL;
   dim3 grid(irr_cdiv(W, TS), irr_cdiv(H, TS), B);
+  if ((W & 3) == 0 && ((f1_bs | out_bs) & 3) == 0 && (((uintptr_t)f1 | (uintptr_t)out) & 15) == 0 && !getenv("IRR_CORR_SCALAR")) {
+    hipLaunchKernelGGL(corr81_fwd4_kernel, grid, dim3(192), 0, (hipStream_t)stream, f1, f2, out, C, H, W, f1_bs, f2_bs,
+                       out_bs, fuse_lrelu);
+    IRR_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(corr81_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, f1, f2, out, C, H, W, f1_bs, f2_bs,
                      out_bs, fuse_lrelu);
   IRR_LAUNCH_CHECK();
