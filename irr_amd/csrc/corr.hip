@@ -23,24 +23,44 @@ constexpr int TP = TS + 2 * HALO; // 24
 constexpr int PITCH = TP + 1;     // 25
 constexpr int CC = 16;            // channels per LDS stage
 
+// Generic tile staging with the loads of a batch issued together (a one-load-per-iteration loop exposes the full memory
+// latency on every element and dominated these kernels).
+template <int NCH, int PITCH_, int NTHR>
+__device__ __forceinline__ void stage_tile_t(float (*tile)[TP][PITCH_], const float* __restrict__ src, long plane,
+                                             int c0, int C, int y0, int x0, int H, int W, int tid) {
+  // tile[c][ty][tx] = src[c0+c][y0-4+ty][x0-4+tx], zero outside image / channel range
+  constexpr int N = NCH * TP * TP;
+  constexpr int UN = 12;
+  for (int i0 = tid; i0 < N; i0 += NTHR * UN) {
+    float v[UN];
+    int cc[UN], ty[UN], tx[UN];
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const int i = i0 + k * NTHR;
+      const int c = i / (TP * TP);
+      const int r = i - c * (TP * TP);
+      ty[k] = r / TP;
+      tx[k] = r - ty[k] * TP;
+      cc[k] = c;
+      const int y = y0 - HALO + ty[k], x = x0 - HALO + tx[k];
+      v[k] = 0.f;
+      if (i < N && c0 + c < C && y >= 0 && y < H && x >= 0 && x < W) v[k] = src[(long)(c0 + c) * plane + (long)y * W + x];
+    }
+#pragma unroll
+    for (int k = 0; k < UN; ++k)
+      if (i0 + k * NTHR < N) tile[cc[k]][ty[k]][tx[k]] = v[k];
+  }
+}
+
 __device__ __forceinline__ void stage_tile(float (*tile)[TP][PITCH], const float* __restrict__ src, long plane,
                                            int c0, int C, int y0, int x0, int H, int W, int tid) {
-  // tile[c][ty][tx] = src[c0+c][y0-4+ty][x0-4+tx], zero outside image / channel range
-  for (int i = tid; i < CC * TP * TP; i += TS * TS) {
-    int c = i / (TP * TP);
-    int r = i - c * (TP * TP);
-    int ty = r / TP, tx = r - ty * TP;
-    int y = y0 - HALO + ty, x = x0 - HALO + tx;
-    float v = 0.f;
-    if (c0 + c < C && y >= 0 && y < H && x >= 0 && x < W) v = src[(long)(c0 + c) * plane + (long)y * W + x];
-    tile[c][ty][tx] = v;
-  }
+  stage_tile_t<CC, PITCH, TS * TS>(tile, src, plane, c0, C, y0, x0, H, W, tid);
 }
 
 __global__ __launch_bounds__(256) void corr81_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                         float* __restrict__ out, int C, int H, int W, long f1_bs,
                                                         long f2_bs, long out_bs, int fuse_lrelu) {
-  __shared__ float tile[CC][TP][PITCH];
+  __shared__ __attribute__((aligned(16))) float tile[CC][TP][PITCH];
   const int tid = threadIdx.x;
   const int tx = tid & (TS - 1), ty = tid >> 4;
   const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS, b = blockIdx.z;
@@ -79,27 +99,32 @@ __global__ __launch_bounds__(256) void corr81_fwd_kernel(const float* __restrict
 }
 
 // ---- forward, quad variant (W % 4 == 0) ----------------------------------------------------------------------------
-// The kernel above issues one LDS read per FMA (81 per channel and pixel) and is LDS-bound at ~2 TB/s.  Here a lane owns
-// FOUR consecutive pixels of a row and THREE of the nine vertical displacements (108 accumulators): per channel it reads
-// its f1 quad once and, per vertical displacement, the 12-float window of the staged f2 row as three aligned
-// ds_read_b128 -- 9 LDS instructions per 108 FMAs -- so the VALU, not the LDS, is the limit and the kernel sits close to
-// its HBM time (f1, f2 read once, the 81-plane output written once as 16-B stores).  Block = 16 x 16 pixels = 64 quads x
-// 3 displacement groups = 192 threads; f2 tile rows have a pitch of 48 floats (conflict-free for the 4-row x 4-quad
-// lane groups of ds_read_b128).
-constexpr int QP = 48;            // LDS row pitch (floats) of the quad variant
-constexpr int QC = 8;             // channels per LDS stage
+// The kernel above issues one LDS read per FMA (81 per channel and pixel), stages its tile one dword at a time and
+// writes 64-B row segments: 317 us at 96x112x64 (1.3 TB/s of algorithmic traffic).  Here
+//   * the block owns 8 rows x 32 columns, so every output store instruction writes full 128-B lines;
+//   * a lane owns FOUR consecutive pixels of a row and THREE of the nine vertical displacements (108 accumulators): per
+//     channel it reads its f1 quad and, per vertical displacement, the 12-float window of the staged f2 row as three aligned
+//     ds_read_b128 -- 10 LDS instructions per 108 FMAs;
+//   * both operands are staged per 8-channel stage as aligned 16-B units with all loads of a thread issued together
+//     (f2: (8+8) x (32+8) halo tile, f1: the block's own pixels), so the FMA loop contains no global load.
+// 8 rows x 8 quads x 3 displacement groups = 192 threads.
+constexpr int QX = 32, QY = 8;                     // tile
+constexpr int QTX = QX + 2 * HALO, QTY = QY + 2 * HALO;   // 40 x 16 halo tile
+constexpr int QP = QTX;                            // LDS row pitch (floats; 16-B aligned rows)
+constexpr int QC = 8;                              // channels per LDS stage
 
 typedef float f32x4c __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(192) void corr81_fwd4_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                          float* __restrict__ out, int C, int H, int W, long f1_bs,
                                                          long f2_bs, long out_bs, int fuse_lrelu) {
-  __shared__ __attribute__((aligned(16))) float tile[QC][TP][QP];
+  __shared__ __attribute__((aligned(16))) float tile[QC][QTY][QP];
+  __shared__ __attribute__((aligned(16))) float t1[QC][QY][QX];      // the block's own f1 pixels
   const int tid = threadIdx.x;
   const int grp = tid / 64;                       // vertical displacements 3*grp .. 3*grp + 2
   const int t64 = tid - grp * 64;
-  const int q = t64 & 3, ty = t64 >> 2;           // quad column (4 pixels), tile row
-  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS, b = blockIdx.z;
+  const int q = t64 & 7, ty = t64 >> 3;           // quad column (4 pixels), tile row
+  const int x0 = blockIdx.x * QX, y0 = blockIdx.y * QY, b = blockIdx.z;
   const int x = x0 + 4 * q, y = y0 + ty;
   const bool inside = (x < W) && (y < H);         // W % 4 == 0: a quad is inside or outside as a whole
   const long plane = (long)H * W;
@@ -116,20 +141,45 @@ __global__ __launch_bounds__(192) void corr81_fwd4_kernel(const float* __restric
 
   for (int c0 = 0; c0 < C; c0 += QC) {
     __syncthreads();
-    for (int i = tid; i < QC * TP * TP; i += 192) {
-      const int c = i / (TP * TP);
-      const int r = i - c * (TP * TP);
-      const int sy = r / TP, sx = r - sy * TP;
-      const int yy = y0 - HALO + sy, xx = x0 - HALO + sx;
-      float v = 0.f;
-      if (c0 + c < C && yy >= 0 && yy < H && xx >= 0 && xx < W) v = f2b[(long)(c0 + c) * plane + (long)yy * W + xx];
-      tile[c][sy][sx] = v;
+    {
+      constexpr int RU = QTX / 4;                           // 16-B units per halo row
+      constexpr int N2 = QC * QTY * RU, K2 = (N2 + 191) / 192;
+      constexpr int N1 = QC * QY * (QX / 4), K1 = (N1 + 191) / 192;
+      f32x4c v2[K2], v1[K1];
+#pragma unroll
+      for (int k = 0; k < K2; ++k) {
+        const int i = tid + k * 192;
+        const int c = i / (QTY * RU), r = i - c * (QTY * RU);
+        const int sy = r / RU, sx = (r - sy * RU) * 4;
+        const int yy = y0 - HALO + sy, xx = x0 - HALO + sx;
+        v2[k] = f32x4c{0.f, 0.f, 0.f, 0.f};
+        if (i < N2 && c0 + c < C && yy >= 0 && yy < H && xx >= 0 && xx < W) v2[k] = *(const f32x4c*)(f2b + (long)(c0 + c) * plane + (long)yy * W + xx);
+      }
+#pragma unroll
+      for (int k = 0; k < K1; ++k) {
+        const int i = tid + k * 192;
+        const int c = i / (QY * (QX / 4)), r = i - c * (QY * (QX / 4));
+        const int yy = y0 + r / (QX / 4), xx = x0 + (r % (QX / 4)) * 4;
+        v1[k] = f32x4c{0.f, 0.f, 0.f, 0.f};
+        if (i < N1 && c0 + c < C && yy < H && xx < W) v1[k] = *(const f32x4c*)(f1b + (long)(c0 + c) * plane + (long)yy * W + xx);
+      }
+#pragma unroll
+      for (int k = 0; k < K2; ++k) {
+        const int i = tid + k * 192;
+        const int c = i / (QTY * RU), r = i - c * (QTY * RU);
+        const int sy = r / RU, sx = (r - sy * RU) * 4;
+        if (i < N2) *(f32x4c*)(&tile[c][sy][sx]) = v2[k];
+      }
+#pragma unroll
+      for (int k = 0; k < K1; ++k) {
+        const int i = tid + k * 192;
+        if (i < N1) *(f32x4c*)(&t1[0][0][0] + 4 * i) = v1[k];
+      }
     }
     __syncthreads();
     const int cn = min(QC, C - c0);
     for (int c = 0; c < cn; ++c) {
-      f32x4c a = {0.f, 0.f, 0.f, 0.f};
-      if (inside) a = *(const f32x4c*)(f1b + (long)(c0 + c) * plane + (long)y * W + x);
+      const f32x4c a = *(const f32x4c*)(&t1[c][ty][4 * q]);
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const float* row = &tile[c][ty + 3 * grp + r][4 * q];
@@ -167,7 +217,7 @@ __global__ __launch_bounds__(256) void corr81_bwd_kernel(const float* __restrict
                                                         const float* __restrict__ fwd_out, float* __restrict__ gin,
                                                         int C, int H, int W, long other_bs, long gout_bs, long out_bs,
                                                         long gin_bs) {
-  __shared__ float tile[CC][TP][PITCH];
+  __shared__ __attribute__((aligned(16))) float tile[CC][TP][PITCH];
   const int tid = threadIdx.x;
   const int tx = tid & (TS - 1), ty = tid >> 4;
   const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS, b = blockIdx.z;
@@ -222,8 +272,9 @@ extern "C" int irr_corr81_fwd_f32(const float* f1, const float* f2, float* out, 
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !f1 || !f2 || !out) return IRR_EINVAL;
   if (B > 65535) return IRR_EINVAL;
   dim3 grid(irr_cdiv(W, TS), irr_cdiv(H, TS), B);
-  if ((W & 3) == 0 && ((f1_bs | out_bs) & 3) == 0 && (((uintptr_t)f1 | (uintptr_t)out) & 15) == 0 && !getenv("IRR_CORR_SCALAR")) {
-    hipLaunchKernelGGL(corr81_fwd4_kernel, grid, dim3(192), 0, (hipStream_t)stream, f1, f2, out, C, H, W, f1_bs, f2_bs,
+  dim3 grid4(irr_cdiv(W, QX), irr_cdiv(H, QY), B);
+  if ((W & 3) == 0 && ((f1_bs | out_bs) & 3) == 0 && (((uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)out) & 15) == 0 && ((f2_bs & 3) == 0) && !getenv("IRR_CORR_SCALAR")) {
+    hipLaunchKernelGGL(corr81_fwd4_kernel, grid4, dim3(192), 0, (hipStream_t)stream, f1, f2, out, C, H, W, f1_bs, f2_bs,
                        out_bs, fuse_lrelu);
     IRR_LAUNCH_CHECK();
     return 0;
