@@ -18,5 +18,13 @@
 
 static inline int irr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// A/B switches read from the environment ONCE per call site (the launchers run thousands of times per step).
+#include <stdlib.h>
+#define IRR_ENV_FLAG(name)                                   \
+  ([]() -> bool {                                            \
+    static const bool v = getenv(name) != nullptr;           \
+    return v;                                                \
+  }())
+
 __device__ __forceinline__ float irr_lrelu(float v) { return v > 0.f ? v : 0.1f * v; }
 __device__ __forceinline__ float irr_lrelu_grad(float y) { return y > 0.f ? 1.f : 0.1f; }

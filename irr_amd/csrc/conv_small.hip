@@ -391,7 +391,7 @@ extern "C" int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const 
                                           long res_bs, int lrelu, float alpha, int accumulate, void* stream) {
   if (!x || !w || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 1 || Cout > 4 || B > 65535) return IRR_EINVAL;
   if ((k != 1 && k != 3) || dil < 1) return IRR_EINVAL;
-  if (k == 3 && dil == 1 && (W & 3) == 0 && Cout <= 2 && ((x_bs | y_bs | res_bs) & 3) == 0 && !getenv("IRR_SMALLCO_SCALAR")) {
+  if (k == 3 && dil == 1 && (W & 3) == 0 && Cout <= 2 && ((x_bs | y_bs | res_bs) & 3) == 0 && !IRR_ENV_FLAG("IRR_SMALLCO_SCALAR")) {
     dim3 grid4(irr_cdiv((long)H * W / 4, 64), B, 1);             // one wave per block: enough blocks to hide the channel-loop latency
     hipStream_t st = (hipStream_t)stream;
     if (Cout == 1)
@@ -424,7 +424,7 @@ extern "C" int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, flo
   if (chunks < 1) chunks = 1;
   long ppb = (hw + chunks - 1) / chunks;
   if (ppb < 1024) ppb = 1024;
-  if (k == 3 && dil == 1 && (W & 3) == 0 && Cout <= 2 && ((x_bs | gy_bs) & 3) == 0 && !getenv("IRR_SMALLCO_SCALAR")) {
+  if (k == 3 && dil == 1 && (W & 3) == 0 && Cout <= 2 && ((x_bs | gy_bs) & 3) == 0 && !IRR_ENV_FLAG("IRR_SMALLCO_SCALAR")) {
     const long qpb = (ppb + 3) / 4;
     dim3 grid4(irr_cdiv(hw / 4, qpb), Cin, B);
     if (Cout == 1)

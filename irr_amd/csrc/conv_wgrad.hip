@@ -597,7 +597,7 @@ extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
     a.B = (B - b0) < per ? (B - b0) : (int)per;
     a.x = x + (long)b0 * x_bs;
     a.gy = gy + (long)b0 * gy_bs;
-    const bool halo = (k == 3 && stride == 1 && dil == 1 && W >= 56 && !getenv("IRR_WGRAD_NO_HALO"));
+    const bool halo = (k == 3 && stride == 1 && dil == 1 && W >= 56 && !IRR_ENV_FLAG("IRR_WGRAD_NO_HALO"));
     const int rc = halo ? dispatch_halo(a, (hipStream_t)stream)
                         : (k == 3) ? dispatch<3>(a, (hipStream_t)stream) : dispatch<1>(a, (hipStream_t)stream);
     if (rc) return rc;

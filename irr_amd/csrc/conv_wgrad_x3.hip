@@ -17,20 +17,13 @@
 //   * a block walks several columns with persistent accumulators and flushes once: coalesced fp32 atomics into the
 //     [co][tap][ci] workspace that wgrad_unpack_kernel (conv_wgrad.hip) folds into dW; the bias gradient is summed by
 //     the gy stagers (fixed channel per thread) and added once per block.
-#include "common.h"
+#include "x3_split.h"
 
 #ifndef WX3_ABL
 #define WX3_ABL 0      // ablation builds (timing only): 1 = no operand split (VALU) in the staging path
 #endif
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t OOB = 0x80000000u;
 
@@ -47,30 +40,6 @@ struct WX3Args {
   int cols_per_block;
 };
 
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
-  f32x2 v = {a, b};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float lo_f(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float hi_f(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-
-__device__ __forceinline__ void split8(const float* v, u32x4& h, u32x4& m, u32x4& l) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float a = v[2 * q], b = v[2 * q + 1];
-    const uint32_t hp = pk_bf16(a, b);
-    const float ra = a - lo_f(hp), rb = b - hi_f(hp);
-    const uint32_t mp = pk_bf16(ra, rb);
-    const float sa = ra - lo_f(mp), sb = rb - hi_f(mp);
-    h[q] = hp;
-    m[q] = mp;
-    l[q] = pk_bf16(sa, sb);
-  }
-}
-
-__device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 __device__ __forceinline__ uint32_t alignbit16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }
 

@@ -22,7 +22,7 @@
 //   * weights are pre-split at pack time (irr_conv_pack_weights_x3): one coalesced 1 KiB buffer_load_dwordx4 per
 //     (chunk, tap, piece, co-tile) is exactly the A fragment; prefetched one tap ahead.
 //   * epilogue identical to conv_fwd.hip (bias, LeakyReLU, residual/scale, "+=", LeakyReLU'-mask).
-#include "common.h"
+#include "x3_split.h"
 #include <stdlib.h>
 
 #ifndef X3_ABL
@@ -30,13 +30,6 @@
 #endif               // 3 = producers skip their global loads, 4 = independent accumulators (no dependent MFMA chain)
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t OOB = 0x80000000u;     // voffset marker: beyond num_records -> the load returns 0, touches nothing
 
@@ -58,31 +51,6 @@ struct X3Args {
   int nmask;
 };
 
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
-  f32x2 v = {a, b};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32 (RNE)
-}
-__device__ __forceinline__ float lo_f(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float hi_f(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-
-// exact 3-way bf16 split of 8 floats -> three packed 8 x bf16 fragments
-__device__ __forceinline__ void split8(const float* v, u32x4& h, u32x4& m, u32x4& l) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float a = v[2 * q], b = v[2 * q + 1];
-    const uint32_t hp = pk_bf16(a, b);
-    const float ra = a - lo_f(hp), rb = b - hi_f(hp);
-    const uint32_t mp = pk_bf16(ra, rb);
-    const float sa = ra - lo_f(mp), sb = rb - hi_f(mp);
-    h[q] = hp;
-    m[q] = mp;
-    l[q] = pk_bf16(sa, sb);
-  }
-}
-
-__device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 // Block = CT*PG symmetric waves, two blocks per CU (256 registers per wave, 128 of them accumulators): every wave
 // takes part in staging a chunk's patch (load -> split -> LDS), then runs its 9 x NT x 6 MFMAs; while one block
@@ -628,14 +596,14 @@ static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) 
   }
   if (!ok) return false;
   p->blocks = (long)B * ((H + p->t.tr - 1) / p->t.tr) * ((W + p->t.tc - 1) / p->t.tc) * ((CoT + p->ct - 1) / p->ct);
-  if ((p->blocks < g_min_blocks || getenv("IRR_X3_FORCE_NT4")) && p->ct >= 2) {
+  if ((p->blocks < g_min_blocks || IRR_ENV_FLAG("IRR_X3_FORCE_NT4")) && p->ct >= 2) {
     // small pyramid levels: half-size tiles (NT = 4) double the number of blocks
     TileCfg t4;
     const int plane4 = p->ct == 2 ? 616 : 352;
     if (pick_tile(H, W, dil, p->pg, plane4, nts4, 1, &t4)) {
       const long b4 = (long)B * ((H + t4.tr - 1) / t4.tr) * ((W + t4.tc - 1) / t4.tc) * ((CoT + p->ct - 1) / p->ct);
       const double e4 = (double)H * W / ((double)((H + t4.tr - 1) / t4.tr) * ((W + t4.tc - 1) / t4.tc) * t4.tr * t4.tc);
-      if ((b4 > p->blocks || getenv("IRR_X3_FORCE_NT4")) && e4 >= 0.70) { p->t = t4; p->plane = plane4; p->blocks = b4; }
+      if ((b4 > p->blocks || IRR_ENV_FLAG("IRR_X3_FORCE_NT4")) && e4 >= 0.70) { p->t = t4; p->plane = plane4; p->blocks = b4; }
     }
   }
   // padded work must stay close to the real work, and the launch must fill the chip

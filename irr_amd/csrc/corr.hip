@@ -273,7 +273,7 @@ extern "C" int irr_corr81_fwd_f32(const float* f1, const float* f2, float* out, 
   if (B > 65535) return IRR_EINVAL;
   dim3 grid(irr_cdiv(W, TS), irr_cdiv(H, TS), B);
   dim3 grid4(irr_cdiv(W, QX), irr_cdiv(H, QY), B);
-  if ((W & 3) == 0 && ((f1_bs | out_bs) & 3) == 0 && (((uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)out) & 15) == 0 && ((f2_bs & 3) == 0) && !getenv("IRR_CORR_SCALAR")) {
+  if ((W & 3) == 0 && ((f1_bs | out_bs) & 3) == 0 && (((uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)out) & 15) == 0 && ((f2_bs & 3) == 0) && !IRR_ENV_FLAG("IRR_CORR_SCALAR")) {
     hipLaunchKernelGGL(corr81_fwd4_kernel, grid4, dim3(192), 0, (hipStream_t)stream, f1, f2, out, C, H, W, f1_bs, f2_bs,
                        out_bs, fuse_lrelu);
     IRR_LAUNCH_CHECK();

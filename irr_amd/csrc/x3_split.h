@@ -1,0 +1,38 @@
+// Shared by the bf16x3-split kernels (conv_x3.hip, conv_wgrad_x3.hip): exact 3-way bf16 split of fp32 operands and the
+// bf16 MFMA wrapper.  x = hi + mid + lo with round-to-nearest pieces: |mid| <= 2^-8 |x|, |lo| <= 2^-17 |x|, and the 24-bit
+// significand is covered completely.
+#pragma once
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ float lo_f(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_f(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// exact 3-way bf16 split of 8 floats -> three packed 8 x bf16 fragments
+__device__ __forceinline__ void split8(const float* v, u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a = v[2 * q], b = v[2 * q + 1];
+    const uint32_t hp = pk_bf16(a, b);
+    const float ra = a - lo_f(hp), rb = b - hi_f(hp);
+    const uint32_t mp = pk_bf16(ra, rb);
+    const float sa = ra - lo_f(mp), sb = rb - hi_f(mp);
+    h[q] = hp;
+    m[q] = mp;
+    l[q] = pk_bf16(sa, sb);
+  }
+}
+
+__device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
