@@ -265,6 +265,133 @@ __global__ __launch_bounds__(256) void corr81_bwd_kernel(const float* __restrict
   }
 }
 
+// ---- gradients, quad variant (W % 4 == 0) --------------------------------------------------------------------------
+// Same decomposition as corr81_fwd4_kernel: 8 x 32 pixel tile, a lane owns four consecutive pixels and three of the nine
+// vertical displacements.  Its 108 weights (the output gradient at its pixels, times LeakyReLU' of the forward output when
+// the activation was fused) live in registers for the whole kernel; per channel it forms the partial sum over its three
+// displacement rows from three aligned 12-float windows of the staged "other" map, and the three partial sums of a pixel
+// meet in LDS once per 8-channel stage (one 16-B write per channel and lane, 16-B global stores of full 128-B lines).
+//   SECOND == false: g1[c,p] = (1/C) sum_d g[d][p]   * f2[c][p+d]     (tile = f2)
+//   SECOND == true : g2[c,p] = (1/C) sum_d g[d][p-d] * f1[c][p-d]     (tile = f1, window mirrored)
+template <bool SECOND>
+__global__ __launch_bounds__(192) void corr81_bwd4_kernel(const float* __restrict__ other, const float* __restrict__ gout,
+                                                         const float* __restrict__ fwd_out, float* __restrict__ gin,
+                                                         int C, int H, int W, long other_bs, long gout_bs, long out_bs,
+                                                         long gin_bs) {
+  __shared__ __attribute__((aligned(16))) float tile[QC][QTY][QP];
+  __shared__ __attribute__((aligned(16))) float red[3][QC][QY][QX];
+  const int tid = threadIdx.x;
+  const int grp = tid / 64;
+  const int t64 = tid - grp * 64;
+  const int q = t64 & 7, ty = t64 >> 3;
+  const int x0 = blockIdx.x * QX, y0 = blockIdx.y * QY, b = blockIdx.z;
+  const int x = x0 + 4 * q, y = y0 + ty;
+  const bool inside = (x < W) && (y < H);
+  const long plane = (long)H * W;
+  const float* ob = other + (long)b * other_bs;
+  const float* gb = gout + (long)b * gout_bs;
+  const float* fb = fwd_out ? fwd_out + (long)b * out_bs : nullptr;
+  const float inv_c = 1.f / (float)C;
+
+  float wgt[3][4][9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int dy = 3 * grp + r;
+#pragma unroll
+    for (int dx = 0; dx < 9; ++dx) {
+      const int d = dy * 9 + dx;
+      if (!SECOND) {
+        f32x4c g = {0.f, 0.f, 0.f, 0.f};
+        if (inside) {
+          const long off = (long)d * plane + (long)y * W + x;
+          g = *(const f32x4c*)(gb + off);
+          if (fb) {
+            const f32x4c f = *(const f32x4c*)(fb + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] *= irr_lrelu_grad(f[i]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wgt[r][i][dx] = g[i];
+      } else {
+        const int yy = y - (dy - 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int xx = x + i - (dx - 4);
+          float g = 0.f;
+          if (inside && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const long off = (long)d * plane + (long)yy * W + xx;
+            g = gb[off];
+            if (fb) g *= irr_lrelu_grad(fb[off]);
+          }
+          wgt[r][i][dx] = g;
+        }
+      }
+    }
+  }
+
+  for (int c0 = 0; c0 < C; c0 += QC) {
+    __syncthreads();                                        // previous stage's reduction has read `red`, its FMAs `tile`
+    {
+      constexpr int RU = QTX / 4;
+      constexpr int N2 = QC * QTY * RU, K2 = (N2 + 191) / 192;
+      f32x4c v2[K2];
+#pragma unroll
+      for (int k = 0; k < K2; ++k) {
+        const int i = tid + k * 192;
+        const int c = i / (QTY * RU), r = i - c * (QTY * RU);
+        const int sy = r / RU, sx = (r - sy * RU) * 4;
+        const int yy = y0 - HALO + sy, xx = x0 - HALO + sx;
+        v2[k] = f32x4c{0.f, 0.f, 0.f, 0.f};
+        if (i < N2 && c0 + c < C && yy >= 0 && yy < H && xx >= 0 && xx < W) v2[k] = *(const f32x4c*)(ob + (long)(c0 + c) * plane + (long)yy * W + xx);
+      }
+#pragma unroll
+      for (int k = 0; k < K2; ++k) {
+        const int i = tid + k * 192;
+        const int c = i / (QTY * RU), r = i - c * (QTY * RU);
+        const int sy = r / RU, sx = (r - sy * RU) * 4;
+        if (i < N2) *(f32x4c*)(&tile[c][sy][sx]) = v2[k];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < QC; ++c) {
+      f32x4c sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int dy = 3 * grp + r;
+        const float* row = &tile[c][SECOND ? ty + 8 - dy : ty + dy][4 * q];
+        const f32x4c w0 = *(const f32x4c*)(row), w1 = *(const f32x4c*)(row + 4), w2 = *(const f32x4c*)(row + 8);
+        const float wv[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int dx = 0; dx < 9; ++dx) sacc[i] = fmaf(wgt[r][i][dx], wv[SECOND ? i + 8 - dx : i + dx], sacc[i]);
+      }
+      *(f32x4c*)(&red[grp][c][ty][4 * q]) = sacc;
+    }
+    __syncthreads();
+    {
+      constexpr int N = QC * QY * (QX / 4), K = (N + 191) / 192;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int i = tid + k * 192;
+        if (i >= N) continue;
+        const int c = i / (QY * (QX / 4)), r = i - c * (QY * (QX / 4));
+        const int ry = r / (QX / 4), rq = r - ry * (QX / 4);
+        const int yy = y0 + ry, xx = x0 + 4 * rq;
+        if (c0 + c >= C || yy >= H || xx >= W) continue;
+        const f32x4c p0 = *(const f32x4c*)(&red[0][c][ry][4 * rq]), p1 = *(const f32x4c*)(&red[1][c][ry][4 * rq]),
+                     p2 = *(const f32x4c*)(&red[2][c][ry][4 * rq]);
+        f32x4c o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = ((p0[j] + p1[j]) + p2[j]) * inv_c;
+        *(f32x4c*)(gin + (long)b * gin_bs + (long)(c0 + c) * plane + (long)yy * W + xx) = o;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int irr_corr81_fwd_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, long f1_bs,
@@ -291,6 +418,22 @@ extern "C" int irr_corr81_bwd_f32(const float* f1, const float* f2, const float*
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !f1 || !f2 || !gout) return IRR_EINVAL;
   if (B > 65535) return IRR_EINVAL;
   dim3 grid(irr_cdiv(W, TS), irr_cdiv(H, TS), B);
+  const bool al16 = (((uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)gout | (uintptr_t)out | (uintptr_t)g1 | (uintptr_t)g2) & 15) == 0 &&
+                    ((f1_bs | f2_bs | gout_bs | out_bs | g1_bs | g2_bs) & 3) == 0;
+  if ((W & 3) == 0 && al16 && !IRR_ENV_FLAG("IRR_CORR_SCALAR")) {
+    dim3 grid4(irr_cdiv(W, QX), irr_cdiv(H, QY), B);
+    if (g1) {
+      hipLaunchKernelGGL(corr81_bwd4_kernel<false>, grid4, dim3(192), 0, (hipStream_t)stream, f2, gout, out, g1, C, H, W, f2_bs,
+                         gout_bs, out_bs, g1_bs);
+      IRR_LAUNCH_CHECK();
+    }
+    if (g2) {
+      hipLaunchKernelGGL(corr81_bwd4_kernel<true>, grid4, dim3(192), 0, (hipStream_t)stream, f1, gout, out, g2, C, H, W, f1_bs,
+                         gout_bs, out_bs, g2_bs);
+      IRR_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   if (g1) {
     hipLaunchKernelGGL(corr81_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, f2, gout, out, g1, C, H, W,
                        f2_bs, gout_bs, out_bs, g1_bs);
