@@ -25,6 +25,10 @@
 #include "x3_split.h"
 #include <stdlib.h>
 
+#ifdef X3S_TRACE
+static unsigned long long* g_x3s_dbg = nullptr;
+#endif
+
 #ifndef X3_ABL
 #define X3_ABL 0     // ablation builds (timing only, results wrong): 1 = no weight loads in the loop, 2 = no LDS reads in the loop,
 #endif               // 3 = producers skip their global loads, 4 = independent accumulators (no dependent MFMA chain)
@@ -252,7 +256,15 @@ struct X3SArgs {
   const float* mask;
   long mask_bs;
   int nmask;
+  unsigned long long* dbg;      // X3S_TRACE builds only
 };
+
+// s_memtime trace points (IRR_X3S_TRACE=1 builds, tools/x3s_trace.py): block 7, lane 0 of every wave
+#ifdef X3S_TRACE
+#define TR(slot) do { if (blockIdx.x == 7 && lane == 0 && ntr < 400) { dbgp[ntr++] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); } } while (0)
+#else
+#define TR(slot) do {} while (0)
+#endif
 
 __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
   constexpr int PLANE_PIX = 352;                           // >= 10 x 34 halo patch
@@ -269,6 +281,10 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long hw = (long)a.H * a.W;
   const long t_begin = blockIdx.x, t_step = gridDim.x;
+#ifdef X3S_TRACE
+  int ntr = 0;
+  unsigned long long* dbgp = a.dbg + (size_t)wave * 400;
+#endif
 
   // The MFMA waves touch no global memory at all: weights live in LDS for the lifetime of the (persistent) block, and
   // finished accumulators are handed to the producer waves through LDS, which run the epilogue (bias, LeakyReLU,
@@ -385,20 +401,29 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
     bool pending = false;
     for (long t = t_begin; t < a.ntiles; t += t_step) {
       // phase after barrier #(2n-1): the MFMA waves are on (n-1, chunk 1); slot 0 is free
+      TR(1);
       if (pending) epilogue_finish();                       // tile n-2: operands and accumulators are in registers
       pending = false;
+      TR(2);
       write_chunk(0);
+      TR(3);
       if (t + t_step < a.ntiles) issue_chunk(t + t_step, 0);
-      __syncthreads();                                      // barrier #2n: (n, chunk 0) published; accumulators of tile n-1 published
+      TR(4);
+      __syncthreads();
+      TR(5);                                      // barrier #2n: (n, chunk 0) published; accumulators of tile n-1 published
       // phase: MFMA waves on (n, chunk 0); slot 1 is free; the accumulator stage holds tile n-1 until barrier #2n+1
       if (tprev >= 0) {
         epilogue_loads(tprev);
         epilogue_grab();
         pending = true;
       }
+      TR(6);
       write_chunk(1);
+      TR(7);
       if (t + t_step < a.ntiles) issue_chunk(t + t_step, 1);
-      __syncthreads();                                      // barrier #2n+1: (n, chunk 1) published; accumulator stage free again
+      TR(8);
+      __syncthreads();
+      TR(9);                                      // barrier #2n+1: (n, chunk 1) published; accumulator stage free again
       tprev = t;
     }
     if (pending) epilogue_finish();
@@ -422,7 +447,9 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
+      TR(10 + c);
       __syncthreads();                                      // barrier #2n+c: chunk c of tile n is in slot c
+      TR(12 + c);
       if (c == 1) {
         // (the accumulator stage was released by the barrier that just passed: tile n-1's epilogue is done)
       }
@@ -458,6 +485,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    TR(14);
     // hand the accumulators to the epilogue waves: D[i][jj], i = (r&3) + 8*(r>>2) + 4*g (channel), jj = column
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -614,6 +642,14 @@ static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) 
 
 }  // namespace
 
+#ifdef X3S_TRACE
+extern "C" int irr_x3s_trace_dump(unsigned long long* host) {
+  if (!g_x3s_dbg) return -1;
+  hipDeviceSynchronize();
+  return (int)hipMemcpy(host, g_x3s_dbg, 8 * 400 * 8, hipMemcpyDeviceToHost);
+}
+#endif
+
 extern "C" int irr_conv_x3_set_min_blocks(int n) {
   const int old = g_min_blocks;
   if (n >= 0) g_min_blocks = n;
@@ -669,6 +705,14 @@ extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bi
     s.x_bs = x_bs; s.y_bs = y_bs; s.res_bs = res_bs;
     s.lrelu = lrelu; s.accumulate = accumulate; s.alpha = alpha;
     s.mask_bs = mask_bs; s.nmask = nmask;
+    s.dbg = nullptr;
+#ifdef X3S_TRACE
+    static unsigned long long* dbg_buf = nullptr;
+    if (!dbg_buf) { hipMalloc(&dbg_buf, 8 * 400 * 8); }
+    hipMemsetAsync(dbg_buf, 0, 8 * 400 * 8, (hipStream_t)stream);
+    s.dbg = dbg_buf;
+    g_x3s_dbg = dbg_buf;
+#endif
     constexpr size_t lds_bytes = (18 * 3 * 64 + 2 * 6 * 352) * 16 + 32 * 256 * 4;
     static bool attr_set = false;
     if (!attr_set) {
