@@ -45,6 +45,7 @@ struct X3Args {
   float* y;
   int B, Cin, H, W, Cout;
   int dil;
+  int RD;                                  // row fold: 1, or dil (the rows y = r (mod dil) of a sample form an independent dil-1-in-y problem)
   int CoT, nchunk;
   int TR, TC, tiles_x, tiles_y;
   long x_bs, y_bs, res_bs;
@@ -77,10 +78,14 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
   const int tx = bt % a.tiles_x;
   bt /= a.tiles_x;
   const int ty = bt % a.tiles_y;
-  const int b = bt / a.tiles_y;
-  const int y0 = ty * a.TR, x0 = tx * a.TC;
+  bt /= a.tiles_y;
+  const int rr = bt % a.RD;                                 // row residue class of this block (0 when rows are not folded)
+  const int b = bt / a.RD;
+  const int y0 = ty * a.TR, x0 = tx * a.TC;                 // y0 counts rows of the residue class: image row = rr + RD * y
   const int d = a.dil;
-  const int LW = a.TC + 2 * d, LH = a.TR + 2 * d;
+  const int dy = a.RD > 1 ? 1 : d;                          // vertical tap distance in rows of the class
+  const int Hs = (a.H - rr + a.RD - 1) / a.RD;
+  const int LW = a.TC + 2 * d, LH = a.TR + 2 * dy;
   const int npix = LH * LW;
   const long hw = (long)a.H * a.W;
   const int cot = blockIdx.y * CT + ct;
@@ -99,9 +104,9 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
     const int pix = u - gg * npix;
     const bool inr = u < 2 * npix;
     const int ly = pix / LW, lx = pix - ly * LW;
-    const int iy = y0 - d + ly, ix = x0 - d + lx;
-    const bool ok = inr && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    svoff[r] = ok ? (uint32_t)(((long)b * a.x_bs + (long)gg * 8 * hw + (long)iy * a.W + ix) * 4) : OOB;
+    const int iy = y0 - dy + ly, ix = x0 - d + lx;
+    const bool ok = inr && iy >= 0 && iy < Hs && ix >= 0 && ix < a.W;
+    svoff[r] = ok ? (uint32_t)(((long)b * a.x_bs + (long)gg * 8 * hw + (long)(rr + iy * a.RD) * a.W + ix) * 4) : OOB;
     swidx[r] = inr ? gg * PLANE_PIX + pix : -1;
   }
   const uint32_t hw4 = (uint32_t)(hw * 4);
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
           issue_w(slot ^ 1, nc, nt);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const int toff = ((tap / 3) * LW + (tap % 3)) * d;
+        const int toff = (tap / 3) * LW * dy + (tap % 3) * d;
         u32x4 xb[2][3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) xb[0][p] = lds[xidx[0] + toff + 2 * p * PLANE_PIX];
@@ -208,9 +213,9 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
   for (int s = 0; s < NT; ++s) {
     const int t = (pg * NT + s) * 32 + j;
     const int row = t / a.TC, col = t - row * a.TC;
-    const int oy = y0 + row, ox = x0 + col;
-    if (oy >= a.H || ox >= a.W) continue;
-    const long pofs = (long)oy * a.W + ox;
+    const int oys = y0 + row, ox = x0 + col;
+    if (oys >= Hs || ox >= a.W) continue;
+    const long pofs = (long)(rr + oys * a.RD) * a.W + ox;
     float* yb = a.y + (long)b * a.y_bs + pofs;
     const float* rb = a.res ? a.res + (long)b * a.res_bs + pofs : nullptr;
     const float* mb = a.mask ? a.mask + (long)b * a.mask_bs + pofs : nullptr;
@@ -553,7 +558,7 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, u32x4* __restrict__ 
 struct TileCfg { int nt, tr, tc; };
 
 // choose the TR x TC tile (TR*TC = 32*NT*PG pixels) that wastes the fewest MFMA columns, then the smallest halo
-static bool pick_tile(int H, int W, int dil, int PG, int plane_pix, const int* nts, int n_nts, TileCfg* out) {
+static bool pick_tile(int H, int W, int dy, int dx, int PG, int plane_pix, const int* nts, int n_nts, TileCfg* out) {
   double best = 1e30;
   bool found = false;
   for (int q = 0; q < n_nts; ++q) {
@@ -561,9 +566,9 @@ static bool pick_tile(int H, int W, int dil, int PG, int plane_pix, const int* n
     for (int tc = 4; tc <= P; ++tc) {
       if (P % tc) continue;
       const int tr = P / tc;
-      if ((long)(tr + 2 * dil) * (tc + 2 * dil) > plane_pix) continue;
+      if ((long)(tr + 2 * dy) * (tc + 2 * dx) > plane_pix) continue;
       const double tiles = (double)((H + tr - 1) / tr) * ((W + tc - 1) / tc);
-      const double cost = tiles * P * (1.0 + 0.05 * (double)(tr + 2 * dil) * (tc + 2 * dil) / P);
+      const double cost = tiles * P * (1.0 + 0.05 * (double)(tr + 2 * dy) * (tc + 2 * dx) / P);
       if (cost < best) { best = cost; out->nt = nts[q]; out->tr = tr; out->tc = tc; found = true; }
     }
   }
@@ -573,9 +578,10 @@ static bool pick_tile(int H, int W, int dil, int PG, int plane_pix, const int* n
 template <int CT, int PG, int NT, int PLANE_PIX>
 int launch_x3(X3Args& a, const TileCfg& t, hipStream_t st) {
   a.TR = t.tr; a.TC = t.tc;
+  const int Hs = (a.H + a.RD - 1) / a.RD;
   a.tiles_x = (a.W + t.tc - 1) / t.tc;
-  a.tiles_y = (a.H + t.tr - 1) / t.tr;
-  dim3 grid((unsigned)((long)a.B * a.tiles_x * a.tiles_y), (unsigned)((a.CoT + CT - 1) / CT), 1);
+  a.tiles_y = (Hs + t.tr - 1) / t.tr;
+  dim3 grid((unsigned)((long)a.B * a.RD * a.tiles_x * a.tiles_y), (unsigned)((a.CoT + CT - 1) / CT), 1);
   hipLaunchKernelGGL((conv_x3_kernel<CT, PG, NT, PLANE_PIX>), grid, dim3(CT * PG * 64), 0, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
@@ -591,12 +597,15 @@ static int pick_ct(int CoT) {
   return 4;
 }
 
-struct Plan { int ct, pg, plane; TileCfg t; long blocks; };
+struct Plan { int ct, pg, plane, rd; TileCfg t; long blocks; double eff; };
 
-static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) {
-  if (Cin < 16 || dil < 1 || H < 8 || W < 8) return false;
+// rd = 1: plain (TR + 2 dil) x (TC + 2 dil) halo patches.  rd = dil: rows folded by residue class, the patch is
+// (TR + 2) x (TC + 2 dil) -- the only way a dilation-8/16 patch fits the LDS planes, and a smaller halo for 2 and 4.
+static bool make_plan_rd(int B, int Cin, int H, int W, int Cout, int dil, int rd, Plan* p) {
   const int CoT = (Cout + 31) / 32;
-  if (Cin < 64 && CoT == 1 && g_min_blocks > 0) return false;   // two or three chunks AND one co-tile: see conv_x3s_kernel
+  const int Hs = (H + rd - 1) / rd;
+  const int dy = rd > 1 ? 1 : dil;
+  p->rd = rd;
   p->ct = pick_ct(CoT);
   static const int nts78[2] = {8, 7};
   static const int nts4[1] = {4};
@@ -604,40 +613,56 @@ static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) 
   if (p->ct >= 3) {
     p->pg = 1;
     p->plane = 352;
-    ok = pick_tile(H, W, dil, 1, 352, nts78, 2, &p->t);
-    if (!ok) { p->plane = 616; ok = pick_tile(H, W, dil, 1, 616, nts78, 2, &p->t); }
+    ok = pick_tile(Hs, W, dy, dil, 1, 352, nts78, 2, &p->t);
+    if (!ok) { p->plane = 616; ok = pick_tile(Hs, W, dy, dil, 1, 616, nts78, 2, &p->t); }
   } else if (p->ct == 2) {
     p->pg = 2;
     p->plane = 616;
     // (measured at 96x112: quarter-size sub-tile sets, 3 blocks per CU, beat NT = 8 by 17-21 % for the 64-channel layers)
-    ok = pick_tile(H, W, dil, 2, 616, nts4, 1, &p->t);
-    if (!ok) ok = pick_tile(H, W, dil, 2, 616, nts78, 2, &p->t);
+    ok = pick_tile(Hs, W, dy, dil, 2, 616, nts4, 1, &p->t);
+    if (!ok) ok = pick_tile(Hs, W, dy, dil, 2, 616, nts78, 2, &p->t);
   } else {
     p->pg = 4;
     static const int nts2[1] = {2};
     p->plane = 352;                                       // 256-pixel tiles, four blocks per CU (+4 ... +18 % over NT = 4)
-    ok = pick_tile(H, W, dil, 4, 352, nts2, 1, &p->t);
+    ok = pick_tile(Hs, W, dy, dil, 4, 352, nts2, 1, &p->t);
     if (!ok) {
       p->plane = 616;
-      ok = pick_tile(H, W, dil, 4, 616, nts4, 1, &p->t);
+      ok = pick_tile(Hs, W, dy, dil, 4, 616, nts4, 1, &p->t);
     }
   }
   if (!ok) return false;
-  p->blocks = (long)B * ((H + p->t.tr - 1) / p->t.tr) * ((W + p->t.tc - 1) / p->t.tc) * ((CoT + p->ct - 1) / p->ct);
+  auto ntiles = [&](const TileCfg& t) { return (long)((Hs + t.tr - 1) / t.tr) * ((W + t.tc - 1) / t.tc); };
+  p->blocks = (long)B * rd * ntiles(p->t) * ((CoT + p->ct - 1) / p->ct);
   if ((p->blocks < g_min_blocks || IRR_ENV_FLAG("IRR_X3_FORCE_NT4")) && p->ct >= 2) {
     // small pyramid levels: half-size tiles (NT = 4) double the number of blocks
     TileCfg t4;
     const int plane4 = p->ct == 2 ? 616 : 352;
-    if (pick_tile(H, W, dil, p->pg, plane4, nts4, 1, &t4)) {
-      const long b4 = (long)B * ((H + t4.tr - 1) / t4.tr) * ((W + t4.tc - 1) / t4.tc) * ((CoT + p->ct - 1) / p->ct);
-      const double e4 = (double)H * W / ((double)((H + t4.tr - 1) / t4.tr) * ((W + t4.tc - 1) / t4.tc) * t4.tr * t4.tc);
+    if (pick_tile(Hs, W, dy, dil, p->pg, plane4, nts4, 1, &t4)) {
+      const long b4 = (long)B * rd * ntiles(t4) * ((CoT + p->ct - 1) / p->ct);
+      const double e4 = (double)H * W / ((double)rd * ntiles(t4) * t4.tr * t4.tc);
       if ((b4 > p->blocks || IRR_ENV_FLAG("IRR_X3_FORCE_NT4")) && e4 >= 0.70) { p->t = t4; p->plane = plane4; p->blocks = b4; }
     }
   }
-  // padded work must stay close to the real work, and the launch must fill the chip
-  const double eff = (double)H * W / ((double)((H + p->t.tr - 1) / p->t.tr) * ((W + p->t.tc - 1) / p->t.tc) * p->t.tr * p->t.tc);
-  if (eff < 0.70) return false;
-  return true;
+  // padded work must stay close to the real work
+  p->eff = (double)H * W / ((double)rd * ntiles(p->t) * p->t.tr * p->t.tc);
+  return p->eff >= 0.70;
+}
+
+static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) {
+  if (Cin < 16 || dil < 1 || H < 8 || W < 8) return false;
+  const int CoT = (Cout + 31) / 32;
+  if (Cin < 64 && CoT == 1 && g_min_blocks > 0) return false;   // two or three chunks AND one co-tile: see conv_x3s_kernel
+  if (dil > 1 && !IRR_ENV_FLAG("IRR_X3_NO_ROWFOLD")) {
+    Plan f;
+    const bool okf = make_plan_rd(B, Cin, H, W, Cout, dil, dil, &f);
+    Plan u;
+    const bool oku = make_plan_rd(B, Cin, H, W, Cout, dil, 1, &u);
+    if (okf && (!oku || f.eff >= u.eff - 0.08)) { *p = f; return true; }
+    if (oku) { *p = u; return true; }
+    return false;
+  }
+  return make_plan_rd(B, Cin, H, W, Cout, dil, 1, p);
 }
 
 }  // namespace
@@ -745,7 +770,7 @@ extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bi
   if (!make_plan(B, Cin, H, W, Cout, dil, &p)) return IRR_EINVAL;
   X3Args a;
   a.wq = (const u32x4*)wq; a.bias = bias;
-  a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.dil = dil;
+  a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.dil = dil; a.RD = p.rd;
   a.CoT = (Cout + 31) / 32; a.nchunk = (Cin + 15) / 16;
   a.x_bs = x_bs; a.y_bs = y_bs; a.res_bs = res_bs;
   a.lrelu = lrelu; a.accumulate = accumulate; a.alpha = alpha;

@@ -105,6 +105,8 @@ X3_CASES = [  # (Cin, Cout, dil, B, H, W): every block shape (CT=4/3/2/1), NT=7/
     (115, 128, 1, 2, 24, 28), (565, 128, 1, 1, 16, 48), (371, 96, 1, 1, 33, 47), (531, 32, 1, 1, 32, 48),
     (128, 64, 1, 1, 40, 24), (64, 32, 1, 1, 70, 90), (128, 128, 2, 1, 24, 28), (128, 128, 4, 1, 24, 28),
     (16, 565, 1, 1, 24, 28), (243, 128, 1, 1, 48, 56), (35, 96, 1, 1, 12, 58),
+    # row-folded dilated patches (rows y = r mod dil form one block row set): dilation 8 / 16, heights not divisible by dil
+    (128, 96, 8, 1, 50, 56), (96, 128, 8, 1, 48, 56), (64, 96, 16, 1, 90, 112), (128, 128, 2, 1, 25, 28), (128, 128, 4, 2, 30, 36),
 ]
 
 

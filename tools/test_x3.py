@@ -13,6 +13,8 @@ ACC = [  # cin, cout, dil, B, H, W
     (115, 128, 1, 2, 24, 28), (565, 128, 1, 1, 16, 48), (371, 96, 1, 1, 33, 47), (531, 32, 1, 2, 20, 36),
     (128, 64, 1, 1, 40, 24), (32, 32, 1, 1, 70, 90), (128, 128, 2, 1, 24, 28), (128, 128, 4, 1, 24, 28), (16, 565, 1, 1, 24, 28),
     (243, 128, 1, 1, 48, 56),
+    (128, 96, 8, 1, 48, 56), (96, 64, 16, 1, 48, 56), (96, 128, 8, 2, 27, 36), (64, 96, 16, 1, 50, 44), (128, 128, 2, 1, 25, 28),
+    (128, 128, 4, 2, 30, 36), (96, 64, 16, 2, 96, 112),
 ]
 PERF = [  # name, cin, cout, dil, B, H, W
     ("ctx.conv0 L4", 565, 128, 1, 64, 96, 112), ("dense.conv1 L4", 115, 128, 1, 64, 96, 112),
@@ -22,7 +24,12 @@ PERF = [  # name, cin, cout, dil, B, H, W
     ("dense.conv2 L3", 243, 128, 1, 64, 48, 56), ("dgrad ctx0 L4", 128, 565, 1, 64, 96, 112),
     ("dense.conv2 L2", 243, 128, 1, 64, 24, 28), ("ctx.conv0 L2", 565, 128, 1, 64, 24, 28), ("dense.conv4 L2", 467, 64, 1, 64, 24, 28), ("refine 32->64 L4", 32, 64, 1, 64, 96, 112),
     ("refine 64->32 dgrad L4", 64, 32, 1, 64, 96, 112),
+    ("ctx d8 L4", 128, 96, 8, 64, 96, 112), ("ctx d16 L4", 96, 64, 16, 64, 96, 112), ("ctx d8 dgrad L4", 96, 128, 8, 64, 96, 112),
+    ("ctx d16 dgrad L4", 64, 96, 16, 64, 96, 112), ("ctx d8 L3", 128, 96, 8, 64, 48, 56), ("ctx d2 L3", 128, 128, 2, 64, 48, 56),
+    ("ctx d4 L3", 128, 128, 4, 64, 48, 56), ("ctx d16 L3", 96, 64, 16, 64, 48, 56),
 ]
+if os.environ.get("X3_ONLY"):
+    PERF = [p for p in PERF if os.environ["X3_ONLY"] in p[0]]
 
 
 def timeit(fn, iters=5):
