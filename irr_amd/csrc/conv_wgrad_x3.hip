@@ -18,6 +18,7 @@
 //     [co][tap][ci] workspace that wgrad_unpack_kernel (conv_wgrad.hip) folds into dW; the bias gradient is summed by
 //     the gy stagers (fixed channel per thread) and added once per block.
 #include "x3_split.h"
+#include <stdlib.h>
 
 #ifndef WX3_ABL
 #define WX3_ABL 0      // ablation builds (timing only): 1 = no operand split (VALU) in the staging path
@@ -369,8 +370,11 @@ int launch_wx3(WX3Args a, hipStream_t st) {
   }
   a.nstrips = (a.W + KG * 8 - 1) / (KG * 8);
   const int gy_ = irr_cdiv(a.Cin, 32 * NW), gz_ = irr_cdiv(a.Cout, 32 * MW);
-  // one block per CU (LDS); about two rounds of blocks over the chip, each block walking >= 1 column
-  const long want = 2L * cu_count() / ((long)gy_ * gz_) > 0 ? 2L * cu_count() / ((long)gy_ * gz_) : 1;
+  // one block per CU (LDS) and ONE round of blocks over the chip, each block walking >= 1 column: every block ends with
+  // 9 * 32 MW * 32 NW atomic adds into ws, a fixed cost per block that a second round doubles (measured: one round is
+  // 2-7 % faster at 96x112, 10-25 % at 48x56, 15-45 % at 24x28)
+  static const int rounds = getenv("IRR_WX3_ROUNDS") ? atoi(getenv("IRR_WX3_ROUNDS")) : 1;     // experiment switch
+  const long want = (long)rounds * cu_count() / ((long)gy_ * gz_) > 0 ? (long)rounds * cu_count() / ((long)gy_ * gz_) : 1;
   const int hk = (a.H + DIL - 1) / DIL;                     // rows of the longest residue walk
   int rows = hk;                                           // split columns vertically only when there are too few of them
   a.nchunks_y = 1;
@@ -391,6 +395,8 @@ int launch_wx3(WX3Args a, hipStream_t st) {
 
 // (KG, R) by image width: strips of KG groups must tile the row without waste
 static int pick_kg(int W) {
+  static const int force = getenv("IRR_WX3_KG") ? atoi(getenv("IRR_WX3_KG")) : 0;     // experiment switch
+  if (force == 1 || force == 2 || force == 4) return force;
   const int groups = (W + 7) / 8;                          // W % 8 == 4: the last group of a row is half empty
   if (groups % 4 == 0) return 4;
   if (groups % 2 == 0) return 2;

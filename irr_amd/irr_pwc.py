@@ -70,6 +70,7 @@ class PWCNet(nn.Module):
         # measured: 281.6 ms/step with the second stream vs 278.0 without (bs32 384x448): the big level-3/4 launches only
         # time-share the chip and the coarse levels are too short to matter -> off by default
         self.branch_streams = os.environ.get("IRR_BRANCH_STREAMS", "0") != "0"
+        self.branch_levels = int(os.environ.get("IRR_BRANCH_LEVELS", "5"))     # pyramid levels l < this use the second stream
 
     # the validity-mask threshold of WarpingLayer: 1.0 = reference as-is, 0.9999 = robust parity mode
     @property
@@ -80,9 +81,9 @@ class PWCNet(nn.Module):
     def mask_threshold(self, v: float) -> None:
         self.warping_layer.mask_threshold = float(v)
 
-    def _branch_stream(self, dev):
+    def _branch_stream(self, dev, level=0):
         """second HIP stream for the occlusion branch (experiment switch IRR_BRANCH_STREAMS=1; default: one stream)"""
-        if not self.branch_streams or dev.type != "cuda":
+        if not self.branch_streams or dev.type != "cuda" or level >= self.branch_levels:
             return None
         st = self.__dict__.get("_side_stream")
         if st is None or st.device != dev:
@@ -137,7 +138,7 @@ class PWCNet(nn.Module):
                 # The occlusion decoder + context network are independent of the flow branch until refine_occ: with
                 # IRR_BRANCH_STREAMS=1 they run on a second HIP stream (autograd replays their backward there too).
                 occ_in = torch.cat([corr, x_1by1, occ], dim=1)
-                side = self._branch_stream(dev)
+                side = self._branch_stream(dev, l)
                 if side is not None:
                     main = torch.cuda.current_stream()
                     side.wait_stream(main)

@@ -20,7 +20,7 @@ PERF = [("ctx.conv0 L4", 565, 128, 64, 96, 112), ("dense.conv1 L4", 115, 128, 64
         ("refine 128->128 L4", 128, 128, 64, 96, 112), ("dense.conv2 L3", 243, 128, 64, 48, 56), ("ctx.conv0 L3", 565, 128, 64, 48, 56),
         ("128->128 448x1024 L4", 128, 128, 16, 112, 256), ("dense.conv4 L4", 467, 64, 64, 96, 112), ("refine 128->64 L4", 128, 64, 64, 96, 112),
         ("refine 64->64 L4", 64, 64, 64, 96, 112), ("dense.conv5 L4", 531, 32, 64, 96, 112), ("refine 64->32 L4", 64, 32, 64, 96, 112),
-        ("dense.conv5 L3", 531, 32, 64, 48, 56), ("occup 32->32 L6", 32, 32, 64, 384, 448), ("occup 32->32 L5", 32, 32, 64, 192, 224), ("occup init 11->32 L6", 11, 32, 64, 384, 448), ("dense.conv2 L2", 243, 128, 64, 24, 28), ("ctx.conv0 L2", 565, 128, 64, 24, 28), ("dense.conv4 L2", 467, 64, 64, 24, 28)]
+        ("dense.conv5 L3", 531, 32, 64, 48, 56), ("dense.conv3 L3", 371, 96, 64, 48, 56), ("dense.conv4 L3", 467, 64, 64, 48, 56), ("dense.conv1 L3", 115, 128, 64, 48, 56), ("occup 32->32 L6", 32, 32, 64, 384, 448), ("occup 32->32 L5", 32, 32, 64, 192, 224), ("occup init 11->32 L6", 11, 32, 64, 384, 448), ("dense.conv2 L2", 243, 128, 64, 24, 28), ("ctx.conv0 L2", 565, 128, 64, 24, 28), ("dense.conv4 L2", 467, 64, 64, 24, 28)]
 
 
 def main():
@@ -49,6 +49,8 @@ def main():
         return
     print("== speed ==")
     for case in PERF_DIL + PERF:
+        if os.environ.get("WX3_ONLY") and os.environ["WX3_ONLY"] not in case[0]:
+            continue
         name, cin, cout, B, H, W = case[:6]
         dil = case[6] if len(case) > 6 else 1
         x = torch.randn(B, cin, H, W, device="cuda")
