@@ -607,14 +607,30 @@ static bool make_plan_rd(int B, int Cin, int H, int W, int Cout, int dil, int rd
   const int dy = rd > 1 ? 1 : dil;
   p->rd = rd;
   p->ct = pick_ct(CoT);
-  static const int nts78[2] = {8, 7};
+  static int nts78[2] = {8, 7};
   static const int nts4[1] = {4};
+  static const int force_nt = getenv("IRR_X3_NT") ? atoi(getenv("IRR_X3_NT")) : 0;       // experiment switch: 7 or 8
+  if (force_nt == 7 || force_nt == 8) nts78[0] = nts78[1] = force_nt;
   bool ok;
   if (p->ct >= 3) {
+    // NT = 8 or 7 (256 / 224-pixel tiles): the one with the smaller estimated time.  Blocks of a launch take equal time and
+    // 512 of them are resident, so a launch of few rounds pays for its partly filled last round (2688 blocks of NT = 8 at
+    // 96x112x64 = 5.25 rounds cost 6; 3072 blocks of NT = 7 cost 6 * 7/8); one sub-tile of fixed cost per block.
     p->pg = 1;
-    p->plane = 352;
-    ok = pick_tile(Hs, W, dy, dil, 1, 352, nts78, 2, &p->t);
-    if (!ok) { p->plane = 616; ok = pick_tile(Hs, W, dy, dil, 1, 616, nts78, 2, &p->t); }
+    ok = false;
+    double best = 1e30;
+    const int cog = (CoT + p->ct - 1) / p->ct;
+    for (int q = 0; q < 2; ++q) {
+      TileCfg t;
+      int plane = 352;
+      bool okq = pick_tile(Hs, W, dy, dil, 1, 352, nts78 + q, 1, &t);
+      if (!okq) { plane = 616; okq = pick_tile(Hs, W, dy, dil, 1, 616, nts78 + q, 1, &t); }
+      if (!okq) continue;
+      const double blocks = (double)B * rd * ((Hs + t.tr - 1) / t.tr) * ((W + t.tc - 1) / t.tc) * cog;
+      const double rounds = blocks / 512.0;
+      const double est = (rounds <= 8.0 ? (double)(long)(rounds + 0.999) : rounds) * (t.nt + 1.0) * (plane == 616 ? 1.04 : 1.0);
+      if (est < best) { best = est; p->t = t; p->plane = plane; ok = true; }
+    }
   } else if (p->ct == 2) {
     p->pg = 2;
     p->plane = 616;
