@@ -376,14 +376,21 @@ int launch_wx3(WX3Args a, hipStream_t st) {
   static const int rounds = getenv("IRR_WX3_ROUNDS") ? atoi(getenv("IRR_WX3_ROUNDS")) : 1;     // experiment switch
   const long want = (long)rounds * cu_count() / ((long)gy_ * gz_) > 0 ? (long)rounds * cu_count() / ((long)gy_ * gz_) : 1;
   const int hk = (a.H + DIL - 1) / DIL;                     // rows of the longest residue walk
-  int rows = hk;                                           // split columns vertically only when there are too few of them
+  // columns (b, strip, residue) are split vertically into 1, 2, 4 or 8 row chunks: the split that makes the blocks' equal
+  // shares of columns the cheapest (a block walks cols_per_block columns of rows + ring-fill rows each)
+  int rows = hk;
   a.nchunks_y = 1;
-  while ((long)a.B * a.nstrips * DIL * a.nchunks_y < want && rows > 8 * R) {
-    a.nchunks_y *= 2;
-    rows = ((hk + a.nchunks_y - 1) / a.nchunks_y + R - 1) / R * R;
+  double best = 1e30;
+  for (int c = 1; c <= 8; c *= 2) {
+    const int rc = c == 1 ? hk : ((hk + c - 1) / c + R - 1) / R * R;
+    if (c > 1 && rc < 8 * R) break;
+    const int nch = (hk + rc - 1) / rc;
+    const long ncols = (long)a.B * a.nstrips * DIL * nch;
+    const long cpb = (ncols + want - 1) / want;
+    const double t = (double)cpb * (rc + 2);
+    if (t < best * 0.97) { best = t; rows = rc; a.nchunks_y = nch; }
   }
   a.rows_per_chunk = rows;
-  a.nchunks_y = (hk + rows - 1) / rows;
   a.ncols = (long)a.B * a.nstrips * DIL * a.nchunks_y;
   a.cols_per_block = (int)((a.ncols + want - 1) / want);
   if (a.cols_per_block < 1) a.cols_per_block = 1;
