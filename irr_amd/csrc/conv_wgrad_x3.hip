@@ -456,11 +456,11 @@ extern "C" int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Co
   if (W % 4) return 0;
   if (dil != 1) return 5000 + dil;
   if (W < 24 || H < 8 || Cin < 8) return 0;
-  if (Cout <= 32 && Cin < 64 && (Cin > 32 || W % 32)) return 0;            // (32 -> 32 layers: K split over 8 wave groups)
   if ((long)B * H * W < 40000 && irr_conv_x3_set_min_blocks(-1) > 0) return 0;    // small levels stay on the fp32 kernels
   const int kg = pick_kg(W);
   const int cot = (Cout + 31) / 32;
-  if (cot == 1 && Cin <= 32) return 1144;                                  // <1,1,4,4,KW=8>
+  if (cot == 1 && Cin <= 32) return W % 32 == 0 ? 1144 : 1124;             // <1,1,4,4,KW=8> / <1,1,2,4,KW=4>
+  if ((cot == 1 && Cin <= 64) || (cot == 2 && Cin <= 32)) return 2124;     // <2,1,2,4,KW=4> (roles swapped when Cout <= 32)
   const int mw = cot == 1 ? 8 : cot == 2 ? 2 : cot == 3 ? 3 : 4;            // 8: operand roles swapped (see irr_conv2d_wgrad_x3)
   return mw * 100 + kg * 10 + (4 / kg);
 }
@@ -518,7 +518,8 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
   //   dW[co][ci][t] = sum gy[p] x[p + d(t)] = sum x[p'] gy[p' - d(t)] = dW'[ci][co][8 - t],
   // so the launch runs with the roles exchanged (8 "output-channel" waves over Cin, one "input" tile = Cout) and the
   // unpack kernel transposes and flips the taps.  The bias gradient then comes from a separate pass over the small gy.
-  const bool ksplit = cot == 1 && Cin <= 32;               // one (co, ci) tile: eight wave groups split the pixels
+  const bool ksplit = cot == 1 && Cin <= 32;               // one (co, ci) tile: eight (four) wave groups split the pixels
+  const bool k4 = (cot == 1 && Cin > 32 && Cin <= 64) || (cot == 2 && Cin <= 32);   // two tiles: 2 waves x 4 pixel groups
   const bool swapped = cot == 1 && !ksplit;
   WX3Args a;
   a.ws = ws; a.gbias = swapped ? nullptr : gbias; a.alpha = alpha;
@@ -538,7 +539,9 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
     a.gy = (swapped ? x : gy) + (long)b0 * a.gy_bs;
     int rc;
     if (ksplit) {
-      rc = launch_wx3<1, 1, 4, 4, 8>(a, st);
+      rc = W % 32 == 0 ? launch_wx3<1, 1, 4, 4, 8>(a, st) : launch_wx3<1, 1, 2, 4, 4>(a, st);
+    } else if (k4) {
+      rc = launch_wx3<2, 1, 2, 4, 4>(a, st);
     } else if (swapped) {
       rc = kg == 4 ? launch_wx3<8, 1, 4, 1>(a, st) : kg == 2 ? launch_wx3<8, 1, 2, 2>(a, st) : launch_wx3<8, 1, 1, 4>(a, st);
     } else if (cot == 2) {

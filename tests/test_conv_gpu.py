@@ -211,6 +211,9 @@ WX3_CASES = [  # (Cin, Cout, B, H, W): every block shape (MW=4/3/2 and the swapp
     (32, 32, 2, 24, 64), (32, 9, 1, 16, 96), (24, 32, 2, 20, 32),          # one (co, ci) tile: pixels split over eight wave groups
     (243, 128, 2, 24, 28), (64, 64, 1, 12, 44), (371, 96, 1, 10, 36), (531, 32, 1, 24, 28),   # W % 8 == 4: half-empty last group
     (11, 32, 2, 16, 64),                                                                    # OccUpsampleNetwork.init_conv
+    # one or two tiles, W % 32 != 0: four pixel wave groups (<1,1,2,4,4>, <2,1,2,4,4> direct and with exchanged roles)
+    (32, 32, 2, 24, 56), (32, 32, 1, 16, 112), (24, 20, 2, 20, 40), (64, 32, 2, 12, 56), (48, 32, 1, 16, 48), (32, 64, 2, 16, 112),
+    (20, 64, 1, 12, 56), (64, 32, 1, 24, 28), (32, 48, 1, 17, 36),
 ]
 
 

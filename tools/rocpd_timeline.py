@@ -1,0 +1,72 @@
+"""Occupancy timeline of the LAST train step in a rocprofv3 --kernel-trace rocpd database: how much of the step has
+no kernel running, exactly one running with a grid that cannot fill 256 CUs, or two lanes running.
+usage: python tools/rocpd_timeline.py <results.db> [n_steps_in_run]"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    if "--cols" in sys.argv:
+        print(cols)
+    def pick(*subs):
+        for c in cols:
+            if all(s in c.lower() for s in subs):
+                return c
+        return None
+    c_start, c_end = pick("start"), pick("end")
+    gx, gy, gz = pick("grid", "x"), pick("grid", "y"), pick("grid", "z")
+    wx, wy, wz = pick("workgroup", "x"), pick("workgroup", "y"), pick("workgroup", "z")
+    c_stream = pick("stream") or pick("queue")
+    q = f"select name, {c_start}, {c_end}, {gx}, {gy}, {gz}, {wx}, {wy}, {wz}, {c_stream} from kernels order by {c_start}"
+    rows = db.execute(q).fetchall()
+    # last step = from the last 'adam' kernel but one to the last one
+    adam = [i for i, r in enumerate(rows) if "adam" in r[0].lower()]
+    if len(adam) >= 2:
+        rows = rows[adam[-2] + 1:adam[-1] + 1]
+    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    ev = []
+    for name, s, e, a, b, c, x, y, z, st in rows:
+        blocks = (a // max(x, 1)) * (b // max(y, 1)) * (c // max(z, 1)) if a >= x else a * b * c
+        ev.append((s, 1, blocks, name, st))
+        ev.append((e, -1, blocks, name, st))
+    ev.sort(key=lambda t: (t[0], t[1]))
+    active = {}
+    last = t0
+    idle = single_small = single_big = multi = 0
+    small_by = {}
+    for t, d, blocks, name, st in ev:
+        dt = t - last
+        if dt > 0:
+            n = len(active)
+            if n == 0:
+                idle += dt
+            elif n == 1:
+                (k, (bl, nm)), = active.items()
+                if bl < 256:
+                    single_small += dt
+                    key = nm.split("(")[0][-60:]
+                    small_by[key] = small_by.get(key, 0) + dt
+                else:
+                    single_big += dt
+            else:
+                multi += dt
+        last = t
+        key = (name, st, blocks, d > 0)
+        if d > 0:
+            active[(name, st, t)] = (blocks, name)
+        else:
+            for k in list(active):
+                if k[0] == name and k[1] == st:
+                    del active[k]
+                    break
+    span = t1 - t0
+    print(f"step span {span / 1e6:.2f} ms: idle {idle / 1e6:.2f} ms, one kernel < 256 blocks {single_small / 1e6:.2f} ms, "
+          f"one kernel >= 256 blocks {single_big / 1e6:.2f} ms, >= 2 kernels {multi / 1e6:.2f} ms  ({len(rows)} dispatches)")
+    for k, v in sorted(small_by.items(), key=lambda kv: -kv[1])[:25]:
+        print(f"   {v / 1e6:7.2f} ms  {k}")
+
+
+if __name__ == "__main__":
+    main()

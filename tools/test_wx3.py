@@ -20,7 +20,7 @@ PERF = [("ctx.conv0 L4", 565, 128, 64, 96, 112), ("dense.conv1 L4", 115, 128, 64
         ("refine 128->128 L4", 128, 128, 64, 96, 112), ("dense.conv2 L3", 243, 128, 64, 48, 56), ("ctx.conv0 L3", 565, 128, 64, 48, 56),
         ("128->128 448x1024 L4", 128, 128, 16, 112, 256), ("dense.conv4 L4", 467, 64, 64, 96, 112), ("refine 128->64 L4", 128, 64, 64, 96, 112),
         ("refine 64->64 L4", 64, 64, 64, 96, 112), ("dense.conv5 L4", 531, 32, 64, 96, 112), ("refine 64->32 L4", 64, 32, 64, 96, 112),
-        ("dense.conv5 L3", 531, 32, 64, 48, 56), ("dense.conv3 L3", 371, 96, 64, 48, 56), ("dense.conv4 L3", 467, 64, 64, 48, 56), ("dense.conv1 L3", 115, 128, 64, 48, 56), ("occup 32->32 L6", 32, 32, 64, 384, 448), ("occup 32->32 L5", 32, 32, 64, 192, 224), ("occup init 11->32 L6", 11, 32, 64, 384, 448), ("dense.conv2 L2", 243, 128, 64, 24, 28), ("ctx.conv0 L2", 565, 128, 64, 24, 28), ("dense.conv4 L2", 467, 64, 64, 24, 28)]
+        ("dense.conv5 L3", 531, 32, 64, 48, 56), ("refine 32->32 L4", 32, 32, 64, 96, 112), ("refine 32->32 L3", 32, 32, 64, 48, 56), ("refine 64->32 L3", 64, 32, 64, 48, 56), ("dgradlike 32->64 L4", 32, 64, 64, 96, 112), ("dense.conv3 L3", 371, 96, 64, 48, 56), ("dense.conv4 L3", 467, 64, 64, 48, 56), ("dense.conv1 L3", 115, 128, 64, 48, 56), ("occup 32->32 L6", 32, 32, 64, 384, 448), ("occup 32->32 L5", 32, 32, 64, 192, 224), ("occup init 11->32 L6", 11, 32, 64, 384, 448), ("dense.conv2 L2", 243, 128, 64, 24, 28), ("ctx.conv0 L2", 565, 128, 64, 24, 28), ("dense.conv4 L2", 467, 64, 64, 24, 28)]
 
 
 def main():
