@@ -146,32 +146,71 @@ __device__ __forceinline__ void load_patch6(const float* __restrict__ row, bool 
   }
 }
 
-template <int NC>
-__global__ __launch_bounds__(64) void conv_smallco_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                               const float* __restrict__ bias, const float* __restrict__ res,
-                                                               float* __restrict__ y, int Cin, int H, int W, long x_bs, long y_bs,
-                                                               long res_bs, int lrelu, float alpha, int accumulate) {
+// Branch-free variant on a buffer resource for lanes that hold CONSECUTIVE quads of one sample: the 16-B load of a patch
+// row carries voffset = SOOB (beyond num_records: returns 0, touches nothing) where the row is outside the image; the two
+// side pixels come from the neighbouring lanes' quads (ds_bpermute), only lanes 0 and 63 of a wave load theirs (a strided
+// dword load costs the L1 as many tag lookups as the 16-B load: three loads per row ran at 1.9 TB/s).
+constexpr uint32_t SOOB = 0x80000000u;
+__device__ __forceinline__ void patch6_voffsets(int iy, int x0, int H, int W, bool ok, int lane, uint32_t& vm, uint32_t& vl,
+                                                uint32_t& vr) {
+  const bool rok = ok && iy >= 0 && iy < H;
+  const uint32_t base = (uint32_t)((iy * W + x0) * 4);
+  vm = rok ? base : SOOB;
+  vl = (rok && x0 > 0 && lane == 0) ? base - 4u : SOOB;
+  vr = (rok && x0 + 4 < W && lane == 63) ? base + 16u : SOOB;
+}
+__device__ __forceinline__ void load_patch6_buf(__amdgpu_buffer_rsrc_t rs, uint32_t soff, uint32_t vm, uint32_t vl, uint32_t vr,
+                                                float* v) {
+  // (cast straight to a float vector: element-wise bit casts of a uint32 vector make this compiler shrink the load to a dword)
+  const f32x4s m = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vm, (int)soff, 0));
+  v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vl, (int)soff, 0));
+  v[5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vr, (int)soff, 0));
+  v[1] = m[0];
+  v[2] = m[1];
+  v[3] = m[2];
+  v[4] = m[3];
+}
+// after the loads have landed: v[0] / v[5] of the inner lanes from the neighbours (zero at the row ends)
+__device__ __forceinline__ void patch6_sides(float* v, int x0, int W, int lane) {
+  const float up = __shfl_up(v[4], 1, 64), dn = __shfl_down(v[1], 1, 64);
+  if (lane > 0) v[0] = x0 > 0 ? up : 0.f;
+  if (lane < 63) v[5] = x0 + 4 < W ? dn : 0.f;
+}
+
+// KS waves per block share 64 pixel quads and split the input channels (wave k: channels k, k + KS, ...): a launch has
+// only H*W/4 quads per sample, too few waves to hide the latency of a 500-channel loop without the split; the partial sums
+// meet in LDS and wave 0 runs the epilogue.
+template <int NC, int KS>
+__global__ __launch_bounds__(64 * KS) void conv_smallco_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, const float* __restrict__ res,
+                                                                    float* __restrict__ y, int Cin, int H, int W, long x_bs, long y_bs,
+                                                                    long res_bs, int lrelu, float alpha, int accumulate) {
+  __shared__ float red[(KS > 1 ? KS - 1 : 1) * NC * 4 * 64];
   const long hw = (long)H * W;
-  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;          // quad index
-  if (q * 4 >= hw) return;
+  const int lane = threadIdx.x & 63;
+  const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long q = (long)blockIdx.x * 64 + lane;                         // quad index
+  const bool qok = q * 4 < hw;
   const int b = blockIdx.y;
-  const long p = q * 4;
+  const long p = qok ? q * 4 : 0;
   const int oy = (int)(p / W), x0 = (int)(p - (long)oy * W);
   float acc[NC][4];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[c][i] = 0.f;
-  const float* xb = x + (long)b * x_bs;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * x_bs), (short)0, (int)SOOB, 0x00020000);
+  uint32_t vm[3], vl[3], vr[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) patch6_voffsets(oy - 1 + r, x0, H, W, qok, lane, vm[r], vl[r], vr[r]);
+  const uint32_t hw4 = (uint32_t)(hw * 4);
 #pragma unroll 2
-  for (int ci = 0; ci < Cin; ++ci) {
-    const float* xc = xb + (long)ci * hw;
+  for (int ci = ks; ci < Cin; ci += KS) {
     float v[3][6];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int iy = oy - 1 + r;
-      load_patch6(xc + (long)iy * W, iy >= 0 && iy < H, x0, W, v[r]);
-    }
+    for (int r = 0; r < 3; ++r) load_patch6_buf(xr, (uint32_t)ci * hw4, vm[r], vl[r], vr[r], v[r]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) patch6_sides(v[r], x0, W, lane);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const float* wc = w + ((long)c * Cin + ci) * 9;                   // wave-uniform -> scalar loads
@@ -185,6 +224,23 @@ __global__ __launch_bounds__(64) void conv_smallco_fwd4_kernel(const float* __re
         }
     }
   }
+  if (KS > 1) {
+    if (ks > 0) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(((ks - 1) * NC + c) * 4 + i) * 64 + lane] = acc[c][i];
+    }
+    __syncthreads();
+    if (ks > 0) return;
+#pragma unroll
+    for (int k = 0; k < KS - 1; ++k)
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[c][i] += red[((k * NC + c) * 4 + i) * 64 + lane];
+  }
+  if (!qok) return;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const float bsv = bias ? bias[c] : 0.f;
@@ -223,7 +279,8 @@ __global__ __launch_bounds__(256) void conv_smallco_wgrad4_kernel(const float* _
   const int ci = blockIdx.y, b = blockIdx.z;
   const long q0 = (long)blockIdx.x * quads_per_block;
   const long q1 = min(nq, q0 + quads_per_block);
-  const float* xc = x + (long)b * x_bs + (long)ci * hw;
+  const __amdgpu_buffer_rsrc_t xr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * x_bs + (long)ci * hw), (short)0, (int)SOOB, 0x00020000);
   const float* gb = gy + (long)b * gy_bs;
   float acc[NC][9];
   float bsum[NC];
@@ -233,21 +290,33 @@ __global__ __launch_bounds__(256) void conv_smallco_wgrad4_kernel(const float* _
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
   }
-  for (long q = q0 + threadIdx.x; q < q1; q += 256) {
-    const long p = q * 4;
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)gb, (short)0, (int)SOOB, 0x00020000);
+  const uint32_t hw4 = (uint32_t)(hw * 4);
+  for (long qb = q0; qb < q1; qb += 256) {                 // wave-uniform trip count: the side pixels travel between lanes
+    const long q = qb + threadIdx.x;
+    const bool act = q < q1, inimg = q < nq;
+    const long p = inimg ? q * 4 : 0;
     const int oy = (int)(p / W), x0 = (int)(p - (long)oy * W);
     float g[NC][4];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const f32x4s gg = *(const f32x4s*)(gb + (long)c * hw + p);
+      const f32x4s gg = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)(act ? (uint32_t)(p * 4) : SOOB),
+                                                                                        (int)((uint32_t)c * hw4), 0));
 #pragma unroll
       for (int i = 0; i < 4; ++i) { g[c][i] = gg[i]; bsum[c] += gg[i]; }
     }
+    float vv[3][6];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const int iy = oy - 1 + r;
-      float v[6];
-      load_patch6(xc + (long)iy * W, iy >= 0 && iy < H, x0, W, v);
+      uint32_t vm, vl, vr;
+      patch6_voffsets(oy - 1 + r, x0, H, W, inimg, (int)(threadIdx.x & 63), vm, vl, vr);
+      load_patch6_buf(xr, 0u, vm, vl, vr, vv[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) patch6_sides(vv[r], x0, W, (int)(threadIdx.x & 63));
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float* v = vv[r];
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -361,6 +430,71 @@ __global__ __launch_bounds__(256) void conv_smallco_dgrad_kernel(const float* __
   }
 }
 
+// Quad version (dilation 1, W % 4 == 0): a thread owns four adjacent pixels, keeps their 3 x 6 gy neighbourhood in
+// registers and streams over the channels in batches of four: the read-modify-write operands of a batch (16-B buffer
+// loads, out-of-range voffset for channels past the end) are all in flight before the first store.
+template <int NC>
+__global__ __launch_bounds__(256) void conv_smallco_dgrad4_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                                 float* __restrict__ gx, const float* __restrict__ mask, int Cin,
+                                                                 int H, int W, long gy_bs, long gx_bs, long mask_bs, int nmask,
+                                                                 int accumulate, int ci_per_block) {
+  constexpr int U = 4;
+  const long hw = (long)H * W;
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * ci_per_block;
+  const int c1 = min(Cin, c0 + ci_per_block);
+  const bool qok = q * 4 < hw;
+  const long p = qok ? q * 4 : 0;
+  const int oy = (int)(p / W), x0 = (int)(p - (long)oy * W);
+  float gp[NC][3][6];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = oy - 1 + r;
+      load_patch6(gy + (long)b * gy_bs + (long)c * hw + (long)iy * W, qok && iy >= 0 && iy < H, x0, W, gp[c][r]);
+    }
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(gx + (long)b * gx_bs), (short)0, (int)SOOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(mask ? mask + (long)b * mask_bs : gx), (short)0, (int)SOOB, 0x00020000);
+  const uint32_t vp = qok ? (uint32_t)(p * 4) : SOOB;
+  const uint32_t hw4 = (uint32_t)(hw * 4);
+  const int nm = mask ? nmask : 0;
+  for (int ci = c0; ci < c1; ci += U) {
+    f32x4s d[U], mk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t so = (uint32_t)(ci + u) * hw4;
+      d[u] = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)((accumulate && ci + u < c1) ? vp : SOOB), (int)so, 0));
+      mk[u] = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(mr, (int)((ci + u < nm && ci + u < c1) ? vp : SOOB), (int)so, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int cc = min(ci + u, c1 - 1);                       // (clamped: the result of a channel past the end is dropped)
+      f32x4s v = d[u];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const float* wc = w + ((long)c * Cin + cc) * 9;          // wave-uniform -> scalar loads
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const float ww = wc[a * 3 + t];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaf(ww, gp[c][2 - a][i + 2 - t], v[i]);
+          }
+      }
+      if (ci + u < nm) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= irr_lrelu_grad(mk[u][i]);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), xr,
+                                             (int)(ci + u < c1 ? vp : SOOB), (int)((uint32_t)(ci + u) * hw4), 0);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int irr_conv2d_smallco_dgrad_f32(const float* gy, const float* w, float* gx, const float* mask, int B, int Cin,
@@ -376,6 +510,22 @@ extern "C" int irr_conv2d_smallco_dgrad_f32(const float* gy, const float* w, flo
   const int cpb = (Cin + split - 1) / split;
   dim3 grid(pblocks, irr_cdiv(Cin, cpb), B);
   hipStream_t st = (hipStream_t)stream;
+  if (dil == 1 && (W & 3) == 0 && ((gy_bs | gx_bs | mask_bs) & 3) == 0 && !IRR_ENV_FLAG("IRR_SMALLCO_SCALAR")) {
+    const int qblocks = irr_cdiv(hw / 4, 256);
+    int split4 = (int)((2048 + (long)qblocks * B - 1) / ((long)qblocks * B));
+    if (split4 < 1) split4 = 1;
+    if (split4 > Cin) split4 = Cin;
+    const int cpb4 = ((Cin + split4 - 1) / split4 + 3) / 4 * 4;
+    dim3 grid4(qblocks, irr_cdiv(Cin, cpb4), B);
+    if (Cout == 1)
+      hipLaunchKernelGGL((conv_smallco_dgrad4_kernel<1>), grid4, dim3(256), 0, st, gy, w, gx, mask, Cin, H, W, gy_bs, gx_bs, mask_bs,
+                         nmask, accumulate, cpb4);
+    else
+      hipLaunchKernelGGL((conv_smallco_dgrad4_kernel<2>), grid4, dim3(256), 0, st, gy, w, gx, mask, Cin, H, W, gy_bs, gx_bs, mask_bs,
+                         nmask, accumulate, cpb4);
+    IRR_LAUNCH_CHECK();
+    return 0;
+  }
   if (Cout == 1)
     hipLaunchKernelGGL((conv_smallco_dgrad_kernel<1>), grid, dim3(256), 0, st, gy, w, gx, mask, Cin, H, W, dil, gy_bs, gx_bs, mask_bs,
                        nmask, accumulate, cpb);
@@ -394,12 +544,17 @@ extern "C" int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const 
   if (k == 3 && dil == 1 && (W & 3) == 0 && Cout <= 2 && ((x_bs | y_bs | res_bs) & 3) == 0 && !IRR_ENV_FLAG("IRR_SMALLCO_SCALAR")) {
     dim3 grid4(irr_cdiv((long)H * W / 4, 64), B, 1);             // one wave per block: enough blocks to hide the channel-loop latency
     hipStream_t st = (hipStream_t)stream;
-    if (Cout == 1)
-      hipLaunchKernelGGL((conv_smallco_fwd4_kernel<1>), grid4, dim3(64), 0, st, x, w, bias, res, y, Cin, H, W, x_bs, y_bs, res_bs,
-                         lrelu, alpha, accumulate);
-    else
-      hipLaunchKernelGGL((conv_smallco_fwd4_kernel<2>), grid4, dim3(64), 0, st, x, w, bias, res, y, Cin, H, W, x_bs, y_bs, res_bs,
-                         lrelu, alpha, accumulate);
+    static const int ks_env = getenv("IRR_SMALLCO_KS") ? atoi(getenv("IRR_SMALLCO_KS")) : 0;      // experiment switch
+    const int ks = ks_env ? ks_env : (Cin >= 64 ? 4 : 1);
+#define IRR_FWD4(NC, KS)                                                                                                  \
+  hipLaunchKernelGGL((conv_smallco_fwd4_kernel<NC, KS>), grid4, dim3(64 * KS), 0, st, x, w, bias, res, y, Cin, H, W, x_bs, y_bs, \
+                     res_bs, lrelu, alpha, accumulate)
+    if (Cout == 1) {
+      if (ks >= 8) IRR_FWD4(1, 8); else if (ks >= 4) IRR_FWD4(1, 4); else if (ks == 2) IRR_FWD4(1, 2); else IRR_FWD4(1, 1);
+    } else {
+      if (ks >= 8) IRR_FWD4(2, 8); else if (ks >= 4) IRR_FWD4(2, 4); else if (ks == 2) IRR_FWD4(2, 2); else IRR_FWD4(2, 1);
+    }
+#undef IRR_FWD4
     IRR_LAUNCH_CHECK();
     return 0;
   }

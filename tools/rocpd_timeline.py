@@ -4,6 +4,8 @@ usage: python tools/rocpd_timeline.py <results.db> [n_steps_in_run]"""
 import sqlite3
 import sys
 
+from rocpd_stats import short
+
 
 def main():
     db = sqlite3.connect(sys.argv[1])
@@ -46,7 +48,7 @@ def main():
                 (k, (bl, nm)), = active.items()
                 if bl < 256:
                     single_small += dt
-                    key = nm.split("(")[0][-60:]
+                    key = "%s [%d blocks]" % (short(nm)[:70], bl)
                     small_by[key] = small_by.get(key, 0) + dt
                 else:
                     single_big += dt
@@ -64,7 +66,7 @@ def main():
     span = t1 - t0
     print(f"step span {span / 1e6:.2f} ms: idle {idle / 1e6:.2f} ms, one kernel < 256 blocks {single_small / 1e6:.2f} ms, "
           f"one kernel >= 256 blocks {single_big / 1e6:.2f} ms, >= 2 kernels {multi / 1e6:.2f} ms  ({len(rows)} dispatches)")
-    for k, v in sorted(small_by.items(), key=lambda kv: -kv[1])[:25]:
+    for k, v in sorted(small_by.items(), key=lambda kv: -kv[1])[:45]:
         print(f"   {v / 1e6:7.2f} ms  {k}")
 
 
