@@ -163,10 +163,13 @@ int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, 
                          int k, int stride, int dil, long x_bs, long gy_bs, void* stream);
 
 /* Weight gradient on the bf16 matrix pipe with the exact 3-way split of conv_x3 (csrc/conv_wgrad_x3.hip): same contract
- * as irr_conv2d_wgrad_f32 for k = 3, stride = 1, dilation = 1, W % 8 == 0 (gw accumulated, ws = Cout*Cin*9 floats of
- * scratch, gbias nullable, alpha scales both).  irr_conv2d_wgrad_x3_eligible: non-zero when the problem is accepted
- * and large enough to pay off; 0 -> use irr_conv2d_wgrad_f32. */
+ * as irr_conv2d_wgrad_f32 for k = 3, stride = 1, dilation = 1, W % 4 == 0 (gw accumulated, gbias nullable, alpha
+ * scales both) -- except for the scratch: ws must hold irr_conv2d_wgrad_x3_ws_elems(Cin, Cout) floats (one partial
+ * [Cout][9][Cin] image per block column; the partials are summed in a fixed order, so the weight gradient is
+ * bit-reproducible and needs neither atomics nor a zeroed workspace).  irr_conv2d_wgrad_x3_eligible: non-zero when the
+ * problem is accepted and large enough to pay off; 0 -> use irr_conv2d_wgrad_f32. */
 int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil);
+long irr_conv2d_wgrad_x3_ws_elems(int Cin, int Cout);
 int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                         int B, int Cin, int H, int W, int Cout, long x_bs, long gy_bs, void* stream);
 /* the dilated layers of the context networks (dil in {2,4,8,16}, accepted when irr_conv2d_wgrad_x3_eligible says so) */

@@ -296,16 +296,20 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
             gbias += alpha * gy.sum(dim=(0, 2, 3))
         return gw
     assert gw.is_contiguous()
-    ws = torch.empty(cout * cin * k * k, device=x.device, dtype=torch.float32)
+    use_x3 = (MATH == "x3" and not (cout <= 4 and stride == 1)
+              and bool(hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, k, stride, dil)))
+    # scratch: one [Cout][k*k][Cin] image, or (x3 kernels) one partial image per block column of the launch
+    ws = torch.empty(hip.lib().irr_conv2d_wgrad_x3_ws_elems(cin, cout) if use_x3 else cout * cin * k * k,
+                     device=x.device, dtype=torch.float32)
     if cout <= 4 and stride == 1:
         hip.call("irr_conv2d_smallco_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W, cout, k, dil,
                  hip.bs(x), hip.bs(gy), hip.stream())
         return gw
-    if MATH == "x3" and dil > 1 and hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, k, stride, dil):
+    if use_x3 and dil > 1:
         hip.call("irr_conv2d_wgrad_x3_dil", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
                  cout, dil, hip.bs(x), hip.bs(gy), hip.stream())
         return gw
-    if MATH == "x3" and dil == 1 and hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, k, stride, dil):
+    if use_x3:
         hip.call("irr_conv2d_wgrad_x3", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
                  cout, hip.bs(x), hip.bs(gy), hip.stream())
         return gw

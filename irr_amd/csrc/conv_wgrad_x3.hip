@@ -31,7 +31,8 @@ constexpr uint32_t OOB = 0x80000000u;
 struct WX3Args {
   const float* x;
   const float* gy;
-  float* ws;                     // [Cout][9][Cin] workspace (atomics)
+  float* ws;                     // [grid.x][Cout][9][Cin] workspace: one partial result per block column (plain stores)
+  long n;                        // Cout * 9 * Cin
   float* gbias;                  // nullable
   float alpha;
   int B, Cin, H, W, Cout;
@@ -318,7 +319,9 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       // (bias partial sums below are per thread and do not depend on wk)
     }
   }
-  // ---- flush: ws[co][tap][ci] += alpha * acc (lanes = ci: coalesced atomics) ----
+  // ---- flush: ws[blockIdx.x][co][tap][ci] = alpha * acc (lanes = ci: coalesced stores; wgrad_reduce_x3_kernel sums the
+  // partials in a fixed order: no atomics, no zero-fill of the workspace, bit-reproducible weight gradients) ----
+  float* const wsp = a.ws + (long)blockIdx.x * a.n;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     if (KW > 1 && wk > 0) break;
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
       const int ci = ci0 + wn * 32 + j;
-      if (co < a.Cout && ci < a.Cin) unsafeAtomicAdd(a.ws + ((long)co * 9 + t) * a.Cin + ci, a.alpha * acc[t][r]);
+      if (co < a.Cout && ci < a.Cin) wsp[((long)co * 9 + t) * a.Cin + ci] = a.alpha * acc[t][r];
     }
   }
   if (a.gbias && blockIdx.y == 0) {
@@ -343,6 +346,8 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   }
 }
 
+int g_last_parts = 0;             // grid.x of the last launch_wx3 (host-side hand-over to the reduce launch)
+
 int g_cu_count = 0;
 int cu_count() {
   if (!g_cu_count) {
@@ -352,6 +357,16 @@ int cu_count() {
     if (g_cu_count <= 0) g_cu_count = 256;
   }
   return g_cu_count;
+}
+
+// floats the workspace must hold: one [Cout][9][Cin] partial per block column.  A block covers at most 8 tiles of
+// 32 x 32 channel pairs and a launch has at most cu_count() blocks.
+long ws_capacity(int Cin, int Cout) {
+  const long n = (long)Cout * 9 * Cin;
+  const long tiles = ((long)((Cin + 31) / 32) * ((Cout + 31) / 32) + 7) / 8;
+  long parts = cu_count() / tiles;
+  if (parts < 1) parts = 1;
+  return parts * n;
 }
 
 template <int MW, int NW, int KG, int R, int KW = 1, int DIL = 1>
@@ -371,10 +386,9 @@ int launch_wx3(WX3Args a, hipStream_t st) {
   a.nstrips = (a.W + KG * 8 - 1) / (KG * 8);
   const int gy_ = irr_cdiv(a.Cin, 32 * NW), gz_ = irr_cdiv(a.Cout, 32 * MW);
   // one block per CU (LDS) and ONE round of blocks over the chip, each block walking >= 1 column: every block ends with
-  // 9 * 32 MW * 32 NW atomic adds into ws, a fixed cost per block that a second round doubles (measured: one round is
-  // 2-7 % faster at 96x112, 10-25 % at 48x56, 15-45 % at 24x28)
-  static const int rounds = getenv("IRR_WX3_ROUNDS") ? atoi(getenv("IRR_WX3_ROUNDS")) : 1;     // experiment switch
-  const long want = (long)rounds * cu_count() / ((long)gy_ * gz_) > 0 ? (long)rounds * cu_count() / ((long)gy_ * gz_) : 1;
+  // a flush of 9 * 32 MW * 32 NW partial sums, a fixed cost per block that a second round doubles (measured with the
+  // earlier atomic flush: one round is 2-7 % faster at 96x112, 10-25 % at 48x56, 15-45 % at 24x28)
+  const long want = cu_count() / ((long)gy_ * gz_) > 0 ? cu_count() / ((long)gy_ * gz_) : 1;
   const int hk = (a.H + DIL - 1) / DIL;                     // rows of the longest residue walk
   // columns (b, strip, residue) are split vertically into 1, 2, 4 or 8 row chunks: the split that makes the blocks' equal
   // shares of columns the cheapest (a block walks cols_per_block columns of rows + ring-fill rows each)
@@ -395,9 +409,13 @@ int launch_wx3(WX3Args a, hipStream_t st) {
   a.cols_per_block = (int)((a.ncols + want - 1) / want);
   if (a.cols_per_block < 1) a.cols_per_block = 1;
   dim3 grid(irr_cdiv(a.ncols, a.cols_per_block), gy_, gz_);
+  a.n = (long)a.Cout * 9 * a.Cin;
+  if ((long)grid.x * a.n > ws_capacity(a.Cin, a.Cout)) return IRR_EINVAL;      // (cannot happen: grid.x <= want)
   hipLaunchKernelGGL((conv_wgrad_x3_kernel<MW, NW, KG, R, KW, DIL>), grid, dim3(MW * NW * KW * 64), lds_bytes, st, a);
   hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : (int)e;
+  if (e != hipSuccess) return (int)e;
+  g_last_parts = (int)grid.x;
+  return 0;
 }
 
 // (KG, R) by image width: strips of KG groups must tile the row without waste
@@ -412,17 +430,29 @@ static int pick_kg(int W) {
 
 }  // namespace
 
-// gw[co][ci][tap] += ws[co][tap][ci]            (swapped: the launch ran with the operand roles exchanged, see below,
-//                                                  and produced ws[ci][8-tap][co])
-__global__ void wgrad_unpack_x3_kernel(const float* __restrict__ ws, float* __restrict__ gw, int Cin, int Cout, int swapped,
-                                       long n) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int tap = (int)(i % 9);
-  const long r = i / 9;
-  const int ci = (int)(r % Cin);
-  const long co = r / Cin;
-  gw[i] += swapped ? ws[((long)ci * 9 + (8 - tap)) * Cout + co] : ws[(co * 9 + tap) * Cin + ci];
+// gw[co][ci][tap] += sum over the P partials of ws[p][co][tap][ci]   (swapped: the launch ran with the operand roles
+// exchanged, see below, and produced ws[p][ci][8-tap][co]).  256 threads = 64 consecutive workspace elements x 4 partial
+// lanes (coalesced 256-B reads per partial), fixed summation order.
+__global__ __launch_bounds__(256) void wgrad_reduce_x3_kernel(const float* __restrict__ ws, float* __restrict__ gw, int Cin, int Cout,
+                                                             int swapped, long n, int P) {
+  __shared__ float red[3][64];
+  const int jl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const long j = (long)blockIdx.x * 64 + jl;
+  float s = 0.f;
+  if (j < n)
+    for (int p = pl; p < P; p += 4) s += ws[(long)p * n + j];
+  if (pl > 0) red[pl - 1][jl] = s;
+  __syncthreads();
+  if (pl > 0 || j >= n) return;
+  s = ((s + red[0][jl]) + red[1][jl]) + red[2][jl];
+  // workspace element j = [c1][t][c2] with c2 the fastest (the "input channel" role of the launch)
+  const int d2 = swapped ? Cout : Cin;
+  const int c2 = (int)(j % d2);
+  const long r = j / d2;
+  const int t = (int)(r % 9);
+  const long c1 = r / 9;
+  const long dst = swapped ? ((long)c2 * Cin + c1) * 9 + (8 - t) : (c1 * Cin + c2) * 9 + t;
+  gw[dst] += s;
 }
 
 // gbias[c] += alpha * sum over (b, pixels) of gy (used when the gy stagers of the main kernel cannot provide it)
@@ -449,6 +479,8 @@ static bool dil_ok(int Cout, int W, int dil) {
   if (dil == 16) return cot == 2 && kg != 1;               // (the (1,4) unit with two margin groups exceeds the LDS)
   return false;
 }
+
+extern "C" long irr_conv2d_wgrad_x3_ws_elems(int Cin, int Cout) { return (Cin > 0 && Cout > 0) ? ws_capacity(Cin, Cout) : 0; }
 
 extern "C" int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil) {
   if (k != 3 || stride != 1 || B <= 0) return 0;
@@ -478,7 +510,6 @@ extern "C" int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* g
   if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (W % 8) || !dil_ok(Cout, W, dil)) return IRR_EINVAL;
   const long n = (long)Cout * Cin * 9;
   hipStream_t st = (hipStream_t)stream;
-  IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, st));
   WX3Args a;
   a.ws = ws; a.gbias = gbias; a.alpha = alpha;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.x_bs = x_bs; a.gy_bs = gy_bs;
@@ -500,9 +531,9 @@ extern "C" int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* g
       default: rc = launch_dil<2, 16>(a, kg, st); break;
     }
     if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_x3_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, st, ws, gw, Cin, Cout, 0, n, g_last_parts);
+    IRR_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(wgrad_unpack_x3_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, st, ws, gw, Cin, Cout, 0, n);
-  IRR_LAUNCH_CHECK();
   return 0;
 }
 
@@ -511,7 +542,6 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
   if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (W % 4)) return IRR_EINVAL;
   const long n = (long)Cout * Cin * 9;
   hipStream_t st = (hipStream_t)stream;
-  IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, st));
   const int kg = pick_kg(W);
   const int cot = (Cout + 31) / 32;
   // Cout <= 32: one co-tile cannot feed eight waves.  The correlation is symmetric in its operands,
@@ -552,9 +582,10 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
       rc = kg == 4 ? launch_wx3<3, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<3, 2, 2, 2>(a, st) : launch_wx3<3, 2, 1, 4>(a, st);
     }
     if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_x3_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, st, ws, gw, Cin, Cout, swapped ? 1 : 0, n,
+                       g_last_parts);
+    IRR_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(wgrad_unpack_x3_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, st, ws, gw, Cin, Cout, swapped ? 1 : 0, n);
-  IRR_LAUNCH_CHECK();
   if (swapped && gbias) {
     const int chunk = 8192;
     dim3 grid(irr_cdiv((long)H * W, chunk), Cout, B);
