@@ -503,8 +503,12 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
   __syncthreads();                                          // final barrier (pairs with the producers')
 }
 
+// 16-channel chunks of a layer.  Cin = 16 with one co-tile (the 16 -> 16 pyramid convs) is packed as TWO chunks, the second
+// with zero weights (the kernels re-read channels [Cin-16, Cin) for it): that is the shape conv_x3s_kernel is built for.
+static int x3_nchunk(int Cin, int Cout) { return (Cin == 16 && Cout <= 32) ? 2 : (Cin + 15) / 16; }
+
 static bool x3s_ok(int B, int Cin, int H, int W, int Cout, int dil) {
-  if (dil != 1 || Cout > 32 || Cin <= 16 || Cin > 32 || (W & 3)) return false;
+  if (dil != 1 || Cout > 32 || Cin < 16 || Cin > 32 || (W & 3)) return false;
   const long tiles = (long)B * ((H + 7) / 8) * ((W + 31) / 32);
   const double eff = (double)H * W / ((double)((H + 7) / 8) * ((W + 31) / 32) * 256);
   return eff >= 0.8 && (tiles >= 2048 || g_min_blocks == 0);
@@ -698,13 +702,13 @@ extern "C" int irr_conv_x3_set_min_blocks(int n) {
 }
 
 extern "C" long irr_conv_x3_packed_bytes(int Cin, int Cout) {
-  const long CoT = (Cout + 31) / 32, nchunk = (Cin + 15) / 16;
+  const long CoT = (Cout + 31) / 32, nchunk = x3_nchunk(Cin, Cout);
   return nchunk * 9 * 3 * CoT * 64 * 16;
 }
 
 extern "C" int irr_conv_pack_weights_x3(const float* w, void* wq, int Cin, int Cout, int transpose, void* stream) {
   if (!w || !wq || Cin < 16 || Cout <= 0) return IRR_EINVAL;
-  const int CoT = (Cout + 31) / 32, nchunk = (Cin + 15) / 16;
+  const int CoT = (Cout + 31) / 32, nchunk = x3_nchunk(Cin, Cout);
   const long nunits = (long)nchunk * 9 * CoT * 64;
   hipLaunchKernelGGL(pack_x3_kernel, dim3(irr_cdiv(nunits, 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)wq, Cin, Cout,
                      CoT, nchunk, transpose ? 1 : 0, 0, 0, 0, 0, nunits);
@@ -787,7 +791,7 @@ extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bi
   X3Args a;
   a.wq = (const u32x4*)wq; a.bias = bias;
   a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.dil = dil; a.RD = p.rd;
-  a.CoT = (Cout + 31) / 32; a.nchunk = (Cin + 15) / 16;
+  a.CoT = (Cout + 31) / 32; a.nchunk = x3_nchunk(Cin, Cout);
   a.x_bs = x_bs; a.y_bs = y_bs; a.res_bs = res_bs;
   a.lrelu = lrelu; a.accumulate = accumulate; a.alpha = alpha;
   a.mask_bs = mask_bs; a.nmask = nmask;

@@ -107,6 +107,7 @@ X3_CASES = [  # (Cin, Cout, dil, B, H, W): every block shape (CT=4/3/2/1), NT=7/
     (16, 565, 1, 1, 24, 28), (243, 128, 1, 1, 48, 56), (35, 96, 1, 1, 12, 58),
     # row-folded dilated patches (rows y = r mod dil form one block row set): dilation 8 / 16, heights not divisible by dil
     (128, 96, 8, 1, 50, 56), (96, 128, 8, 1, 48, 56), (64, 96, 16, 1, 90, 112), (128, 128, 2, 1, 25, 28), (128, 128, 4, 2, 30, 36),
+    (16, 16, 1, 2, 24, 64),                               # 16 -> 16 pyramid convs: two chunks, the second with zero weights
 ]
 
 
@@ -237,7 +238,7 @@ def test_conv_wgrad_x3_is_fp32_faithful(case, x3_everywhere):
     assert e_w <= 3e-6 and e_b <= 3e-6, (e_w, e_b)
 
 
-X3S_CASES = [(32, 32, 2, 24, 64), (32, 32, 1, 70, 92), (24, 32, 1, 16, 32), (32, 9, 2, 16, 96)]
+X3S_CASES = [(32, 32, 2, 24, 64), (32, 32, 1, 70, 92), (24, 32, 1, 16, 32), (32, 9, 2, 16, 96), (16, 16, 2, 24, 64), (16, 32, 1, 16, 96)]
 
 
 @pytest.mark.parametrize("case", X3S_CASES, ids=[f"{c[0]}to{c[1]}_{c[3]}x{c[4]}" for c in X3S_CASES])

@@ -64,6 +64,21 @@ def main():
                     del active[k]
                     break
     span = t1 - t0
+    per = {}
+    for name, s_, e_, a_, b_, c_, x_, y_, z_, st in rows:
+        v = per.setdefault(st, [s_, e_, 0, 0])
+        v[0] = min(v[0], s_); v[1] = max(v[1], e_); v[2] += e_ - s_; v[3] += 1
+    for st, v in sorted(per.items(), key=lambda kv: -kv[1][2]):
+        print(f"stream {st}: first start +{(v[0] - t0) / 1e6:.2f} ms, last end +{(v[1] - t0) / 1e6:.2f} ms, kernel time {v[2] / 1e6:.2f} ms, {v[3]} dispatches")
+    # tail: what runs in the last 12 ms of the step
+    tail = [(r[1], r[2], r[0], r[9]) for r in rows if r[2] > t1 - 12e6]
+    agg = {}
+    for s_, e_, nm, st in tail:
+        k = (st, short(nm)[:60])
+        a2 = agg.setdefault(k, [0, 0]); a2[0] += 1; a2[1] += e_ - max(s_, t1 - 12e6)
+    print("last 12 ms of the step:")
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"   stream {k[0]}  {v[1] / 1e6:6.2f} ms  {v[0]:4d}x  {k[1]}")
     print(f"step span {span / 1e6:.2f} ms: idle {idle / 1e6:.2f} ms, one kernel < 256 blocks {single_small / 1e6:.2f} ms, "
           f"one kernel >= 256 blocks {single_big / 1e6:.2f} ms, >= 2 kernels {multi / 1e6:.2f} ms  ({len(rows)} dispatches)")
     for k, v in sorted(small_by.items(), key=lambda kv: -kv[1])[:45]:
