@@ -154,10 +154,13 @@ int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bias, const f
 
 /* dW[co][ci][tap] += sum_{b,y,x} gy[b,co,y,x] * x[b,ci,y*stride+(ty-pad), x*stride+(tx-pad)]
  * gw is the plain (Cout,Cin,k,k) tensor and is ACCUMULATED into (caller zeroes it when it wants "=").
- * ws: caller-owned scratch of Cout*Cin*k*k floats (split-K partials land there with coalesced atomics in
- * [co][tap][ci] order and are then added to gw).
+ * ws: caller-owned scratch of irr_conv2d_wgrad_ws_elems(...) floats (same shape arguments): every block column of the
+ * split-K launch stores its partial [co][tap][ci] image there and a second kernel adds them to gw in a fixed order
+ * (no atomics, no zero-fill; the weight gradient is bit-reproducible).
  * gbias (nullable): gbias[co] += sum_{b,y,x} gy[b,co,y,x] (the bias gradient, taken from the staged gy tiles).
  * alpha scales both results (residual branches y = x + alpha*conv(t): models/irr_modules.py:51-53). */
+long irr_conv2d_wgrad_ws_elems(int B, int Cin, int H, int W, int Cout, int OH, int OW, int k, int stride, int dil,
+                               long x_bs, long gy_bs);
 int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                          int B, int Cin, int H, int W, int Cout, int OH, int OW,
                          int k, int stride, int dil, long x_bs, long gy_bs, void* stream);

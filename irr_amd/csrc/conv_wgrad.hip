@@ -30,7 +30,8 @@ constexpr int PITCH = KP + 1;
 struct WgArgs {
   const float* x;
   const float* gy;
-  float* gw;                    // workspace, [Cout][KK][Cin]
+  float* gw;                    // workspace, [grid.x][Cout][KK][Cin]: one partial result per block column (plain stores)
+  long n;                       // Cout * KK * Cin
   float* gbias;                 // optional: gbias[co] += sum of gy over pixels (taken from the staged gy tiles)
   float alpha;                  // scales both results (residual branches: y = x + alpha*conv(...))
   int B, Cin, H, W, Cout, OH, OW;
@@ -214,10 +215,13 @@ __global__ __launch_bounds__(MTB* KS * 64) void conv_wgrad_kernel(const WgArgs a
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (co >= a.Cout) continue;
-      // workspace layout [co][tap][ci]: lanes (ci) are contiguous -> one cache line per half-wave atomic
-      float* dst = a.gw + ((long)co * KK + ty_w * KS) * a.Cin + ci;
+      // workspace layout [block column][co][tap][ci]: lanes (ci) are contiguous; wgrad_reduce_kernel sums the columns
+      float* dst = a.gw + (long)blockIdx.x * a.n + ((long)co * KK + ty_w * KS) * a.Cin + ci;
 #pragma unroll
-      for (int t = 0; t < KS; ++t) unsafeAtomicAdd(dst + (long)t * a.Cin, a.alpha * acc[t][r]);
+      for (int t = 0; t < KS; ++t) {
+        if (a.n) dst[(long)t * a.Cin] = a.alpha * acc[t][r];
+        else unsafeAtomicAdd(dst + (long)t * a.Cin, a.alpha * acc[t][r]);      // IRR_WGRAD_ATOMIC=1: one shared, zeroed image
+      }
     }
   }
 }
@@ -411,9 +415,12 @@ __global__ __launch_bounds__(MTB * 3 * 64) void conv_wgrad_halo_kernel(const WgA
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (co >= a.Cout) continue;
-      float* dst = a.gw + ((long)co * KK + ty_w * KS) * a.Cin + ci;
+      float* dst = a.gw + (long)blockIdx.x * a.n + ((long)co * KK + ty_w * KS) * a.Cin + ci;
 #pragma unroll
-      for (int t = 0; t < KS; ++t) unsafeAtomicAdd(dst + (long)t * a.Cin, a.alpha * acc[t][r]);
+      for (int t = 0; t < KS; ++t) {
+        if (a.n) dst[(long)t * a.Cin] = a.alpha * acc[t][r];
+        else unsafeAtomicAdd(dst + (long)t * a.Cin, a.alpha * acc[t][r]);      // IRR_WGRAD_ATOMIC=1: one shared, zeroed image
+      }
     }
   }
 }
@@ -428,6 +435,10 @@ static int cu_count() {
   }
   return n;
 }
+
+// plan-only mode: the launch functions record their grid.x (= number of partial workspace images) and launch nothing
+static bool g_plan_only = false;
+static long g_parts = 0;
 
 template <int MTB, int KS>
 int launch(WgArgs a, hipStream_t st) {
@@ -450,6 +461,8 @@ int launch(WgArgs a, hipStream_t st) {
   if (cpb < 8) cpb = 8;
   a.chunks_per_block = (int)cpb;
   dim3 grid(irr_cdiv(nchunks, cpb), gy_, gz_);
+  g_parts = grid.x;
+  if (g_plan_only) return 0;
   hipLaunchKernelGGL((conv_wgrad_kernel<MTB, KS>), grid, dim3(MTB * KS * 64), 0, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
@@ -474,6 +487,8 @@ int launch_halo(WgArgs a, hipStream_t st) {
   if (cpb < 4) cpb = 4;
   a.chunks_per_block = (int)cpb;
   dim3 grid(irr_cdiv(ntiles, cpb), gy_, gz_);
+  g_parts = grid.x;
+  if (g_plan_only) return 0;
   hipLaunchKernelGGL((conv_wgrad_halo_kernel<MTB, TR>), grid, dim3(MTB * 3 * 64), 0, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
@@ -502,16 +517,25 @@ int dispatch(const WgArgs& a, hipStream_t st) {
   return launch<4, KS>(a, st);
 }
 
-// gw[co][ci][tap] += ws[co][tap][ci]
-__global__ __launch_bounds__(256) void wgrad_unpack_kernel(const float* __restrict__ ws, float* __restrict__ gw, int Cin,
-                                                          int KK, long n) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int tap = (int)(i % KK);
-  const long r = i / KK;
-  const int ci = (int)(r % Cin);
-  const long co = r / Cin;
-  gw[i] += ws[(co * KK + tap) * Cin + ci];
+// gw[co][ci][tap] += sum over the P block columns of ws[p][co][tap][ci]: 256 threads = 64 consecutive workspace elements
+// x 4 column lanes (coalesced reads), fixed summation order -> no atomics, no zeroed workspace, reproducible bits.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw, int Cin, int KK,
+                                                          long n, int P) {
+  __shared__ float red[3][64];
+  const int jl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const long j = (long)blockIdx.x * 64 + jl;
+  float s = 0.f;
+  if (j < n)
+    for (int p = pl; p < P; p += 4) s += ws[(long)p * n + j];
+  if (pl > 0) red[pl - 1][jl] = s;
+  __syncthreads();
+  if (pl > 0 || j >= n) return;
+  s = ((s + red[0][jl]) + red[1][jl]) + red[2][jl];
+  const int ci = (int)(j % Cin);
+  const long r = j / Cin;
+  const int tap = (int)(r % KK);
+  const long co = r / KK;
+  gw[(co * Cin + ci) * KK + tap] += s;
 }
 
 // gpre = gy * lrelu'(y) ; gbias[c] += sum_p gpre
@@ -574,6 +598,37 @@ __global__ __launch_bounds__(256) void dgrad_strided_kernel(const float* __restr
 
 }  // namespace
 
+// one batch slice through the kernel family (or, in plan-only mode, only its grid.x)
+static int wgrad_slice(const WgArgs& a, int k, int stride, int dil, hipStream_t st) {
+  const bool halo = (k == 3 && stride == 1 && dil == 1 && a.W >= 56 && !IRR_ENV_FLAG("IRR_WGRAD_NO_HALO"));
+  return halo ? dispatch_halo(a, st) : (k == 3) ? dispatch<3>(a, st) : dispatch<1>(a, st);
+}
+
+static long wgrad_batch_per(int B, int Cin, int H, int W, int Cout, long x_bs, long gy_bs) {
+  // 32-bit byte offsets inside the kernel: split the batch so both views stay below 2 GiB (see OOB)
+  const long lim = (1L << 29) - 64;                                  // elements
+  const long bsmax = x_bs > gy_bs ? x_bs : gy_bs;
+  long per = bsmax > 0 ? (lim - (long)(Cin > Cout ? Cin : Cout) * H * W) / bsmax : B;
+  if (per > B) per = B;
+  return per;
+}
+
+extern "C" long irr_conv2d_wgrad_ws_elems(int B, int Cin, int H, int W, int Cout, int OH, int OW, int k, int stride, int dil,
+                                          long x_bs, long gy_bs) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || (k != 1 && k != 3)) return 0;
+  WgArgs a{};
+  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW;
+  a.stride = stride; a.dil = dil; a.pad = ((k - 1) * dil) / 2;
+  const long per = wgrad_batch_per(B, Cin, H, W, Cout, x_bs, gy_bs);
+  if (per < 1) return 0;
+  a.B = (int)per;                                  // the largest slice has the most block columns
+  g_plan_only = true;
+  g_parts = 0;
+  const int rc = wgrad_slice(a, k, stride, dil, nullptr);
+  g_plan_only = false;
+  return rc ? 0 : g_parts * (long)Cout * Cin * k * k;
+}
+
 extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
                                     int Cin, int H, int W,
                                     int Cout, int OH, int OW, int k, int stride, int dil, long x_bs, long gy_bs,
@@ -582,28 +637,30 @@ extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
   if ((k != 1 && k != 3) || stride < 1 || dil < 1) return IRR_EINVAL;
   WgArgs a;
   const long n = (long)Cout * Cin * k * k;
-  IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, (hipStream_t)stream));
-  a.x = x; a.gy = gy; a.gw = ws; a.gbias = gbias; a.alpha = alpha;
+  const bool atomic = IRR_ENV_FLAG("IRR_WGRAD_ATOMIC");           // A/B switch: the earlier atomic flush into one image
+  if (atomic) IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, (hipStream_t)stream));
+  a.x = x; a.gy = gy; a.gw = ws; a.n = atomic ? 0 : n; a.gbias = gbias; a.alpha = alpha;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW;
   a.stride = stride; a.dil = dil; a.pad = ((k - 1) * dil) / 2;
   a.x_bs = x_bs; a.gy_bs = gy_bs; a.chunks_per_block = 0;
-  // 32-bit byte offsets inside the kernel: split the batch so both views stay below 4 GiB
-  const long lim = (1L << 29) - 64;                                  // elements: both views stay below 2 GiB (see OOB)
-  const long bsmax = x_bs > gy_bs ? x_bs : gy_bs;
-  long per = bsmax > 0 ? (lim - (long)(Cin > Cout ? Cin : Cout) * H * W) / bsmax : B;
+  const long per = wgrad_batch_per(B, Cin, H, W, Cout, x_bs, gy_bs);
   if (per < 1) return IRR_EINVAL;
-  if (per > B) per = B;
   for (int b0 = 0; b0 < B; b0 += (int)per) {
     a.B = (B - b0) < per ? (B - b0) : (int)per;
     a.x = x + (long)b0 * x_bs;
     a.gy = gy + (long)b0 * gy_bs;
-    const bool halo = (k == 3 && stride == 1 && dil == 1 && W >= 56 && !IRR_ENV_FLAG("IRR_WGRAD_NO_HALO"));
-    const int rc = halo ? dispatch_halo(a, (hipStream_t)stream)
-                        : (k == 3) ? dispatch<3>(a, (hipStream_t)stream) : dispatch<1>(a, (hipStream_t)stream);
+    const int rc = wgrad_slice(a, k, stride, dil, (hipStream_t)stream);
     if (rc) return rc;
+    if (!atomic) {
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, ws, gw, Cin, k * k, n,
+                         (int)g_parts);
+      IRR_LAUNCH_CHECK();
+    }
   }
-  hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ws, gw, Cin, k * k, n);
-  IRR_LAUNCH_CHECK();
+  if (atomic) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, ws, gw, Cin, k * k, n, 1);
+    IRR_LAUNCH_CHECK();
+  }
   return 0;
 }
 
