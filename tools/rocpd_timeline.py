@@ -70,6 +70,13 @@ def main():
         v[0] = min(v[0], s_); v[1] = max(v[1], e_); v[2] += e_ - s_; v[3] += 1
     for st, v in sorted(per.items(), key=lambda kv: -kv[1][2]):
         print(f"stream {st}: first start +{(v[0] - t0) / 1e6:.2f} ms, last end +{(v[1] - t0) / 1e6:.2f} ms, kernel time {v[2] / 1e6:.2f} ms, {v[3]} dispatches")
+    cnt = {}
+    for r in rows:
+        k = short(r[0])[:90]
+        c2 = cnt.setdefault(k, [0, 0]); c2[0] += 1; c2[1] += r[2] - r[1]
+    print("dispatches of the step by kernel (count, total ms):")
+    for k, v in sorted(cnt.items(), key=lambda kv: -kv[1][0])[:30]:
+        print(f"   {v[0]:5d}  {v[1] / 1e6:7.2f} ms  {k}")
     # tail: what runs in the last 12 ms of the step
     tail = [(r[1], r[2], r[0], r[9]) for r in rows if r[2] > t1 - 12e6]
     agg = {}
