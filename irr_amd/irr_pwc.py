@@ -27,9 +27,51 @@ from .modules import (ContextNetwork, FeatureExtractor, FlowEstimatorDense, OccC
                       OccUpsampleNetwork, RefineFlow, RefineOcc, WarpingLayer, conv, initialize_msra)
 
 
+class _SwapHalves(torch.autograd.Function):
+    """[a; b] -> [b; a] along the batch axis.  As one node its backward is ONE copy kernel (the same swap of the gradient)
+    instead of two zero-filled slice gradients, two copies and an add."""
+
+    @staticmethod
+    def forward(ctx, t):
+        b = t.shape[0] // 2
+        return torch.cat([t[b:], t[:b]], dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        b = g.shape[0] // 2
+        return torch.cat([g[b:], g[:b]], dim=0)
+
+
 def _swap_halves(t: torch.Tensor) -> torch.Tensor:
+    return _SwapHalves.apply(t) if t.requires_grad else torch.cat([t[t.shape[0] // 2:], t[:t.shape[0] // 2]], dim=0)
+
+
+class _SplitHalves(torch.autograd.Function):
+    """[a; b] -> (a, b) (views).  Backward: one concatenation of the two gradients (zeros for an unused half) instead of two
+    zero-filled full-size slice gradients and an add."""
+
+    @staticmethod
+    def forward(ctx, t):
+        b = t.shape[0] // 2
+        ctx.half = (b,) + tuple(t.shape[1:])
+        return t[:b], t[b:]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None and g2 is None:
+            return None
+        ref = g1 if g1 is not None else g2
+        z = None
+        if g1 is None or g2 is None:
+            z = torch.zeros(ctx.half, device=ref.device, dtype=ref.dtype)
+        return torch.cat([g1 if g1 is not None else z, g2 if g2 is not None else z], dim=0)
+
+
+def _split_halves(t: torch.Tensor):
+    if t.requires_grad:
+        return _SplitHalves.apply(t)
     b = t.shape[0] // 2
-    return torch.cat([t[b:], t[:b]], dim=0)
+    return t[:b], t[b:]
 
 
 class PWCNet(nn.Module):
@@ -81,6 +123,15 @@ class PWCNet(nn.Module):
     def mask_threshold(self, v: float) -> None:
         self.warping_layer.mask_threshold = float(v)
 
+    def _scale_tensors(self, s_loc, s_glb, dev):
+        """(1,2,1,1) device tensors of the per-level flow scales, uploaded once per (scales, device)"""
+        cache = self.__dict__.setdefault("_scale_cache", {})
+        key = (s_loc, s_glb, str(dev))
+        if key not in cache:
+            cache[key] = (torch.tensor(s_loc, device=dev, dtype=torch.float32).view(1, 2, 1, 1),
+                          torch.tensor(s_glb, device=dev, dtype=torch.float32).view(1, 2, 1, 1))
+        return cache[key]
+
     def _branch_stream(self, dev, level=0):
         """second HIP stream for the occlusion branch (experiment switch IRR_BRANCH_STREAMS=1; default: one stream)"""
         if not self.branch_streams or dev.type != "cuda" or level >= self.branch_levels:
@@ -100,7 +151,6 @@ class PWCNet(nn.Module):
         dev = x1_raw.device
 
         raw = torch.cat([x1_raw, x2_raw], dim=0)                 # [x1; x2]   (2B)
-        raw_o = _swap_halves(raw)                                # [x2; x1]
         pyr = self.feature_pyramid_extractor(raw) + [raw]        # coarsest first; both images in one pass
 
         def warp(x, fl):
@@ -127,8 +177,7 @@ class PWCNet(nn.Module):
 
                 s_loc = (float(w / W / div), float(h / H / div))      # to_local  (pwc_modules.py:72-73)
                 s_glb = (float(W * div / w), float(H * div / h))      # to_global (pwc_modules.py:75-76)
-                t_loc = flow.new_tensor(s_loc).view(1, 2, 1, 1)
-                t_glb = flow.new_tensor(s_glb).view(1, 2, 1, 1)
+                t_loc, t_glb = self._scale_tensors(s_loc, s_glb, dev)
                 flow = flow * t_loc
 
                 # estimator + "est = flow + res" + cat([x_intm, est]) in one cat-free node (conv.dense_estimator)
@@ -167,21 +216,21 @@ class PWCNet(nn.Module):
                     occ_cont.record_stream(pending_join[0])
                 occ = self.refine_occ(occ_cont.detach(), x_1by1, x_1by1 - x_1by1_o_warp)
 
-                flows.append([flow_cont[:B], flow_cont[B:], flow[:B], flow[B:]])
-                occs.append([occ_cont[:B], occ_cont[B:], occ[:B], occ[B:]])
+                flows.append([*_split_halves(flow_cont), *_split_halves(flow)])
+                occs.append([*_split_halves(occ_cont), *_split_halves(occ)])
             else:
                 flow = Fn.resize_bilinear_ac(flow, h, w)
-                flows.append([flow[:B], flow[B:]])
+                flows.append(list(_split_halves(flow)))
                 xo_warp = warp(xo, flow)
                 flow_o_warp = warp(_swap_halves(flow), flow)
                 if l != self.num_levels - 1:
                     # conv_1x1_1 on x and on the warped other image: one launch over the 4B batch
                     both = self.conv_1x1_1(torch.cat([x, xo_warp], dim=0))
-                    x_in, xo_w_in = both[:2 * B], both[2 * B:]
+                    x_in, xo_w_in = _split_halves(both)
                 else:
                     x_in, xo_w_in = x, xo_warp
                 occ = self.occ_shuffle_upsample(occ, torch.cat([x_in, xo_w_in, flow, flow_o_warp], dim=1))
-                occs.append([occ[:B], occ[B:]])
+                occs.append(list(_split_halves(occ)))
 
         if self.training:
             return {'flow': flows, 'occ': occs}
