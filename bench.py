@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--prealloc-gb", type=float, default=-1.0,
+                    help="device memory reserved in the caching allocator before the first step (one block, split on demand), so that "
+                         "no hipMalloc lands in the timed steps; default: 30 %% of the device (86 GB on MI355X), 0 = off")
     ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU")
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=448)
@@ -108,6 +111,12 @@ def main():
     from irr_amd.train import ModelAndLoss, TrainStep
     from irr_amd.optim import FusedAdam
 
+    pre_gb = a.prealloc_gb if a.prealloc_gb >= 0 else 0.30 * torch.cuda.get_device_properties(device).total_memory / 1e9
+    if pre_gb > 0:
+        # a step peaks at 39 GB allocated / 69 GB reserved (bs32, 384x448): the pool would otherwise still grow by a few
+        # segments during the first timed steps
+        blk = torch.empty(int(pre_gb * 1e9), dtype=torch.uint8, device=device)
+        del blk
     args = types.SimpleNamespace(batch_size=a.batch, model_div_flow=0.05)
     torch.manual_seed(0)                                     # same MSRA init on every rank
     model = irr_amd.PWCNet(args).to(device).train()
@@ -126,8 +135,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    marks = [] if os.environ.get("IRR_BENCH_STEPTIMES") else None      # diagnostic: per-step GPU time (events, no extra syncs)
+
+    def mark():
+        if marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((time.perf_counter(), ev))
+
     for _ in range(a.warmup):
+        mark()
         step(batch)
+    seg0 = torch.cuda.memory_stats(device).get("segment.all.allocated", 0) if marks is not None else 0
     timer = None
     if not a.no_kernel_timer:
         timer = C.KernelTimer()
@@ -135,9 +154,19 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        mark()
         ld, _, _ = step(batch)
+    mark()
     barrier()
     dt = time.perf_counter() - t0
+    if marks is not None and rank == 0:
+        print("per-step ms (gpu / cpu issue), first %d are warm-up: " % a.warmup +
+              " ".join("%.1f/%.1f" % (m0[1].elapsed_time(m1[1]), 1e3 * (m1[0] - m0[0])) for m0, m1 in zip(marks[:-1], marks[1:])),
+              file=sys.stderr)
+        st = torch.cuda.memory_stats(device)
+        print("allocator: segments created in the timed steps %d (total %d), retries %d, peak allocated %.1f GB, reserved %.1f GB"
+              % (st.get("segment.all.allocated", 0) - seg0, st.get("segment.all.allocated", 0), st.get("num_alloc_retries", 0),
+                 torch.cuda.max_memory_allocated(device) / 1e9, torch.cuda.max_memory_reserved(device) / 1e9), file=sys.stderr)
     C.TIMER = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
