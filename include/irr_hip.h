@@ -151,6 +151,16 @@ int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bias, const f
                       long x_bs, long y_bs, long res_bs,
                       int lrelu, float alpha, int accumulate,
                       const float* mask, long mask_bs, int nmask, void* stream);
+/* Small pyramid levels (launches of fewer blocks than the chip has slots): the same kernel with blockIdx.z splitting the
+ * 16-channel chunks (K); the slices store raw partial sums into ws and a second kernel sums them and applies the epilogue.
+ * irr_conv2d_fwd_x3_ws_elems: floats of scratch the problem needs (0 = runs unsplit, use irr_conv2d_fwd_x3).
+ * irr_conv2d_fwd_x3 itself never splits (without scratch the problem runs unsplit: same results class, slower). */
+long irr_conv2d_fwd_x3_ws_elems(int B, int Cin, int H, int W, int Cout, int dil);
+int irr_conv2d_fwd_x3_splitk(const float* x, const void* wq, const float* bias, const float* res, float* y,
+                             int B, int Cin, int H, int W, int Cout, int dil,
+                             long x_bs, long y_bs, long res_bs,
+                             int lrelu, float alpha, int accumulate,
+                             const float* mask, long mask_bs, int nmask, float* ws, long ws_elems, void* stream);
 
 /* dW[co][ci][tap] += sum_{b,y,x} gy[b,co,y,x] * x[b,ci,y*stride+(ty-pad), x*stride+(tx-pad)]
  * gw is the plain (Cout,Cin,k,k) tensor and is ACCUMULATED into (caller zeroes it when it wants "=").

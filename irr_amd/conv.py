@@ -149,6 +149,19 @@ def packed_weights_x3(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # primitives (no autograd)
 # ----------------------------------------------------------------------------------------------
+def _call_conv(args) -> None:
+    """Launch a conv entry point from its argument tuple.  irr_conv2d_fwd_x3 problems that are too small to fill the chip
+    get a scratch buffer and run through the K-split entry point (csrc/conv_x3.hip: blockIdx.z splits the channel chunks)."""
+    if args[0] == "irr_conv2d_fwd_x3":
+        B, cin, H, W, cout, dil = args[6:12]
+        n = hip.lib().irr_conv2d_fwd_x3_ws_elems(B, cin, H, W, cout, dil)
+        if n > 0:
+            ws = torch.empty(n, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+            hip.call("irr_conv2d_fwd_x3_splitk", *args[1:-1], ws.data_ptr(), n, args[-1])
+            return
+    hip.call(*args)
+
+
 def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, dil: int,
                  lrelu: bool, out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                  alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
@@ -194,11 +207,11 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                 int(lrelu), float(alpha), int(accumulate), None, 0, 0, hip.stream())
         variant = None
     if TIMER is None:
-        hip.call(*args)
+        _call_conv(args)
     else:
         if variant is None:
             variant = hip.lib().irr_conv2d_fwd_variant(B, cout, oh, ow, k)
-        TIMER.wrap(variant, 2.0 * B * oh * ow * cout * cin * k * k, lambda: hip.call(*args))
+        TIMER.wrap(variant, 2.0 * B * oh * ow * cout * cin * k * k, lambda: _call_conv(args))
     return out
 
 
@@ -256,11 +269,11 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                     int(accumulate), *margs, hip.stream())
             variant = None
         if TIMER is None:
-            hip.call(*args)
+            _call_conv(args)
         else:
             if variant is None:
                 variant = hip.lib().irr_conv2d_fwd_variant(B, cin, H, W, k)
-            TIMER.wrap(variant, 2.0 * B * H * W * cout * cin * k * k, lambda: hip.call(*args), "dgrad")
+            TIMER.wrap(variant, 2.0 * B * H * W * cout * cin * k * k, lambda: _call_conv(args), "dgrad")
     elif stride == 2 and k == 3 and dil == 1 and H == 2 * oh and W == 2 * ow and cout >= 2:
         # transposed stride-2 conv == stride-1 conv (flipped weights) of the zero-interleaved gradient
         z = torch.zeros(B, cout, H, W, device=gy.device, dtype=torch.float32)
@@ -546,9 +559,9 @@ class _DenseEstimatorFn(torch.autograd.Function):
                         t1 - t0, H, W, 3, 1, 1, hip.bs(G), hip.bs(G), 0, 0, 1.0, 1, *margs, hip.stream())
                 variant = hip.lib().irr_conv2d_fwd_variant(B, t1 - t0, H, W, 3)
             if TIMER is None:
-                hip.call(*args)
+                _call_conv(args)
             else:
-                TIMER.wrap(variant, 2.0 * B * H * W * t0 * (t1 - t0) * 9, lambda: hip.call(*args), "dgrad")
+                TIMER.wrap(variant, 2.0 * B * H * W * t0 * (t1 - t0) * 9, lambda: _call_conv(args), "dgrad")
             if not last:                                   # G[:, t0:t1] is now the pre-activation gradient of conv(4-k_)
                 i = 3 - k_
                 grads_w[i], grads_b[i] = wgrad_param(buf[:, t1:ctot], G[:, t0:t1], ctx.wobjs[i], ctx.bobjs[i], 1, 1)

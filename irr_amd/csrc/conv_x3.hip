@@ -54,6 +54,8 @@ struct X3Args {
   const float* mask;
   long mask_bs;
   int nmask;
+  int ksplit;                              // > 1 (small pyramid levels): blockIdx.z walks a slice of the 16-channel chunks and
+  float* part;                             // stores raw partial sums part[kz][b][co][pixel]; x3_splitk_epilogue_kernel finishes
 };
 
 
@@ -147,9 +149,10 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
     for (int p = 0; p < 3; ++p)
       wa[slot][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)wvoff, (int)(so + p * wpiece), 0));
   };
-  if (active) issue_w(0, 0, 0);
+  const int c_begin = (int)(((long)blockIdx.z * a.nchunk) / a.ksplit), c_end = (int)(((long)(blockIdx.z + 1) * a.nchunk) / a.ksplit);
+  if (active) issue_w(0, c_begin, 0);
 
-  for (int c = 0; c < a.nchunk; ++c) {
+  for (int c = c_begin; c < c_end; ++c) {
     // load the chunk's halo patch, split it into its three bf16 pieces and publish it.  (No register prefetch across
     // the MFMA phase: 128 of the wave's 256 registers are accumulators; the second block on the CU covers the wait.)
     issue_x(c);
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
       }
     }
     __syncthreads();
-    const bool more = c + 1 < a.nchunk;
+    const bool more = c + 1 < c_end;
     if (active) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
@@ -216,6 +219,15 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
     const int oys = y0 + row, ox = x0 + col;
     if (oys >= Hs || ox >= a.W) continue;
     const long pofs = (long)(rr + oys * a.RD) * a.W + ox;
+    if (a.ksplit > 1) {                      // raw partial sums of this chunk slice; the epilogue runs in a second kernel
+      float* pb = a.part + (((long)blockIdx.z * a.B + b) * a.Cout) * ohw + pofs;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (co < a.Cout) pb[(long)co * ohw] = acc[s][r];
+      }
+      continue;
+    }
     float* yb = a.y + (long)b * a.y_bs + pofs;
     const float* rb = a.res ? a.res + (long)b * a.res_bs + pofs : nullptr;
     const float* mb = a.mask ? a.mask + (long)b * a.mask_bs + pofs : nullptr;
@@ -585,7 +597,7 @@ int launch_x3(X3Args& a, const TileCfg& t, hipStream_t st) {
   const int Hs = (a.H + a.RD - 1) / a.RD;
   a.tiles_x = (a.W + t.tc - 1) / t.tc;
   a.tiles_y = (Hs + t.tr - 1) / t.tr;
-  dim3 grid((unsigned)((long)a.B * a.RD * a.tiles_x * a.tiles_y), (unsigned)((a.CoT + CT - 1) / CT), 1);
+  dim3 grid((unsigned)((long)a.B * a.RD * a.tiles_x * a.tiles_y), (unsigned)((a.CoT + CT - 1) / CT), (unsigned)a.ksplit);
   hipLaunchKernelGGL((conv_x3_kernel<CT, PG, NT, PLANE_PIX>), grid, dim3(CT * PG * 64), 0, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
@@ -601,7 +613,7 @@ static int pick_ct(int CoT) {
   return 4;
 }
 
-struct Plan { int ct, pg, plane, rd; TileCfg t; long blocks; double eff; };
+struct Plan { int ct, pg, plane, rd, ksplit; TileCfg t; long blocks; double eff; };
 
 // rd = 1: plain (TR + 2 dil) x (TC + 2 dil) halo patches.  rd = dil: rows folded by residue class, the patch is
 // (TR + 2) x (TC + 2 dil) -- the only way a dilation-8/16 patch fits the LDS planes, and a smaller halo for 2 and 4.
@@ -666,6 +678,16 @@ static bool make_plan_rd(int B, int Cin, int H, int W, int Cout, int dil, int rd
   }
   // padded work must stay close to the real work
   p->eff = (double)H * W / ((double)rd * ntiles(p->t) * p->t.tr * p->t.tc);
+  // small pyramid levels: too few tiles to fill the chip -> blockIdx.z additionally splits the 16-channel chunks (K); the
+  // partial sums meet in x3_splitk_epilogue_kernel.  At least two chunks per slice, about two blocks per CU in total.
+  p->ksplit = 1;
+  if (g_min_blocks > 0 && p->blocks < g_min_blocks && !IRR_ENV_FLAG("IRR_X3_NO_SPLITK")) {
+    const int nchunk = x3_nchunk(Cin, Cout);
+    long ks = (512 + p->blocks - 1) / p->blocks;
+    if (ks > nchunk / 2) ks = nchunk / 2;
+    if (ks > 16) ks = 16;
+    if (ks >= 2) p->ksplit = (int)ks;
+  }
   return p->eff >= 0.70;
 }
 
@@ -734,13 +756,49 @@ extern "C" int irr_conv2d_x3_eligible(int B, int Cin, int H, int W, int Cout, in
   if (x3s_ok(B, Cin, H, W, Cout, dil)) return 9001;                       // streaming 32-channel kernel
   Plan p;
   if (!make_plan(B, Cin, H, W, Cout, dil, &p)) return 0;
-  if (p.blocks < g_min_blocks) return 0;            // tiny pyramid levels stay on the fp32 split-K kernel
+  if (p.blocks * p.ksplit < g_min_blocks / 2) return 0;       // launches that cannot fill half the chip even with a K split: fp32 split-K kernel
   return p.ct * 1000 + p.pg * 100 + p.t.nt * 10 + (p.plane == 352 ? 1 : p.plane == 616 ? 2 : 3);
 }
 
-extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bias, const float* res, float* y, int B,
-                                 int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
-                                 float alpha, int accumulate, const float* mask, long mask_bs, int nmask, void* stream) {
+// finishes a K-split launch: y = epilogue(sum over the slices of part[kz][b][co][pixel])  (same order of operations as the
+// epilogue of conv_x3_kernel: bias, LeakyReLU, residual / alpha, accumulate, LeakyReLU'-mask)
+__global__ __launch_bounds__(256) void x3_splitk_epilogue_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                                const float* __restrict__ res, float* __restrict__ y,
+                                                                const float* __restrict__ mask, int B, int Cout, long hw, int ksplit,
+                                                                long y_bs, long res_bs, long mask_bs, int nmask, int lrelu,
+                                                                float alpha, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)B * Cout * hw;
+  if (i >= n) return;
+  const long pix = i % hw;
+  const long r = i / hw;
+  const int co = (int)(r % Cout);
+  const long b = r / Cout;
+  float v = 0.f;
+  for (int k = 0; k < ksplit; ++k) v += part[(long)k * n + i];
+  v += bias ? bias[co] : 0.f;
+  if (lrelu) v = irr_lrelu(v);
+  const long o = (long)co * hw + pix;
+  if (res) v = res[b * res_bs + o] + alpha * v;
+  else v *= alpha;
+  float* dst = y + b * y_bs + o;
+  if (accumulate) v += *dst;
+  if (mask && co < nmask) v *= irr_lrelu_grad(mask[b * mask_bs + o]);
+  *dst = v;
+}
+
+// floats of scratch a K-split launch needs (0: the problem runs unsplit)
+extern "C" long irr_conv2d_fwd_x3_ws_elems(int B, int Cin, int H, int W, int Cout, int dil) {
+  if (B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1 || x3s_ok(B, Cin, H, W, Cout, dil)) return 0;
+  Plan p;
+  if (!make_plan(B, Cin, H, W, Cout, dil, &p) || p.ksplit <= 1) return 0;
+  return (long)p.ksplit * B * Cout * H * W;
+}
+
+static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const float* res, float* y, int B,
+                       int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
+                       float alpha, int accumulate, const float* mask, long mask_bs, int nmask, float* ws, long ws_elems,
+                       void* stream) {
   if (!x || !wq || !y || B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1) return IRR_EINVAL;
   if (x3s_ok(B, Cin, H, W, Cout, dil)) {
     X3SArgs s;
@@ -795,6 +853,8 @@ extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bi
   a.x_bs = x_bs; a.y_bs = y_bs; a.res_bs = res_bs;
   a.lrelu = lrelu; a.accumulate = accumulate; a.alpha = alpha;
   a.mask_bs = mask_bs; a.nmask = nmask;
+  a.ksplit = (ws && (long)p.ksplit * B * Cout * H * W <= ws_elems) ? p.ksplit : 1;     // no scratch: run unsplit (slower, same result class)
+  a.part = ws;
   // 32-bit byte voffsets below the 2 GiB out-of-range marker: split the batch accordingly
   const long lim = (1L << 29) - (long)(Cin + 16) * H * W - 64;        // elements
   if (lim <= 0) return IRR_EINVAL;
@@ -829,6 +889,27 @@ extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bi
       default: return IRR_EINVAL;
     }
     if (rc) return rc;
+    if (a.ksplit > 1) {
+      const long n = (long)a.B * Cout * H * W;
+      hipLaunchKernelGGL(x3_splitk_epilogue_kernel, dim3((unsigned)irr_cdiv(n, 256)), dim3(256), 0, st, ws, bias, a.res, a.y, a.mask, a.B,
+                         Cout, (long)H * W, a.ksplit, y_bs, res_bs, mask_bs, nmask, lrelu, alpha, accumulate);
+      IRR_LAUNCH_CHECK();
+    }
   }
   return 0;
+}
+
+extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bias, const float* res, float* y, int B,
+                                 int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
+                                 float alpha, int accumulate, const float* mask, long mask_bs, int nmask, void* stream) {
+  return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, accumulate, mask, mask_bs, nmask,
+                     nullptr, 0, stream);
+}
+
+extern "C" int irr_conv2d_fwd_x3_splitk(const float* x, const void* wq, const float* bias, const float* res, float* y, int B,
+                                        int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
+                                        float alpha, int accumulate, const float* mask, long mask_bs, int nmask, float* ws,
+                                        long ws_elems, void* stream) {
+  return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, accumulate, mask, mask_bs, nmask,
+                     ws, ws_elems, stream);
 }

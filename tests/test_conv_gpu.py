@@ -275,6 +275,45 @@ def test_conv_x3_streaming_kernel_epilogues(case, x3_everywhere):
         assert (gx.cpu().double() - ref).abs().max().item() <= 2e-6 * float(ref.abs().max())
 
 
+X3K_CASES = [(565, 128, 1, 64, 12, 14), (128, 128, 2, 64, 12, 14), (467, 64, 1, 64, 24, 28), (115, 128, 1, 64, 12, 14)]
+
+
+@pytest.mark.parametrize("case", X3K_CASES, ids=[f"{c[0]}to{c[1]}d{c[2]}_{c[4]}x{c[5]}" for c in X3K_CASES])
+def test_conv_x3_k_split_small_levels(case):
+    """Small pyramid levels at the BASELINE batch (default routing): conv_x3_kernel with blockIdx.z splitting the channel
+    chunks + x3_splitk_epilogue_kernel.  Forward with bias + LeakyReLU, residual + alpha, accumulate, and the data gradient
+    with accumulate + LeakyReLU'-mask, against fp64."""
+    from irr_amd import conv as C, hip
+    cin, cout, dil, B, H, W = case
+    assert hip.lib().irr_conv2d_fwd_x3_ws_elems(B, cin, H, W, cout, dil) > 0, "case must take the K-split path"
+    assert C.x3_code(B, cin, H, W, cout, 3, 1, dil) != 0
+    g = torch.Generator().manual_seed(cin + 3 * cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(B, cout, H, W, generator=g)
+    base = torch.randn(B, cout, H, W, generator=g)
+    conv = F.conv2d(x.double(), w.double(), b.double(), padding=dil, dilation=dil)
+    tol = 3e-6 * float(conv.abs().max())
+    y = C.conv_forward(x.cuda(), w.cuda(), b.cuda(), 1, dil, True)
+    assert (y.cpu().double() - F.leaky_relu(conv, 0.1)).abs().max().item() <= tol
+    y = C.conv_forward(x.cuda(), w.cuda(), b.cuda(), 1, dil, False, res=res.cuda(), alpha=0.1)
+    assert (y.cpu().double() - (res.double() + 0.1 * conv)).abs().max().item() <= tol
+    acc = base.clone().cuda()
+    C.conv_forward(x.cuda(), w.cuda(), None, 1, dil, False, out=acc, accumulate=True)
+    ref = base.double() + F.conv2d(x.double(), w.double(), None, padding=dil, dilation=dil)
+    assert (acc.cpu().double() - ref).abs().max().item() <= tol
+    if hip.lib().irr_conv2d_fwd_x3_ws_elems(B, cout, H, W, cin, dil) > 0:
+        gy = torch.randn(B, cout, H, W, generator=g)
+        g0 = torch.randn(B, cin, H, W, generator=g)
+        m2 = torch.randn(B, cin, H, W, generator=g)
+        gx = g0.clone().cuda()
+        C.conv_dgrad(gy.cuda(), w.cuda(), 1, dil, (H, W), gx=gx, accumulate=True, mask=m2.cuda(), nmask=cin)
+        gref = (g0.double() + torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=dil, dilation=dil)) * \
+            torch.where(m2 > 0, 1.0, 0.1).double()
+        assert (gx.cpu().double() - gref).abs().max().item() <= 3e-6 * float(gref.abs().max())
+
+
 @pytest.mark.parametrize("cout,dil", [(2, 1), (1, 1), (2, 2), (1, 4)])
 def test_conv_smallco_dgrad_accumulate_mask(cout, dil):
     """irr_conv2d_smallco_dgrad_f32 (the conv_last / context-tail data gradient): plain, and accumulate + LeakyReLU'-mask

@@ -27,6 +27,9 @@ PERF = [  # name, cin, cout, dil, B, H, W
     ("ctx d8 L4", 128, 96, 8, 64, 96, 112), ("ctx d16 L4", 96, 64, 16, 64, 96, 112), ("ctx d8 dgrad L4", 96, 128, 8, 64, 96, 112),
     ("ctx d16 dgrad L4", 64, 96, 16, 64, 96, 112), ("ctx d8 L3", 128, 96, 8, 64, 48, 56), ("ctx d2 L3", 128, 128, 2, 64, 48, 56),
     ("ctx d4 L3", 128, 128, 4, 64, 48, 56), ("ctx d16 L3", 96, 64, 16, 64, 48, 56),
+    ("ksplit ctx.conv0 L1", 565, 128, 1, 64, 12, 14), ("ksplit dense.conv1 L1", 115, 128, 1, 64, 12, 14), ("ksplit dense.conv2 L1", 243, 128, 1, 64, 12, 14),
+    ("ksplit dense.conv3 L1", 371, 96, 1, 64, 12, 14), ("ksplit dense.conv4 L1", 467, 64, 1, 64, 12, 14), ("ksplit ctx d2 L1", 128, 128, 2, 64, 12, 14),
+    ("ksplit dgrad ctx0 L1", 128, 565, 1, 64, 12, 14), ("ksplit dense.conv4 L2b", 467, 64, 1, 64, 24, 28), ("ksplit dense.conv3 L2b", 371, 96, 1, 64, 24, 28),
 ]
 if os.environ.get("X3_ONLY"):
     PERF = [p for p in PERF if os.environ["X3_ONLY"] in p[0]]
