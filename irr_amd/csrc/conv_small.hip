@@ -273,15 +273,12 @@ template <int NC>
 __global__ __launch_bounds__(256) void conv_smallco_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                  float* __restrict__ ws, float* __restrict__ gbias, float alpha,
                                                                  int Cin, int H, int W, long x_bs, long gy_bs,
-                                                                 int quads_per_block) {
+                                                                 int quads_per_block, int B, int bpb) {
   const long hw = (long)H * W;
   const long nq = hw / 4;
-  const int ci = blockIdx.y, b = blockIdx.z;
+  const int ci = blockIdx.y;
   const long q0 = (long)blockIdx.x * quads_per_block;
   const long q1 = min(nq, q0 + quads_per_block);
-  const __amdgpu_buffer_rsrc_t xr =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * x_bs + (long)ci * hw), (short)0, (int)SOOB, 0x00020000);
-  const float* gb = gy + (long)b * gy_bs;
   float acc[NC][9];
   float bsum[NC];
 #pragma unroll
@@ -290,8 +287,12 @@ __global__ __launch_bounds__(256) void conv_smallco_wgrad4_kernel(const float* _
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
   }
-  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)gb, (short)0, (int)SOOB, 0x00020000);
   const uint32_t hw4 = (uint32_t)(hw * 4);
+  // bpb samples per block (small pyramid levels: one sample has too few quads to amortise the block reduction)
+  for (int b = blockIdx.z * bpb; b < min(B, (int)(blockIdx.z + 1) * bpb); ++b) {
+  const __amdgpu_buffer_rsrc_t xr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * x_bs + (long)ci * hw), (short)0, (int)SOOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)(gy + (long)b * gy_bs), (short)0, (int)SOOB, 0x00020000);
   for (long qb = q0; qb < q1; qb += 256) {                 // wave-uniform trip count: the side pixels travel between lanes
     const long q = qb + threadIdx.x;
     const bool act = q < q1, inimg = q < nq;
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(256) void conv_smallco_wgrad4_kernel(const float* _
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[c][r * 3 + t] = fmaf(g[c][i], v[i + t], acc[c][r * 3 + t]);
     }
+  }
   }
   __shared__ float red[4][NC * 9];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -581,11 +583,15 @@ extern "C" int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, flo
   if (ppb < 1024) ppb = 1024;
   if (k == 3 && dil == 1 && (W & 3) == 0 && Cout <= 2 && ((x_bs | gy_bs) & 3) == 0 && !IRR_ENV_FLAG("IRR_SMALLCO_SCALAR")) {
     const long qpb = (ppb + 3) / 4;
-    dim3 grid4(irr_cdiv(hw / 4, qpb), Cin, B);
+    // at least ~8 quads per thread and block: several samples per block at the small pyramid levels
+    int bpb = (int)((8 * 256 + hw / 4 - 1) / (hw / 4));
+    if (bpb < 1) bpb = 1;
+    while (bpb > 1 && (long)Cin * irr_cdiv(B, bpb) < 1024) --bpb;          // keep the chip filled
+    dim3 grid4(irr_cdiv(hw / 4, qpb), Cin, irr_cdiv(B, bpb));
     if (Cout == 1)
-      hipLaunchKernelGGL((conv_smallco_wgrad4_kernel<1>), grid4, dim3(256), 0, st, x, gy, ws, gbias, alpha, Cin, H, W, x_bs, gy_bs, (int)qpb);
+      hipLaunchKernelGGL((conv_smallco_wgrad4_kernel<1>), grid4, dim3(256), 0, st, x, gy, ws, gbias, alpha, Cin, H, W, x_bs, gy_bs, (int)qpb, B, bpb);
     else
-      hipLaunchKernelGGL((conv_smallco_wgrad4_kernel<2>), grid4, dim3(256), 0, st, x, gy, ws, gbias, alpha, Cin, H, W, x_bs, gy_bs, (int)qpb);
+      hipLaunchKernelGGL((conv_smallco_wgrad4_kernel<2>), grid4, dim3(256), 0, st, x, gy, ws, gbias, alpha, Cin, H, W, x_bs, gy_bs, (int)qpb, B, bpb);
     IRR_LAUNCH_CHECK();
     hipLaunchKernelGGL(smallco_unpack_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, st, ws, gw, Cin, 9, n);
     IRR_LAUNCH_CHECK();
