@@ -285,6 +285,15 @@ def test_conv_x3_k_split_small_levels(case):
     with accumulate + LeakyReLU'-mask, against fp64."""
     from irr_amd import conv as C, hip
     cin, cout, dil, B, H, W = case
+    C.x3_code(1, 64, 8, 8, 64, 3, 1, 1)                       # (applies IRR_X3_MIN_BLOCKS once, if set)
+    old = hip.lib().irr_conv_x3_set_min_blocks(384)          # the K split belongs to the default routing
+    try:
+        _k_split_checks(C, hip, cin, cout, dil, B, H, W)
+    finally:
+        hip.lib().irr_conv_x3_set_min_blocks(old)
+
+
+def _k_split_checks(C, hip, cin, cout, dil, B, H, W):
     assert hip.lib().irr_conv2d_fwd_x3_ws_elems(B, cin, H, W, cout, dil) > 0, "case must take the K-split path"
     assert C.x3_code(B, cin, H, W, cout, 3, 1, dil) != 0
     g = torch.Generator().manual_seed(cin + 3 * cout)
