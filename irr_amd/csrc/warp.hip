@@ -94,6 +94,10 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
   }
 }
 
+// Backward: gather for gflow, atomic scatter for gx.  The scatter is bound by the atomic rate (~200 G/s), so horizontally
+// adjacent pixels share their work: when the right-hand targets (ne, se) of lane L-1 are the left-hand targets (nw, sw) of
+// lane L -- the normal case for a smooth flow -- lane L adds both contributions and issues ONE atomic per address: two
+// atomics per pixel and channel instead of four (one ds_bpermute of the output gradient per channel).
 __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ flow,
                                                       const float* __restrict__ gridx, const float* __restrict__ gridy,
                                                       const float* __restrict__ gout, float* __restrict__ gx,
@@ -102,39 +106,52 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
                                                       float den_w, float den_h, float div_flow, float mask_thr) {
   const long plane = (long)H * W;
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= plane) return;
+  const bool act = p < plane;
+  const long pp = act ? p : plane - 1;
+  const int lane = threadIdx.x & 63;
   const int b = blockIdx.z;
-  const int yy = (int)(p / W), xx = (int)(p - (long)yy * W);
+  const int yy = (int)(pp / W), xx = (int)(pp - (long)yy * W);
   const float* fl = flow + (long)b * flow_bs;
-  const Taps t = make_taps(fl[p], fl[plane + p], gridx[xx], gridy[yy], H, W, den_w, den_h, div_flow, mask_thr);
+  const Taps t = make_taps(fl[pp], fl[plane + pp], gridx[xx], gridy[yy], H, W, den_w, den_h, div_flow, mask_thr);
+  const bool on = act && t.mask != 0.f;
+  const long o_nw = (long)t.y0 * W + t.x0;
+  // effective scatter weights (0 = nothing to add) and the hand-over between neighbouring lanes
+  const float wnw = (on && t.in_nw) ? t.nw : 0.f, wne = (on && t.in_ne) ? t.ne : 0.f;
+  const float wsw = (on && t.in_sw) ? t.sw : 0.f, wse = (on && t.in_se) ? t.se : 0.f;
+  const int lx0 = __shfl_up(t.x0, 1, 64), ly0 = __shfl_up(t.y0, 1, 64);
+  const float lwne = __shfl_up(wne, 1, 64), lwse = __shfl_up(wse, 1, 64);
+  const bool take = lane > 0 && act && lx0 + 1 == t.x0 && ly0 == t.y0 && (lwne != 0.f || lwse != 0.f);   // I add the left lane's ne / se
+  const bool given = __shfl_down((int)take, 1, 64) != 0 && lane < 63;                                       // my ne / se go to the right lane
+  const float tne = take ? lwne : 0.f, tse = take ? lwse : 0.f;
+  // the left lane's targets are inside the image by its own flags; they are the addresses o_nw / o_nw + W of this lane
+  const bool do_nw = wnw != 0.f || tne != 0.f, do_sw = wsw != 0.f || tse != 0.f;
+  const bool do_ne = wne != 0.f && !given, do_se = wse != 0.f && !given;
   float gix = 0.f, giy = 0.f;
-  if (t.mask != 0.f) {
-    const long o_nw = (long)t.y0 * W + t.x0;
-    const float* xb = x + (long)b * x_bs;
-    const float* gb = gout + (long)b * gout_bs + p;
-    float* gxb = gx ? gx + (long)b * gx_bs : nullptr;
-    for (int c = 0; c < C; ++c) {
-      const float g = gb[(long)c * plane];
+  const float* xb = x + (long)b * x_bs;
+  const float* gb = gout + (long)b * gout_bs + pp;
+  float* gxb = gx ? gx + (long)b * gx_bs : nullptr;
+  for (int c = 0; c < C; ++c) {
+    const float g = act ? gb[(long)c * plane] : 0.f;
+    if (gxb) {
+      const float gl = __shfl_up(g, 1, 64);
+      float* gc = gxb + (long)c * plane;
+      if (do_nw) unsafeAtomicAdd(gc + o_nw, g * wnw + gl * tne);
+      if (do_ne) unsafeAtomicAdd(gc + o_nw + 1, g * wne);
+      if (do_sw) unsafeAtomicAdd(gc + o_nw + W, g * wsw + gl * tse);
+      if (do_se) unsafeAtomicAdd(gc + o_nw + W + 1, g * wse);
+    }
+    if (gflow && on) {
       const float* xc = xb + (long)c * plane;
-      if (gxb) {
-        float* gc = gxb + (long)c * plane;
-        if (t.in_nw) unsafeAtomicAdd(gc + o_nw, g * t.nw);
-        if (t.in_ne) unsafeAtomicAdd(gc + o_nw + 1, g * t.ne);
-        if (t.in_sw) unsafeAtomicAdd(gc + o_nw + W, g * t.sw);
-        if (t.in_se) unsafeAtomicAdd(gc + o_nw + W + 1, g * t.se);
-      }
-      if (gflow) {
-        const float a = t.in_nw ? xc[o_nw] : 0.f;
-        const float bq = t.in_ne ? xc[o_nw + 1] : 0.f;
-        const float cq = t.in_sw ? xc[o_nw + W] : 0.f;
-        const float dq = t.in_se ? xc[o_nw + W + 1] : 0.f;
-        // d/d ix : -nw_val*s + ne_val*s - sw_val*n + se_val*n ;  d/d iy : -nw_val*e - ne_val*w + sw_val*e + se_val*w
-        gix += g * ((bq - a) * t.s + (dq - cq) * t.n);
-        giy += g * ((cq - a) * t.e + (dq - bq) * t.w);
-      }
+      const float a = t.in_nw ? xc[o_nw] : 0.f;
+      const float bq = t.in_ne ? xc[o_nw + 1] : 0.f;
+      const float cq = t.in_sw ? xc[o_nw + W] : 0.f;
+      const float dq = t.in_se ? xc[o_nw + W + 1] : 0.f;
+      // d/d ix : -nw_val*s + ne_val*s - sw_val*n + se_val*n ;  d/d iy : -nw_val*e - ne_val*w + sw_val*e + se_val*w
+      gix += g * ((bq - a) * t.s + (dq - cq) * t.n);
+      giy += g * ((cq - a) * t.e + (dq - bq) * t.w);
     }
   }
-  if (gflow) {
+  if (gflow && act) {
     // d ix / d gx = (W-1)/2 ; d gx / d flow_u = 2 / max(W_im-1,1) / div_flow
     float* gf = gflow + (long)b * gflow_bs;
     gf[p] = gix * (0.5f * (float)(W - 1)) * (2.f / den_w / div_flow);
