@@ -247,6 +247,7 @@ int irr_upsample_nearest2x_bwd_f32(const float* gout, float* gx, int B, int C, i
  *   irr_epe_sum_fwd      *out += weight * sum_{b,p} || tgt - flow ||_2            flow, tgt: (B,2,h,w)
  *   irr_epe_sum_bwd      gflow = gscale[0]*weight * (flow - tgt)/||.||            (0 where the norm is 0)
  *   irr_f1bal_sums       sums[b][0..3] += { -sum t log(s+eps), -sum (1-t) log(1-s+eps), sum t, sum s },  s = sigmoid(logit)
+ *   irr_f1bal_value      out[0] = scale * sum_b [ tp/(st+sp+eps) + fn/((N-st)+(N-sp)+eps) ]   (sums from irr_f1bal_sums, N = HW)
  *   irr_f1bal_bwd        glogit = gscale[0]*weight * d/dlogit [ tp/(st+sp+eps) + fn/((N-st)+(N-sp)+eps) ]
  * gscale is a 1-element DEVICE array (the upstream gradient times the balancing weight), so nothing syncs. */
 int irr_avgpool_f32(const float* in, float* out, int BC, int h, int w, int s, float scale, void* stream);
@@ -255,6 +256,7 @@ int irr_epe_sum_fwd_f32(const float* flow, const float* tgt, float* out, int B, 
 int irr_epe_sum_bwd_f32(const float* flow, const float* tgt, const float* gscale, float* gflow, int B, int HW,
                         long flow_bs, long tgt_bs, long g_bs, float weight, void* stream);
 int irr_f1bal_sums_f32(const float* logit, const float* tgt, float* sums, int B, int HW, long l_bs, long t_bs, void* stream);
+int irr_f1bal_value_f32(const float* sums, float* out, int B, int HW, float scale, void* stream);
 int irr_f1bal_bwd_f32(const float* logit, const float* tgt, const float* sums, const float* gscale, float* glogit,
                       int B, int HW, long l_bs, long t_bs, long g_bs, float weight, void* stream);
 

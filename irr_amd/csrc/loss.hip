@@ -154,6 +154,32 @@ extern "C" int irr_f1bal_sums_f32(const float* logit, const float* tgt, float* s
   return 0;
 }
 
+// out[0] = scale * ( sum_b tp/(st+sp+eps) + sum_b fn/((N-st)+(N-sp)+eps) ): the per-sample algebra of f1_score_bal_loss
+// (losses.py:39-48) on the four sums per sample, one wave, fixed order
+__global__ __launch_bounds__(64) void f1_value_kernel(const float* __restrict__ sums, float* __restrict__ out, int B, float n,
+                                                     float scale) {
+  const float eps = 1e-8f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = threadIdx.x; b < B; b += 64) {
+    const float tp = sums[b * 4 + 0], fn = sums[b * 4 + 1], st = sums[b * 4 + 2], sp = sums[b * 4 + 3];
+    s1 += tp / (st + sp + eps);
+    s2 += fn / ((n - st) + (n - sp) + eps);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_down(s1, o, 64);
+    s2 += __shfl_down(s2, o, 64);
+  }
+  if (threadIdx.x == 0) out[0] = (s1 + s2) * scale;
+}
+
+extern "C" int irr_f1bal_value_f32(const float* sums, float* out, int B, int HW, float scale, void* stream) {
+  if (!sums || !out || B <= 0 || HW <= 0) return IRR_EINVAL;
+  hipLaunchKernelGGL(f1_value_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, out, B, (float)HW, scale);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int irr_f1bal_bwd_f32(const float* logit, const float* tgt, const float* sums, const float* gscale,
                                  float* glogit, int B, int HW, long l_bs, long t_bs, long g_bs, float weight,
                                  void* stream) {

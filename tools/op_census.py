@@ -52,6 +52,20 @@ for ev in prof.events():
     t = tot[ev.name]
     t[0] += 1
     t[1] += ev.device_time_total
+# launches by the outermost enclosing profiler range (autograd node in backward, module-level op in forward)
+top = collections.defaultdict(lambda: [0, 0.0])
+for ev in prof.events():
+    if ev.device_time_total <= 0 or not ev.name.startswith("aten::") or (ev.cpu_parent is not None and ev.cpu_parent.name.startswith("aten::")):
+        continue
+    anc = ev
+    while anc.cpu_parent is not None:
+        anc = anc.cpu_parent
+    key = (anc.name[:70], ev.name)
+    top[key][0] += 1
+    top[key][1] += ev.device_time_total
+print("== torch ops by outermost range (autograd node) ==")
+for k, v in sorted(top.items(), key=lambda kv: -kv[1][0])[:45]:
+    print(f"{v[0]:5d} {v[1] / 1e3:7.2f} ms  {k[0]:70s} {k[1]}")
 print("== per op ==")
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1][1])[:25]:
     print(f"{k:40s} {v[0]:5d} launches {v[1] / 1e3:8.2f} ms")
