@@ -26,6 +26,16 @@ def _linspace_dev(n: int, device: torch.device) -> torch.Tensor:
     return t
 
 
+def _pd(t):
+    """the operand as the kernels need it: dense (H, W) planes at a channel stride of H*W, any batch stride (passed as
+    ``hip.bs``), 16-byte aligned -- channel or batch slices of a larger tensor qualify and are NOT copied"""
+    b, c, h, w = t.shape
+    sb, sc, sh, sw = t.stride()
+    ok = (sw == 1 or w == 1) and (sh == w or h == 1) and (sc == h * w or c == 1) and (b == 1 or sb % 4 == 0) \
+        and t.data_ptr() % 16 == 0
+    return t if ok else t.contiguous()
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -39,7 +49,7 @@ class _CostVolume(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f1, f2, lrelu: bool):
         _need_cuda(f1, f2)
-        f1, f2 = f1.contiguous(), f2.contiguous()
+        f1, f2 = _pd(f1), _pd(f2)
         B, C, H, W = f1.shape
         out = torch.empty(B, 81, H, W, device=f1.device, dtype=torch.float32)
         hip.call("irr_corr81_fwd_f32", hip.ptr(f1), hip.ptr(f2), hip.ptr(out), B, C, H, W,
@@ -51,7 +61,7 @@ class _CostVolume(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         f1, f2, out = ctx.saved_tensors
-        gout = gout.contiguous()
+        gout = _pd(gout)
         B, C, H, W = f1.shape
         g1 = torch.empty_like(f1) if ctx.needs_input_grad[0] else None
         g2 = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
@@ -86,7 +96,7 @@ class _Warp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, flow, height_im: int, width_im: int, div_flow: float, mask_thr: float):
         _need_cuda(x, flow)
-        x, flow = x.contiguous(), flow.contiguous()
+        x, flow = _pd(x), _pd(flow)
         B, C, H, W = x.shape
         gx, gy = _linspace_dev(W, x.device), _linspace_dev(H, x.device)
         out = torch.empty_like(x)
@@ -100,7 +110,7 @@ class _Warp(torch.autograd.Function):
     def backward(ctx, gout):
         x, flow = ctx.saved_tensors
         height_im, width_im, div_flow, mask_thr = ctx.cfg
-        gout = gout.contiguous()
+        gout = _pd(gout)
         B, C, H, W = x.shape
         gxg, gyg = _linspace_dev(W, x.device), _linspace_dev(H, x.device)
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
@@ -126,7 +136,7 @@ class _ResizeAC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, oh: int, ow: int, alpha: float):
         _need_cuda(x)
-        x = x.contiguous()
+        x = _pd(x)
         B, C, H, W = x.shape
         out = torch.empty(B, C, oh, ow, device=x.device, dtype=torch.float32)
         hip.call("irr_resize_bilinear_ac_fwd_f32", hip.ptr(x), hip.ptr(out), B, C, H, W, oh, ow,
@@ -137,7 +147,7 @@ class _ResizeAC(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         H, W, oh, ow, alpha = ctx.cfg
-        gout = gout.contiguous()
+        gout = _pd(gout)
         B, C = gout.shape[:2]
         gx = torch.empty(B, C, H, W, device=gout.device, dtype=torch.float32)
         hip.call("irr_resize_bilinear_ac_bwd_f32", hip.ptr(gout), hip.ptr(gx), B, C, H, W, oh, ow,
@@ -164,7 +174,7 @@ class _RefineTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, v, scale0: float, scale1: float):
         _need_cuda(feat, v)
-        feat, v = feat.contiguous(), v.contiguous()
+        feat, v = _pd(feat), _pd(v)
         B, C, H, W = v.shape
         if feat.shape != (B, 9, H, W):
             raise ValueError(f"refine tail expects 9 kernel channels, got {tuple(feat.shape)}")
@@ -178,7 +188,7 @@ class _RefineTail(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         feat, v = ctx.saved_tensors
-        gout = gout.contiguous()
+        gout = _pd(gout)
         B, C, H, W = v.shape
         gf = torch.empty_like(feat) if ctx.needs_input_grad[0] else None
         gv = torch.empty_like(v) if ctx.needs_input_grad[1] else None
@@ -200,7 +210,7 @@ class _Nearest2x(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         _need_cuda(x)
-        x = x.contiguous()
+        x = _pd(x)
         B, C, H, W = x.shape
         out = torch.empty(B, C, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
         hip.call("irr_upsample_nearest2x_fwd_f32", hip.ptr(x), hip.ptr(out), B, C, H, W, hip.bs(x), hip.bs(out), hip.stream())
@@ -208,7 +218,7 @@ class _Nearest2x(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        gout = gout.contiguous()
+        gout = _pd(gout)
         B, C, OH, OW = gout.shape
         gx = torch.empty(B, C, OH // 2, OW // 2, device=gout.device, dtype=torch.float32)
         hip.call("irr_upsample_nearest2x_bwd_f32", hip.ptr(gout), hip.ptr(gx), B, C, OH // 2, OW // 2,
