@@ -18,18 +18,25 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
 __device__ __forceinline__ float lo_f(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float hi_f(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
-// exact 3-way bf16 split of 8 floats -> three packed 8 x bf16 fragments
+// exact 3-way bf16 split of 8 floats -> three packed 8 x bf16 fragments.  The two residual subtractions of a pair are written
+// as float2 arithmetic so that they compile to one v_pk_add_f32 each (36 instead of 44 VALU instructions per 8 values).
+__device__ __forceinline__ f32x2 unpk_bf16(uint32_t p) {
+  f32x2 r;
+  r[0] = lo_f(p);
+  r[1] = hi_f(p);
+  return r;
+}
 __device__ __forceinline__ void split8(const float* v, u32x4& h, u32x4& m, u32x4& l) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float a = v[2 * q], b = v[2 * q + 1];
-    const uint32_t hp = pk_bf16(a, b);
-    const float ra = a - lo_f(hp), rb = b - hi_f(hp);
-    const uint32_t mp = pk_bf16(ra, rb);
-    const float sa = ra - lo_f(mp), sb = rb - hi_f(mp);
+    const f32x2 a = {v[2 * q], v[2 * q + 1]};
+    const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
+    const f32x2 r = a - unpk_bf16(hp);
+    const uint32_t mp = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+    const f32x2 s2 = r - unpk_bf16(mp);
     h[q] = hp;
     m[q] = mp;
-    l[q] = pk_bf16(sa, sb);
+    l[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(s2, bf16x2));
   }
 }
 
