@@ -198,6 +198,11 @@ int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const float* bias
 int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                                  int B, int Cin, int H, int W, int Cout, int k, int dil,
                                  long x_bs, long gy_bs, void* stream);
+/* weight gradient of a 3x3 layer with THREE input channels (the first pyramid conv, any stride / dilation, padding = dil):
+ * same contract as irr_conv2d_wgrad_f32 (gw accumulated, ws = Cout*Cin*9 floats of scratch, gbias nullable). */
+int irr_conv2d_smallci_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
+                                 int B, int Cin, int H, int W, int Cout, int OH, int OW, int stride, int dil,
+                                 long x_bs, long gy_bs, void* stream);
 /* Stride-1 data gradient of the Cout <= 2 heads (3x3, dilation d): gx[b,ci] (+)= conv_transpose(gy, w)[b,ci], then
  * gx[:, :nmask] *= LeakyReLU'(mask) (mask nullable).  w is the plain (Cout, Cin, 3, 3) tensor.  HBM-bound VALU kernel;
  * replaces the MFMA launch with K = 9*Cout of irr_conv2d_fwd_f32 (transposed pack) for these layers. */

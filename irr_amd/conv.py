@@ -311,14 +311,19 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
     assert gw.is_contiguous()
     use_x3 = (MATH == "x3" and not (cout <= 4 and stride == 1)
               and bool(hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, k, stride, dil)))
-    # scratch: one partial [Cout][k*k][Cin] image per block column of the launch (the Cout <= 4 kernels: one image)
-    if cout <= 4 and stride == 1:
+    # scratch: one partial [Cout][k*k][Cin] image per block column of the launch (the Cout <= 4 / Cin = 3 kernels: one image)
+    smallci = cin == 3 and k == 3 and cout > 4
+    if (cout <= 4 and stride == 1) or smallci:
         nws = cout * cin * k * k
     elif use_x3:
         nws = hip.lib().irr_conv2d_wgrad_x3_ws_elems(cin, cout)
     else:
         nws = hip.lib().irr_conv2d_wgrad_ws_elems(B, cin, H, W, cout, oh, ow, k, stride, dil, hip.bs(x), hip.bs(gy))
     ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+    if smallci:
+        hip.call("irr_conv2d_smallci_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
+                 cout, oh, ow, stride, dil, hip.bs(x), hip.bs(gy), hip.stream())
+        return gw
     if cout <= 4 and stride == 1:
         hip.call("irr_conv2d_smallco_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W, cout, k, dil,
                  hip.bs(x), hip.bs(gy), hip.stream())

@@ -497,6 +497,76 @@ __global__ __launch_bounds__(256) void conv_smallco_dgrad4_kernel(const float* _
   }
 }
 
+// Weight gradient of a layer with a TINY input-channel count (the first pyramid conv 3 -> 16, stride 2: a 32-wide MFMA
+// ci-tile would be 91 % padding and ran at 2 TFLOP/s).  A thread owns output pixels, keeps the NCI x 9 input window of a
+// pixel in registers (buffer loads, out-of-image taps answered with 0) and accumulates it against FOUR output channels
+// (blockIdx.y = channel group); block reduction, then atomics into the [co][tap][ci] scratch image.
+template <int NCI>
+__global__ __launch_bounds__(256) void conv_smallci_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                float* __restrict__ ws, float* __restrict__ gbias, float alpha,
+                                                                int H, int W, int Cout, int OH, int OW, int stride, int dil,
+                                                                int pad, long x_bs, long gy_bs, int pix_per_block) {
+  constexpr int NW = NCI * 9;
+  const long ohw = (long)OH * OW, hw = (long)H * W;
+  const int co0 = blockIdx.y * 4, b = blockIdx.z;
+  const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(ohw, p0 + pix_per_block);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * x_bs), (short)0, (int)SOOB, 0x00020000);
+  const float* gb = gy + (long)b * gy_bs;
+  float acc[4][NW];
+  float bsum[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bsum[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) acc[c][k] = 0.f;
+  }
+  for (long p = p0 + threadIdx.x; p < p1; p += 256) {
+    const int oy = (int)(p / OW), ox = (int)(p - (long)oy * OW);
+    float xv[NW];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int iy = oy * stride - pad + (t / 3) * dil, ix = ox * stride - pad + (t % 3) * dil;
+      const uint32_t vo = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? (uint32_t)((iy * W + ix) * 4) : SOOB;
+#pragma unroll
+      for (int ci = 0; ci < NCI; ++ci)
+        xv[ci * 9 + t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)vo, (int)((uint32_t)ci * (uint32_t)(hw * 4)), 0));
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float g = (co0 + c < Cout) ? gb[(long)(co0 + c) * ohw + p] : 0.f;
+      bsum[c] += g;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) acc[c][k] = fmaf(g, xv[k], acc[c][k]);
+    }
+  }
+  __shared__ float red[4][4 * NW + 4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      float v = acc[c][k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane == 0) red[wv][c * NW + k] = v;
+    }
+    float sb = bsum[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sb += __shfl_down(sb, o, 64);
+    if (lane == 0) red[wv][4 * NW + c] = sb;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * NW + 4; i += 256) {
+    const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (i < 4 * NW) {
+      const int c = i / NW, k = i - c * NW, ci = k / 9, t = k - ci * 9;
+      if (co0 + c < Cout) unsafeAtomicAdd(ws + ((long)(co0 + c) * 9 + t) * NCI + ci, alpha * v);
+    } else if (gbias && co0 + (i - 4 * NW) < Cout) {
+      unsafeAtomicAdd(gbias + co0 + (i - 4 * NW), alpha * v);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int irr_conv2d_smallco_dgrad_f32(const float* gy, const float* w, float* gx, const float* mask, int B, int Cin,
@@ -611,6 +681,27 @@ extern "C" int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, flo
 #undef IRR_SMALL_WG
   IRR_LAUNCH_CHECK();
   hipLaunchKernelGGL(smallco_unpack_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, st, ws, gw, Cin, k * k, n);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_conv2d_smallci_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
+                                            int B, int Cin, int H, int W, int Cout, int OH, int OW, int stride, int dil,
+                                            long x_bs, long gy_bs, void* stream) {
+  if (!x || !gy || !gw || !ws || B <= 0 || Cin != 3 || H <= 0 || W <= 0 || Cout <= 0 || OH <= 0 || OW <= 0 || stride < 1 || dil < 1 ||
+      B > 65535 || (long)Cin * H * W >= (1L << 29))
+    return IRR_EINVAL;
+  const long n = (long)Cout * Cin * 9;
+  hipStream_t st = (hipStream_t)stream;
+  IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, st));
+  const long ohw = (long)OH * OW;
+  long ppb = 256 * 32;                                       // 32 pixels per thread amortise the block reduction
+  while (ppb > 256 * 4 && irr_cdiv(ohw, ppb) * irr_cdiv(Cout, 4) * B < 1024) ppb /= 2;
+  dim3 grid(irr_cdiv(ohw, ppb), irr_cdiv(Cout, 4), B);
+  hipLaunchKernelGGL((conv_smallci_wgrad_kernel<3>), grid, dim3(256), 0, st, x, gy, ws, gbias, alpha, H, W, Cout, OH, OW, stride, dil,
+                     dil, x_bs, gy_bs, (int)ppb);
+  IRR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(smallco_unpack_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, st, ws, gw, Cin, 9, n);
   IRR_LAUNCH_CHECK();
   return 0;
 }

@@ -31,6 +31,8 @@ CASES = [
     (40, 128, 3, 1, 1, True, 2, 10, 64),      # halo-tile wgrad: partial last column tile + padded channels
     (64, 64, 3, 1, 1, True, 1, 7, 90),        # halo-tile wgrad: odd row count
     (35, 96, 3, 1, 1, True, 1, 12, 58),
+    (3, 16, 3, 2, 1, True, 3, 30, 44),       # first pyramid conv: three-input-channel weight-gradient kernel
+    (3, 18, 3, 1, 1, False, 2, 17, 23),
 ]
 
 
