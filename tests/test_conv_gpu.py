@@ -289,10 +289,12 @@ def test_conv_x3_k_split_small_levels(case):
     cin, cout, dil, B, H, W = case
     C.x3_code(1, 64, 8, 8, 64, 3, 1, 1)                       # (applies IRR_X3_MIN_BLOCKS once, if set)
     old = hip.lib().irr_conv_x3_set_min_blocks(384)          # the K split belongs to the default routing
+    C.set_math("x3")
     try:
         _k_split_checks(C, hip, cin, cout, dil, B, H, W)
     finally:
         hip.lib().irr_conv_x3_set_min_blocks(old)
+        C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
 
 
 def _k_split_checks(C, hip, cin, cout, dil, B, H, W):
