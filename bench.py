@@ -127,7 +127,7 @@ def main():
     if not a.no_async_wgrad:
         arena.enable_async_wgrad()
     opt = FusedAdam(model, arena, lr=1e-4, weight_decay=4e-4)
-    step = TrainStep(mal, opt, grad_sync=arena.sync)
+    step = TrainStep(mal, opt, grad_sync=arena.sync, check_nan=os.environ.get("IRR_BENCH_NO_NANCHECK") is None)   # (diagnostic switch)
     batch = synthetic_batch(a.batch, a.height, a.width, 1234 + rank, device)
 
     def barrier():
