@@ -179,48 +179,56 @@ __device__ __forceinline__ void patch6_sides(float* v, int x0, int W, int lane) 
 
 // KS waves per block share 64 pixel quads and split the input channels (wave k: channels k, k + KS, ...): a launch has
 // only H*W/4 quads per sample, too few waves to hide the latency of a 500-channel loop without the split; the partial sums
-// meet in LDS and wave 0 runs the epilogue.
-template <int NC, int KS>
+// meet in LDS and wave 0 runs the epilogue.  A thread owns its quad in R vertically adjacent output rows: it loads R + 2
+// input rows per channel for R output rows, so the rows re-read through the L2 drop from 3x to (R + 2) / R of the input
+// (with one row per thread the kernel sat at the L2 bandwidth: 3 x 1.55 GB in 0.5 ms).
+template <int NC, int KS, int R>
 __global__ __launch_bounds__(64 * KS) void conv_smallco_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                     const float* __restrict__ bias, const float* __restrict__ res,
                                                                     float* __restrict__ y, int Cin, int H, int W, long x_bs, long y_bs,
                                                                     long res_bs, int lrelu, float alpha, int accumulate) {
-  __shared__ float red[(KS > 1 ? KS - 1 : 1) * NC * 4 * 64];
+  __shared__ float red[(KS > 1 ? KS - 1 : 1) * NC * R * 4 * 64];
   const long hw = (long)H * W;
   const int lane = threadIdx.x & 63;
   const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long q = (long)blockIdx.x * 64 + lane;                         // quad index
-  const bool qok = q * 4 < hw;
+  const int qpr = W / 4;                                               // quads per row
+  const long q = (long)blockIdx.x * 64 + lane;                         // index over (row group, quad of the row)
+  const long ngroups = (H + R - 1) / R;
+  const bool qok = q < ngroups * qpr;
   const int b = blockIdx.y;
-  const long p = qok ? q * 4 : 0;
-  const int oy = (int)(p / W), x0 = (int)(p - (long)oy * W);
-  float acc[NC][4];
+  const long qq = qok ? q : 0;
+  const int oy0 = (int)(qq / qpr) * R, x0 = (int)(qq % qpr) * 4;
+  float acc[NC][R][4];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[c][i] = 0.f;
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * x_bs), (short)0, (int)SOOB, 0x00020000);
-  uint32_t vm[3], vl[3], vr[3];
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-  for (int r = 0; r < 3; ++r) patch6_voffsets(oy - 1 + r, x0, H, W, qok, lane, vm[r], vl[r], vr[r]);
+      for (int i = 0; i < 4; ++i) acc[c][r][i] = 0.f;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * x_bs), (short)0, (int)SOOB, 0x00020000);
+  uint32_t vm[R + 2], vl[R + 2], vr[R + 2];
+#pragma unroll
+  for (int r = 0; r < R + 2; ++r) patch6_voffsets(oy0 - 1 + r, x0, H, W, qok, lane, vm[r], vl[r], vr[r]);
   const uint32_t hw4 = (uint32_t)(hw * 4);
 #pragma unroll 2
   for (int ci = ks; ci < Cin; ci += KS) {
-    float v[3][6];
+    float v[R + 2][6];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) load_patch6_buf(xr, (uint32_t)ci * hw4, vm[r], vl[r], vr[r], v[r]);
+    for (int r = 0; r < R + 2; ++r) load_patch6_buf(xr, (uint32_t)ci * hw4, vm[r], vl[r], vr[r], v[r]);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) patch6_sides(v[r], x0, W, lane);
+    for (int r = 0; r < R + 2; ++r) patch6_sides(v[r], x0, W, lane);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const float* wc = w + ((long)c * Cin + ci) * 9;                   // wave-uniform -> scalar loads
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
+      for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-          const float ww = wc[r * 3 + t];
+          const float ww = wc[a * 3 + t];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[c][i] = fmaf(ww, v[r][i + t], acc[c][i]);
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[c][r][i] = fmaf(ww, v[r + a][i + t], acc[c][r][i]);
         }
     }
   }
@@ -229,7 +237,9 @@ __global__ __launch_bounds__(64 * KS) void conv_smallco_fwd4_kernel(const float*
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[(((ks - 1) * NC + c) * 4 + i) * 64 + lane] = acc[c][i];
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) red[((((ks - 1) * NC + c) * R + r) * 4 + i) * 64 + lane] = acc[c][r][i];
     }
     __syncthreads();
     if (ks > 0) return;
@@ -238,44 +248,54 @@ __global__ __launch_bounds__(64 * KS) void conv_smallco_fwd4_kernel(const float*
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[c][i] += red[((k * NC + c) * 4 + i) * 64 + lane];
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[c][r][i] += red[(((k * NC + c) * R + r) * 4 + i) * 64 + lane];
   }
   if (!qok) return;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const float bsv = bias ? bias[c] : 0.f;
-    float* dst = y + (long)b * y_bs + (long)c * hw + p;
-    f32x4s o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float vv = acc[c][i] + bsv;
-      if (lrelu) vv = irr_lrelu(vv);
-      o[i] = vv;
+    for (int r = 0; r < R; ++r) {
+      if (oy0 + r >= H) continue;
+      const long p = (long)(oy0 + r) * W + x0;
+      float* dst = y + (long)b * y_bs + (long)c * hw + p;
+      f32x4s o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float vv = acc[c][r][i] + bsv;
+        if (lrelu) vv = irr_lrelu(vv);
+        o[i] = vv;
+      }
+      if (res) {
+        const f32x4s rr = *(const f32x4s*)(res + (long)b * res_bs + (long)c * hw + p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = rr[i] + alpha * o[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] *= alpha;
+      }
+      if (accumulate) {
+        const f32x4s d0 = *(const f32x4s*)dst;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] += d0[i];
+      }
+      *(f32x4s*)dst = o;
     }
-    if (res) {
-      const f32x4s rr = *(const f32x4s*)(res + (long)b * res_bs + (long)c * hw + p);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = rr[i] + alpha * o[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] *= alpha;
-    }
-    if (accumulate) {
-      const f32x4s d0 = *(const f32x4s*)dst;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] += d0[i];
-    }
-    *(f32x4s*)dst = o;
   }
 }
 
-template <int NC>
+// R vertically adjacent output rows per thread (R + 2 input rows are loaded for R rows of products: the L2 re-read factor
+// drops from 3 to (R + 2) / R, as in the forward kernel).
+template <int NC, int R>
 __global__ __launch_bounds__(256) void conv_smallco_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                  float* __restrict__ ws, float* __restrict__ gbias, float alpha,
                                                                  int Cin, int H, int W, long x_bs, long gy_bs,
                                                                  int quads_per_block, int B, int bpb) {
   const long hw = (long)H * W;
-  const long nq = hw / 4;
+  const int qpr = W / 4;
+  const long nq = (long)((H + R - 1) / R) * qpr;            // "tall quads": 4 pixels x R rows
   const int ci = blockIdx.y;
   const long q0 = (long)blockIdx.x * quads_per_block;
   const long q1 = min(nq, q0 + quads_per_block);
@@ -288,6 +308,7 @@ __global__ __launch_bounds__(256) void conv_smallco_wgrad4_kernel(const float* _
     for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
   }
   const uint32_t hw4 = (uint32_t)(hw * 4);
+  const int lane = threadIdx.x & 63;
   // bpb samples per block (small pyramid levels: one sample has too few quads to amortise the block reduction)
   for (int b = blockIdx.z * bpb; b < min(B, (int)(blockIdx.z + 1) * bpb); ++b) {
   const __amdgpu_buffer_rsrc_t xr =
@@ -296,39 +317,42 @@ __global__ __launch_bounds__(256) void conv_smallco_wgrad4_kernel(const float* _
   for (long qb = q0; qb < q1; qb += 256) {                 // wave-uniform trip count: the side pixels travel between lanes
     const long q = qb + threadIdx.x;
     const bool act = q < q1, inimg = q < nq;
-    const long p = inimg ? q * 4 : 0;
-    const int oy = (int)(p / W), x0 = (int)(p - (long)oy * W);
-    float g[NC][4];
+    const long qq = inimg ? q : 0;
+    const int oy0 = (int)(qq / qpr) * R, x0 = (int)(qq % qpr) * 4;
+    float g[NC][R][4];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const f32x4s gg = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)(act ? (uint32_t)(p * 4) : SOOB),
-                                                                                        (int)((uint32_t)c * hw4), 0));
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { g[c][i] = gg[i]; bsum[c] += gg[i]; }
-    }
-    float vv[3][6];
+      for (int r = 0; r < R; ++r) {
+        const bool ok = act && oy0 + r < H;
+        const f32x4s gg = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         gr, (int)(ok ? (uint32_t)(((oy0 + r) * W + x0) * 4) : SOOB), (int)((uint32_t)c * hw4), 0));
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+        for (int i = 0; i < 4; ++i) { g[c][r][i] = gg[i]; bsum[c] += gg[i]; }
+      }
+    float vv[R + 2][6];
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) {
       uint32_t vm, vl, vr;
-      patch6_voffsets(oy - 1 + r, x0, H, W, inimg, (int)(threadIdx.x & 63), vm, vl, vr);
+      patch6_voffsets(oy0 - 1 + r, x0, H, W, inimg, lane, vm, vl, vr);
       load_patch6_buf(xr, 0u, vm, vl, vr, vv[r]);
     }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) patch6_sides(vv[r], x0, W, (int)(threadIdx.x & 63));
+    for (int r = 0; r < R + 2; ++r) patch6_sides(vv[r], x0, W, lane);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const float* v = vv[r];
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[c][r * 3 + t] = fmaf(g[c][i], v[i + t], acc[c][r * 3 + t]);
-    }
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[c][a * 3 + t] = fmaf(g[c][r][i], vv[r + a][i + t], acc[c][a * 3 + t]);
   }
   }
   __shared__ float red[4][NC * 9];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wv = threadIdx.x >> 6;
   if (gbias && ci == 0) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -614,18 +638,26 @@ extern "C" int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const 
   if (!x || !w || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 1 || Cout > 4 || B > 65535) return IRR_EINVAL;
   if ((k != 1 && k != 3) || dil < 1) return IRR_EINVAL;
   if (k == 3 && dil == 1 && (W & 3) == 0 && Cout <= 2 && ((x_bs | y_bs | res_bs) & 3) == 0 && !IRR_ENV_FLAG("IRR_SMALLCO_SCALAR")) {
-    dim3 grid4(irr_cdiv((long)H * W / 4, 64), B, 1);             // one wave per block: enough blocks to hide the channel-loop latency
     hipStream_t st = (hipStream_t)stream;
-    static const int ks_env = getenv("IRR_SMALLCO_KS") ? atoi(getenv("IRR_SMALLCO_KS")) : 0;      // experiment switch
-    const int ks = ks_env ? ks_env : (Cin >= 64 ? 4 : 1);
-#define IRR_FWD4(NC, KS)                                                                                                  \
-  hipLaunchKernelGGL((conv_smallco_fwd4_kernel<NC, KS>), grid4, dim3(64 * KS), 0, st, x, w, bias, res, y, Cin, H, W, x_bs, y_bs, \
+    static const int ks_env = getenv("IRR_SMALLCO_KS") ? atoi(getenv("IRR_SMALLCO_KS")) : 0;      // experiment switches
+    static const int r_env = getenv("IRR_SMALLCO_R") ? atoi(getenv("IRR_SMALLCO_R")) : 0;
+    // measured (563 -> 2, 64 samples): 96x112 R=4/KS=4 0.37 ms (R=1: 0.52), 48x56 R=1/KS=8 0.13 (KS=4: 0.20), 24x28 R=1/KS=8 0.08
+    const int rr = r_env ? r_env : (((long)B * H * W >= 400000 && H % 4 == 0) ? 4 : 1);
+    const int ks = ks_env ? ks_env : (Cin >= 64 ? (rr >= 4 ? 4 : 8) : (Cin >= 16 ? 4 : 1));
+    dim3 grid4(irr_cdiv((long)((H + rr - 1) / rr) * (W / 4), 64), B, 1);
+#define IRR_FWD4(NC, KS, RR)                                                                                              \
+  hipLaunchKernelGGL((conv_smallco_fwd4_kernel<NC, KS, RR>), grid4, dim3(64 * KS), 0, st, x, w, bias, res, y, Cin, H, W, x_bs, y_bs, \
                      res_bs, lrelu, alpha, accumulate)
+#define IRR_FWD4_R(NC, KS)                                                        \
+  do {                                                                            \
+    if (rr >= 4) IRR_FWD4(NC, KS, 4); else IRR_FWD4(NC, KS, 1); \
+  } while (0)
     if (Cout == 1) {
-      if (ks >= 8) IRR_FWD4(1, 8); else if (ks >= 4) IRR_FWD4(1, 4); else if (ks == 2) IRR_FWD4(1, 2); else IRR_FWD4(1, 1);
+      if (ks >= 8) IRR_FWD4_R(1, 8); else if (ks >= 4) IRR_FWD4_R(1, 4); else IRR_FWD4_R(1, 1);
     } else {
-      if (ks >= 8) IRR_FWD4(2, 8); else if (ks >= 4) IRR_FWD4(2, 4); else if (ks == 2) IRR_FWD4(2, 2); else IRR_FWD4(2, 1);
+      if (ks >= 8) IRR_FWD4_R(2, 8); else if (ks >= 4) IRR_FWD4_R(2, 4); else IRR_FWD4_R(2, 1);
     }
+#undef IRR_FWD4_R
 #undef IRR_FWD4
     IRR_LAUNCH_CHECK();
     return 0;
@@ -652,16 +684,25 @@ extern "C" int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, flo
   long ppb = (hw + chunks - 1) / chunks;
   if (ppb < 1024) ppb = 1024;
   if (k == 3 && dil == 1 && (W & 3) == 0 && Cout <= 2 && ((x_bs | gy_bs) & 3) == 0 && !IRR_ENV_FLAG("IRR_SMALLCO_SCALAR")) {
-    const long qpb = (ppb + 3) / 4;
+    static const int r_env = getenv("IRR_SMALLCO_WR") ? atoi(getenv("IRR_SMALLCO_WR")) : 0;      // experiment switch
+    const int rr = r_env ? r_env : (((long)B * hw >= 400000 && H % 4 == 0) ? 4 : 1);
+    const long ntq = (long)((H + rr - 1) / rr) * (W / 4);                 // tall quads per sample
+    long qpb = ((ppb + 3) / 4 + rr - 1) / rr;
+    if (qpb < 256) qpb = 256;
     // at least ~8 quads per thread and block: several samples per block at the small pyramid levels
-    int bpb = (int)((8 * 256 + hw / 4 - 1) / (hw / 4));
+    int bpb = (int)((8 * 256 + ntq - 1) / ntq);
     if (bpb < 1) bpb = 1;
     while (bpb > 1 && (long)Cin * irr_cdiv(B, bpb) < 1024) --bpb;          // keep the chip filled
-    dim3 grid4(irr_cdiv(hw / 4, qpb), Cin, irr_cdiv(B, bpb));
-    if (Cout == 1)
-      hipLaunchKernelGGL((conv_smallco_wgrad4_kernel<1>), grid4, dim3(256), 0, st, x, gy, ws, gbias, alpha, Cin, H, W, x_bs, gy_bs, (int)qpb, B, bpb);
-    else
-      hipLaunchKernelGGL((conv_smallco_wgrad4_kernel<2>), grid4, dim3(256), 0, st, x, gy, ws, gbias, alpha, Cin, H, W, x_bs, gy_bs, (int)qpb, B, bpb);
+    dim3 grid4(irr_cdiv(ntq, qpb), Cin, irr_cdiv(B, bpb));
+#define IRR_WG4(NC, RR)                                                                                                         \
+  hipLaunchKernelGGL((conv_smallco_wgrad4_kernel<NC, RR>), grid4, dim3(256), 0, st, x, gy, ws, gbias, alpha, Cin, H, W, x_bs, gy_bs, \
+                     (int)qpb, B, bpb)
+    if (Cout == 1) {
+      if (rr >= 4) IRR_WG4(1, 4); else IRR_WG4(1, 1);
+    } else {
+      if (rr >= 4) IRR_WG4(2, 4); else IRR_WG4(2, 1);
+    }
+#undef IRR_WG4
     IRR_LAUNCH_CHECK();
     hipLaunchKernelGGL(smallco_unpack_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, st, ws, gw, Cin, 9, n);
     IRR_LAUNCH_CHECK();
