@@ -402,6 +402,37 @@ def test_conv_smallco_quad_kernels(cout):
     np.testing.assert_allclose(gb.cpu().numpy(), 2 * gy.double().sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("cout", [1, 2])
+def test_conv_smallco_heads_large_level(cout):
+    """The head kernels in their large-level configuration (>= 400000 pixels: four output rows per thread, channel split
+    over 4 waves; height divisible by 4 but not by 8, ragged last row group excluded by H % 4 == 0): forward with bias,
+    weight + bias gradient and the accumulate + mask data gradient against torch's fp32 GPU convolution / fp64 on a slice."""
+    from irr_amd import conv as C
+    g = torch.Generator().manual_seed(90 + cout)
+    B, cin, H, W = 16, 70, 100, 256                          # 409600 pixels
+    x = torch.randn(B, cin, H, W, generator=g).cuda()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    y = C.conv_forward(x, w, b, 1, 1, False)
+    ref = F.conv2d(x[:2].double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
+    np.testing.assert_allclose(y[:2].cpu().numpy(), ref.numpy(), rtol=1e-5, atol=2e-5)
+    ref_last = F.conv2d(x[-1:].double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
+    np.testing.assert_allclose(y[-1:].cpu().numpy(), ref_last.numpy(), rtol=1e-5, atol=2e-5)
+    gy = torch.randn(B, cout, H, W, generator=g).cuda()
+    gw = torch.zeros(cout, cin, 3, 3, device="cuda")
+    gb = torch.zeros(cout, device="cuda")
+    C.conv_wgrad(x, gy, (cout, cin, 3, 3), 1, 1, gw=gw, gbias=gb)
+    wref = torch.nn.grad.conv2d_weight(x.double().cpu(), (cout, cin, 3, 3), gy.double().cpu(), padding=1)
+    np.testing.assert_allclose(gw.cpu().numpy(), wref.numpy(), rtol=2e-4, atol=2e-4 * float(wref.abs().max()))
+    np.testing.assert_allclose(gb.cpu().numpy(), gy.double().sum(dim=(0, 2, 3)).cpu().numpy(), rtol=2e-4, atol=1e-2)
+    g0 = torch.randn(B, cin, H, W, generator=g).cuda()
+    gx = g0.clone()
+    C.conv_dgrad(gy, w, 1, 1, (H, W), gx=gx, accumulate=True, mask=x, nmask=32)
+    gref = torch.nn.grad.conv2d_input(x[:2].shape, w.double().cpu(), gy[:2].double().cpu(), padding=1) + g0[:2].double().cpu()
+    gref[:, :32] *= torch.where(x[:2, :32].cpu() > 0, 1.0, 0.1).double()
+    np.testing.assert_allclose(gx[:2].cpu().numpy(), gref.numpy(), rtol=1e-5, atol=2e-5)
+
+
 def test_x3_family_baseline_size_properties():
     """Size-independent properties at BASELINE configs[2] layer sizes (bs32 -> 2B = 64 samples), where a host reference
     is too slow: (i) weight gradient of a level-4 decoder layer: linear in gy and additive over the batch; (ii) the
