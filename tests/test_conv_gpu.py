@@ -466,3 +466,44 @@ def test_x3_family_baseline_size_properties():
     yf = C.conv_forward(x, w, None, 1, 1, False)
     C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
     assert (y1 - yf).abs().max().item() <= 4e-6 * yf.abs().max().item()
+
+
+BASELINE_X3 = [  # (Cin, Cout, dil, B, H, W): BASELINE configs[2] launches of the configurations chosen at full size only
+    (128, 96, 8, 64, 96, 112),      # row-folded dilation 8, three co-tiles
+    (96, 128, 8, 64, 96, 112),      # its data gradient shape
+    (64, 96, 16, 64, 96, 112),      # dilation 16 data gradient shape
+    (128, 128, 4, 64, 48, 56),      # row-folded dilation 4 at level 3
+    (243, 128, 1, 64, 96, 112),     # 224-pixel tiles chosen by the round-aware rule
+    (16, 16, 1, 64, 192, 224),      # pyramid 16 -> 16 on the streaming kernel (two chunks, second with zero weights)
+    (115, 128, 1, 64, 12, 14),      # K split over blockIdx.z
+]
+
+
+@pytest.mark.parametrize("case", BASELINE_X3, ids=[f"{c[0]}to{c[1]}d{c[2]}_{c[4]}x{c[5]}" for c in BASELINE_X3])
+def test_x3_matches_fp32_kernel_at_baseline_sizes(case):
+    """Default routing at the BASELINE batch: the x3 launch (forward with bias + LeakyReLU, and the transposed-weight data
+    gradient) against the fp32-MFMA kernel on the same operands -- both are within 1-2e-6 of fp64 on small shapes, so they
+    must agree to 4e-6 of the output range here, where a host reference is too slow."""
+    from irr_amd import conv as C, hip
+    cin, cout, dil, B, H, W = case
+    C.x3_code(1, 64, 8, 8, 64, 3, 1, 1)
+    old = hip.lib().irr_conv_x3_set_min_blocks(384)
+    try:
+        torch.manual_seed(cin + cout + dil)
+        x = torch.randn(B, cin, H, W, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, device="cuda") * (2.0 / (cin * 9)) ** 0.5
+        b = torch.randn(cout, device="cuda") * 0.1
+        gy = torch.randn(B, cout, H, W, device="cuda")
+        C.set_math("x3")
+        assert C.x3_code(B, cin, H, W, cout, 3, 1, dil) != 0
+        y3 = C.conv_forward(x, w, b, 1, dil, True)
+        g3 = C.conv_dgrad(gy, w, 1, dil, (H, W)) if C.x3_code(B, cout, H, W, cin, 3, 1, dil) else None
+        C.set_math("f32")
+        yf = C.conv_forward(x, w, b, 1, dil, True)
+        gf = C.conv_dgrad(gy, w, 1, dil, (H, W))
+    finally:
+        hip.lib().irr_conv_x3_set_min_blocks(old)
+        C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
+    assert (y3 - yf).abs().max().item() <= 4e-6 * yf.abs().max().item()
+    if g3 is not None:
+        assert (g3 - gf).abs().max().item() <= 4e-6 * gf.abs().max().item()
