@@ -507,3 +507,35 @@ def test_x3_matches_fp32_kernel_at_baseline_sizes(case):
     assert (y3 - yf).abs().max().item() <= 4e-6 * yf.abs().max().item()
     if g3 is not None:
         assert (g3 - gf).abs().max().item() <= 4e-6 * gf.abs().max().item()
+
+
+BASELINE_WX3 = [  # (Cin, Cout, dil, B, H, W)
+    (64, 32, 1, 64, 96, 112), (32, 32, 1, 64, 96, 112), (32, 64, 1, 64, 96, 112), (565, 128, 1, 64, 48, 56), (128, 96, 8, 64, 96, 112),
+    (115, 128, 1, 64, 96, 112), (32, 32, 1, 64, 192, 224), (531, 32, 1, 64, 48, 56),
+]
+
+
+@pytest.mark.parametrize("case", BASELINE_WX3, ids=[f"{c[0]}to{c[1]}d{c[2]}_{c[4]}x{c[5]}" for c in BASELINE_WX3])
+def test_wgrad_x3_matches_fp32_kernel_at_baseline_sizes(case):
+    """Weight + bias gradient at the BASELINE batch: x3 kernels (partial images + fixed-order reduce; K-split and role-swapped
+    variants, balanced column chunks, dilated walks) against the fp32-MFMA kernels on the same operands."""
+    from irr_amd import conv as C, hip
+    cin, cout, dil, B, H, W = case
+    torch.manual_seed(cin * 3 + cout + dil)
+    x = torch.randn(B, cin, H, W, device="cuda")
+    gy = torch.randn(B, cout, H, W, device="cuda")
+    out = {}
+    try:
+        for m in ("x3", "f32"):
+            C.set_math(m)
+            if m == "x3":
+                assert hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, 3, 1, dil) != 0
+            gw = torch.zeros(cout, cin, 3, 3, device="cuda")
+            gb = torch.zeros(cout, device="cuda")
+            C.conv_wgrad(x, gy, (cout, cin, 3, 3), 1, dil, gw=gw, gbias=gb)
+            out[m] = (gw, gb)
+    finally:
+        C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
+    sw, sb = out["f32"][0].abs().max().item(), out["f32"][1].abs().max().item()
+    assert (out["x3"][0] - out["f32"][0]).abs().max().item() <= 4e-6 * sw
+    assert (out["x3"][1] - out["f32"][1]).abs().max().item() <= 1e-5 * sb
