@@ -274,6 +274,7 @@ struct X3SArgs {
   long mask_bs;
   int nmask;
   unsigned long long* dbg;      // X3S_TRACE builds only
+  int wCoT, wcot;               // co-tiles in the packed weights / the one this launch computes
 };
 
 // s_memtime trace points (IRR_X3S_TRACE=1 builds, tools/x3s_trace.py): block 7, lane 0 of every wave
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
   // The MFMA waves touch no global memory at all: weights live in LDS for the lifetime of the (persistent) block, and
   // finished accumulators are handed to the producer waves through LDS, which run the epilogue (bias, LeakyReLU,
   // residual, accumulate, mask, store) of tile n while the MFMA waves are already on tile n+1.
-  for (int u = tid; u < WUNITS; u += 512) wl[u] = a.wq[u];
+  // (the packed weights interleave the co-tiles of a layer: this launch keeps co-tile a.wcot of a.wCoT)
+  for (int u = tid; u < WUNITS; u += 512) wl[u] = a.wq[((long)(u >> 6) * a.wCoT + a.wcot) * 64 + (u & 63)];
   __syncthreads();
 
   if (wave >= 4) {
@@ -519,8 +521,11 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
 // with zero weights (the kernels re-read channels [Cin-16, Cin) for it): that is the shape conv_x3s_kernel is built for.
 static int x3_nchunk(int Cin, int Cout) { return (Cin == 16 && Cout <= 32) ? 2 : (Cin + 15) / 16; }
 
+// Cout <= 32, or (two launches, one per co-tile) Cout <= 64 with 16 < Cin <= 32: the K = 32 data gradients of the 64 -> 32
+// layers and the c5 -> c4 column of the DenseNet backward, read-modify-write launches that ran at 55 TFLOP/s on conv_x3_kernel
 static bool x3s_ok(int B, int Cin, int H, int W, int Cout, int dil) {
-  if (dil != 1 || Cout > 32 || Cin < 16 || Cin > 32 || (W & 3)) return false;
+  if (dil != 1 || Cout > 64 || Cin < 16 || Cin > 32 || (W & 3)) return false;
+  if (Cout > 32 && (Cin == 16 || IRR_ENV_FLAG("IRR_X3S_NO_COT2"))) return false;
   const long tiles = (long)B * ((H + 7) / 8) * ((W + 31) / 32);
   const double eff = (double)H * W / ((double)((H + 7) / 8) * ((W + 31) / 32) * 256);
   return eff >= 0.8 && (tiles >= 2048 || g_min_blocks == 0);
@@ -831,16 +836,25 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
     long per = bsmax > 0 ? lim / bsmax : B;
     if (per < 1) per = 1;
     if (per > B) per = B;
+    const long hw_ = (long)H * W;
+    s.wCoT = (Cout + 31) / 32;
     for (int b0 = 0; b0 < B; b0 += (int)per) {
       s.B = (B - b0) < per ? (B - b0) : (int)per;
       s.x = x + (long)b0 * x_bs;
-      s.y = y + (long)b0 * y_bs;
-      s.res = res ? res + (long)b0 * res_bs : nullptr;
-      s.mask = mask ? mask + (long)b0 * mask_bs : nullptr;
       s.ntiles = (long)s.B * s.tiles_x * s.tiles_y;
       const long nblk = s.ntiles < 256 ? s.ntiles : 256;             // persistent: one block per CU
-      hipLaunchKernelGGL(conv_x3s_kernel, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
-      IRR_LAUNCH_CHECK();
+      for (int cot = 0; cot < s.wCoT; ++cot) {                       // one launch per 32-channel co-tile
+        const long co0 = 32L * cot;
+        s.wcot = cot;
+        s.Cout = Cout - (int)co0 < 32 ? Cout - (int)co0 : 32;
+        s.bias = bias ? bias + co0 : nullptr;
+        s.y = y + (long)b0 * y_bs + co0 * hw_;
+        s.res = res ? res + (long)b0 * res_bs + co0 * hw_ : nullptr;
+        s.mask = (mask && nmask > co0) ? mask + (long)b0 * mask_bs + co0 * hw_ : nullptr;
+        s.nmask = nmask - (int)co0 < 0 ? 0 : (nmask - (int)co0 > 32 ? 32 : nmask - (int)co0);
+        hipLaunchKernelGGL(conv_x3s_kernel, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
+        IRR_LAUNCH_CHECK();
+      }
     }
     return 0;
   }

@@ -539,3 +539,36 @@ def test_wgrad_x3_matches_fp32_kernel_at_baseline_sizes(case):
     sw, sb = out["f32"][0].abs().max().item(), out["f32"][1].abs().max().item()
     assert (out["x3"][0] - out["f32"][0]).abs().max().item() <= 4e-6 * sw
     assert (out["x3"][1] - out["f32"][1]).abs().max().item() <= 1e-5 * sb
+
+
+@pytest.mark.parametrize("nmask", [0, 40, 64])
+def test_conv_x3s_two_cotiles(nmask, x3_everywhere):
+    """conv_x3s_kernel launched once per 32-channel co-tile (Cout = 64, Cin = 32): the forward epilogues and the data gradient
+    of a 64 -> 32 layer with residual + alpha + accumulate and a LeakyReLU'-mask that ends inside the second co-tile."""
+    from irr_amd import conv as C
+    g = torch.Generator().manual_seed(123 + nmask)
+    B, H, W = 2, 24, 64
+    x = torch.randn(B, 32, H, W, generator=g)
+    w = torch.randn(64, 32, 3, 3, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    res = torch.randn(B, 64, H, W, generator=g)
+    assert C.x3_code(B, 32, H, W, 64, 3, 1, 1) == 9001
+    conv = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    tol = 2e-6 * float(conv.abs().max())
+    y = C.conv_forward(x.cuda(), w.cuda(), b.cuda(), 1, 1, True)
+    assert (y.cpu().double() - F.leaky_relu(conv, 0.1)).abs().max().item() <= tol
+    y = C.conv_forward(x.cuda(), w.cuda(), b.cuda(), 1, 1, False, res=res.cuda(), alpha=0.1)
+    assert (y.cpu().double() - (res.double() + 0.1 * conv)).abs().max().item() <= tol
+    # data gradient of a 64 -> 32 layer: gy has 32 channels, gx 64
+    wl = torch.randn(32, 64, 3, 3, generator=g) * 0.1
+    gy = torch.randn(B, 32, H, W, generator=g)
+    g0 = torch.randn(B, 64, H, W, generator=g)
+    r2 = torch.randn(B, 64, H, W, generator=g)
+    m2 = torch.randn(B, 64, H, W, generator=g)
+    gx = g0.clone().cuda()
+    C.conv_dgrad(gy.cuda(), wl.cuda(), 1, 1, (H, W), gx=gx, accumulate=True, res=r2.cuda(), alpha=0.1,
+                 mask=m2.cuda() if nmask else None, nmask=nmask)
+    ref = g0.double() + r2.double() + 0.1 * torch.nn.grad.conv2d_input((B, 64, H, W), wl.double(), gy.double(), padding=1)
+    if nmask:
+        ref[:, :nmask] *= torch.where(m2[:, :nmask] > 0, 1.0, 0.1).double()
+    assert (gx.cpu().double() - ref).abs().max().item() <= 2e-6 * float(ref.abs().max())
