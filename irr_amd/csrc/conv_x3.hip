@@ -212,6 +212,12 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
 
   // ---- epilogue: D[i][jj], i = (r&3) + 8*(r>>2) + 4*g, jj = lane&31 ----
   const long ohw = hw;
+  // per-sample bases: the byte offsets inside a sample stay below the 2 GiB out-of-range marker for any batch
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long)b * a.y_bs), (short)0, (int)0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res + (long)b * a.res_bs : a.y), (short)0, (int)0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mkr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask + (long)b * a.mask_bs : a.y), (short)0, (int)0x80000000u, 0x00020000);
 #pragma unroll
   for (int s = 0; s < NT; ++s) {
     const int t = (pg * NT + s) * 32 + j;
@@ -228,21 +234,52 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
       }
       continue;
     }
-    float* yb = a.y + (long)b * a.y_bs + pofs;
-    const float* rb = a.res ? a.res + (long)b * a.res_bs + pofs : nullptr;
-    const float* mb = a.mask ? a.mask + (long)b * a.mask_bs + pofs : nullptr;
+    // Read-modify-write epilogues (residual, "+=", LeakyReLU'-mask): the operands of the 16 rows of a sub-tile are loaded
+    // as ONE batch of buffer loads (out-of-range voffset where an operand or a row does not exist) before the first store --
+    // with pointer loads inside the row loop every row waited for its own round trip to memory (the K <= 128 data gradients
+    // of the DenseNet columns ran at 55-110 TFLOP/s because of it).
+    constexpr int RB = NT >= 8 ? 4 : 16;              // rows per batch (NT = 8 has no registers left for 16)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-      if (co >= a.Cout) continue;
-      float v = acc[s][r] + (a.bias ? a.bias[co] : 0.f);
-      if (a.lrelu) v = irr_lrelu(v);
-      float* dst = yb + (long)co * ohw;
-      if (rb) v = rb[(long)co * ohw] + a.alpha * v;
-      else v *= a.alpha;
-      if (a.accumulate) v += *dst;
-      if (mb && co < a.nmask) v *= irr_lrelu_grad(mb[(long)co * ohw]);
-      *dst = v;
+    for (int r0 = 0; r0 < 16; r0 += RB) {
+      uint32_t vo[RB];
+      float bv[RB];
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        const int r = r0 + k;
+        const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        const bool ok = co < a.Cout;
+        vo[k] = ok ? (uint32_t)(((long)co * ohw + pofs) * 4) : OOB;
+        bv[k] = (ok && a.bias) ? a.bias[co] : 0.f;
+      }
+      if (!a.res && !a.accumulate && !a.mask) {
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+          float v = acc[s][r0 + k] + bv[k];
+          if (a.lrelu) v = irr_lrelu(v);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v * a.alpha), yr, (int)vo[k], 0, 0);
+        }
+        continue;
+      }
+      float rv[RB], dv[RB], mv[RB];
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        const int r = r0 + k;
+        const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        rv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsr, (int)(a.res ? vo[k] : OOB), 0, 0));
+        dv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, (int)(a.accumulate ? vo[k] : OOB), 0, 0));
+        mv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mkr, (int)((a.mask && co < a.nmask) ? vo[k] : OOB), 0, 0));
+      }
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        const int r = r0 + k;
+        const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        float v = acc[s][r] + bv[k];
+        if (a.lrelu) v = irr_lrelu(v);
+        v = a.res ? rv[k] + a.alpha * v : v * a.alpha;
+        v += dv[k];                                   // 0 unless accumulating
+        if (a.mask && co < a.nmask) v *= irr_lrelu_grad(mv[k]);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)vo[k], 0, 0);
+      }
     }
   }
 }
