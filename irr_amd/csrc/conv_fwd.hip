@@ -206,24 +206,44 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
   }
 
   // ---- epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*half, j = lane&31 ----
+  // Read-modify-write operands (residual, "+=", LeakyReLU'-mask) of RB rows x NT sub-tiles are loaded as one batch before the
+  // first store of the batch (loads inside the store loop each waited for their own round trip to memory).
+  constexpr int RB = (MT * NT >= 8) ? 2 : 4;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = (cog * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co >= a.Cout) continue;
-      const float bsv = a.bias ? a.bias[co] : 0.f;
+    for (int r0 = 0; r0 < 16; r0 += RB) {
+      float rv[RB][NT], dv[RB][NT], mv[RB][NT], bsv[RB];
+      bool cok[RB];
 #pragma unroll
-      for (int s = 0; s < NT; ++s) {
-        if (!pvalid[s]) continue;
-        float v = acc[m][s][r] + bsv;
-        if (a.lrelu) v = irr_lrelu(v);
-        float* dst = a.y + ooff[s] + (long)co * ohw;
-        if (a.res) v = a.res[roff[s] + (long)co * ohw] + a.alpha * v;
-        else v *= a.alpha;
-        if (a.accumulate) v += *dst;
-        if (a.mask && co < a.nmask) v *= irr_lrelu_grad(a.mask[moff[s] + (long)co * ohw]);
-        *dst = v;
+      for (int k = 0; k < RB; ++k) {
+        const int r = r0 + k;
+        const int co = (cog * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        cok[k] = co < a.Cout;
+        bsv[k] = (cok[k] && a.bias) ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+          const bool ok = cok[k] && pvalid[s];
+          rv[k][s] = (ok && a.res) ? a.res[roff[s] + (long)co * ohw] : 0.f;
+          dv[k][s] = (ok && a.accumulate) ? a.y[ooff[s] + (long)co * ohw] : 0.f;
+          mv[k][s] = (ok && a.mask && co < a.nmask) ? a.mask[moff[s] + (long)co * ohw] : 1.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        const int r = r0 + k;
+        const int co = (cog * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (!cok[k]) continue;
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+          if (!pvalid[s]) continue;
+          float v = acc[m][s][r] + bsv[k];
+          if (a.lrelu) v = irr_lrelu(v);
+          v = a.res ? rv[k][s] + a.alpha * v : v * a.alpha;
+          v += dv[k][s];
+          if (a.mask && co < a.nmask) v *= irr_lrelu_grad(mv[k][s]);
+          a.y[ooff[s] + (long)co * ohw] = v;
+        }
       }
     }
   }
