@@ -238,7 +238,7 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
     // as ONE batch of buffer loads (out-of-range voffset where an operand or a row does not exist) before the first store --
     // with pointer loads inside the row loop every row waited for its own round trip to memory (the K <= 128 data gradients
     // of the DenseNet columns ran at 55-110 TFLOP/s because of it).
-    constexpr int RB = NT >= 8 ? 4 : 16;              // rows per batch (NT = 8 has no registers left for 16)
+    constexpr int RB = NT >= 8 ? 8 : 16;              // rows per batch (NT = 8 has no registers left for 16)
 #pragma unroll
     for (int r0 = 0; r0 < 16; r0 += RB) {
       uint32_t vo[RB];
