@@ -575,7 +575,11 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
     } else if (swapped) {
       rc = kg == 4 ? launch_wx3<8, 1, 4, 1>(a, st) : kg == 2 ? launch_wx3<8, 1, 2, 2>(a, st) : launch_wx3<8, 1, 1, 4>(a, st);
     } else if (cot == 2) {
-      rc = kg == 4 ? launch_wx3<2, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<2, 2, 2, 2>(a, st) : launch_wx3<2, 2, 1, 4>(a, st);
+      // 2 x 2 tiles = four waves would leave one wave per SIMD: two wave groups split the k-steps of a unit (eight waves)
+      if (IRR_ENV_FLAG("IRR_WX3_NO_KW2"))
+        rc = kg == 4 ? launch_wx3<2, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<2, 2, 2, 2>(a, st) : launch_wx3<2, 2, 1, 4>(a, st);
+      else
+        rc = kg == 4 ? launch_wx3<2, 2, 4, 1, 2>(a, st) : kg == 2 ? launch_wx3<2, 2, 2, 2, 2>(a, st) : launch_wx3<2, 2, 1, 4, 2>(a, st);
     } else if (cot % 4 == 0 || cot > 4) {
       rc = kg == 4 ? launch_wx3<4, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<4, 2, 2, 2>(a, st) : launch_wx3<4, 2, 1, 4>(a, st);
     } else {
