@@ -50,30 +50,42 @@ def synthetic_batch(batch, height, width, seed, device):
     return {k: v.to(device) for k, v in b.items()}
 
 
-def cpu_baseline(height, width, budget_s=20.0):
-    """The oracle's train step (CPU restatement of the reference path, kind="port") timed on the host cores of
-    the GPU box, bounded sample: B=2 pairs per step, 1 warm-up + as many timed steps as fit in the budget."""
-    from oracle import irr_pwc_oracle as O
-    # 16 threads is the fastest setting for this graph on the GPU host (EPYC 9575F, 128 cores visible):
-    # probed 8/16/32/64/128 threads -> 0.52/0.59/0.46/0.22/0.07 pairs/s (tools/cpu_threads_probe.py)
-    threads = min(16, os.cpu_count() or 16)
+def _cpu_leg(O, height, width, batch_pairs, threads, warm=2, timed=5):
+    """median step time of the oracle's train step at one (batch, thread count) setting -> image-pairs/s"""
     torch.set_num_threads(threads)
-    B = 2
     P = O.make_trainable(O.synthetic_params(0))
     opt = O.make_adam(P)
-    batch = O.synthetic_batch(B, height, width, 1234)
-    O.train_step(P, opt, batch)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
+    batch = O.synthetic_batch(batch_pairs, height, width, 1234)
+    for _ in range(warm):
         O.train_step(P, opt, batch)
-        n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 4:
-            break
-    dt = (time.perf_counter() - t0) / n
-    return {"value": B / dt, "unit": "image-pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{n} timed steps (+1 warm-up) of the oracle train step (fwd+loss+bwd+Adam), batch {B}, "
-                      f"{height}x{width}, {threads} torch threads on the GPU host (best of 8/16/32/64/128 threads)"}
+    ts = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        O.train_step(P, opt, batch)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return batch_pairs / ts[len(ts) // 2]
+
+
+def cpu_baseline(height, width, quick=False):
+    """The oracle's train step (CPU restatement of the reference path, kind="port") timed on the host cores of the GPU box
+    with the protocol of BASELINE.md section 3: >= 2 warm-up + >= 5 timed steps, median step time; batch 2 and batch 8; the
+    fastest thread count for this graph on the host (16: probed 8/16/32/64/128 threads -> 0.52/0.59/0.46/0.22/0.07 pairs/s
+    on the 128-core EPYC 9575F box, tools/cpu_threads_probe.py -- more threads are SLOWER) and the 8-thread figure that is
+    comparable with the survey container.  ``value`` = the best of the legs.  (~2.5 min of CPU work; ``quick``: one leg.)"""
+    from oracle import irr_pwc_oracle as O
+    ncpu = os.cpu_count() or 16
+    best_thr = min(16, ncpu)
+    legs = [(2, best_thr)] if quick else [(2, best_thr), (2, min(8, ncpu)), (8, best_thr)]
+    out = []
+    for bp, thr in legs:
+        out.append({"batch": bp, "threads": thr, "pairs_per_s": round(_cpu_leg(O, height, width, bp, thr), 4)})
+    top = max(out, key=lambda r: r["pairs_per_s"])
+    return {"value": top["pairs_per_s"], "unit": "image-pairs/s", "cores": top["threads"], "kind": "port",
+            "host_cpus": ncpu, "legs": out,
+            "sample": f"oracle train step (fwd+loss+bwd+Adam) at {height}x{width}: 2 warm-up + 5 timed steps per leg, median step "
+                      f"time; legs = (batch, torch threads) {[(r['batch'], r['threads']) for r in out]}; value = the fastest "
+                      f"leg (batch {top['batch']}, {top['threads']} threads; {ncpu} host CPUs visible, more threads are slower)"}
 
 
 def main():
@@ -88,6 +100,7 @@ def main():
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=448)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick-cpu-baseline", action="store_true", help="one CPU leg (batch 2) instead of three")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-async-wgrad", action="store_true", help="keep weight gradients on the main stream")
     a = ap.parse_args()
@@ -232,7 +245,7 @@ def main():
                "step_mfma_frac": round(value / world * gf * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4) if gf else None,
                "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.height, a.width)
+            out["cpu_baseline"] = cpu_baseline(a.height, a.width, quick=a.quick_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

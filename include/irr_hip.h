@@ -19,7 +19,15 @@
  *   - return value: 0 on success, otherwise the hipError_t of the failing call / launch
  *     (the reference returns 1 on success and raises AT_ERROR on failure, correlation_cuda.cc:78-83);
  *     IRR_EINVAL (-22) for arguments outside the supported range.
- *   - launchers are re-entrant and keep no global mutable state (backward runs on autograd's thread).
+ *   - launchers are re-entrant: they may be called concurrently from several host threads (backward runs on
+ *     autograd's threads) and on several streams / devices.  Host-side state is limited to (a) read-only caches of
+ *     device properties and occupancy numbers, (b) thread-local hand-over variables inside one call, and (c) ONE
+ *     process-wide, atomic routing policy, ``irr_conv_x3_set_min_blocks`` (a tuning knob that decides which kernel
+ *     family a problem is routed to -- both families compute the same function, so a concurrent change can never
+ *     produce a wrong result, only a different choice; production code never touches it);
+ *   - kernels are launched on ``stream`` from the CALLING thread's current HIP device: make the device that owns the
+ *     stream and the buffers current first (the host binding does -- irr_amd/hip.py:device_guard -- as the reference does
+ *     with torch.cuda.device_of, models/correlation_package/correlation.py:21,34).
  */
 #ifndef IRR_HIP_H
 #define IRR_HIP_H
@@ -164,7 +172,8 @@ int irr_conv2d_fwd_x3_splitk(const float* x, const void* wq, const float* bias, 
 
 /* dW[co][ci][tap] += sum_{b,y,x} gy[b,co,y,x] * x[b,ci,y*stride+(ty-pad), x*stride+(tx-pad)]
  * gw is the plain (Cout,Cin,k,k) tensor and is ACCUMULATED into (caller zeroes it when it wants "=").
- * ws: caller-owned scratch of irr_conv2d_wgrad_ws_elems(...) floats (same shape arguments): every block column of the
+ * ws: caller-owned scratch of ws_elems >= irr_conv2d_wgrad_ws_elems(...) floats (same shape arguments; a smaller scratch is
+ * rejected with IRR_EINVAL before anything is launched): every block column of the
  * split-K launch stores its partial [co][tap][ci] image there and a second kernel adds them to gw in a fixed order
  * (no atomics, no zero-fill; the weight gradient is bit-reproducible).
  * gbias (nullable): gbias[co] += sum_{b,y,x} gy[b,co,y,x] (the bias gradient, taken from the staged gy tiles).
@@ -173,7 +182,7 @@ long irr_conv2d_wgrad_ws_elems(int B, int Cin, int H, int W, int Cout, int OH, i
                                long x_bs, long gy_bs);
 int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                          int B, int Cin, int H, int W, int Cout, int OH, int OW,
-                         int k, int stride, int dil, long x_bs, long gy_bs, void* stream);
+                         int k, int stride, int dil, long x_bs, long gy_bs, long ws_elems, void* stream);
 
 /* Weight gradient on the bf16 matrix pipe with the exact 3-way split of conv_x3 (csrc/conv_wgrad_x3.hip): same contract
  * as irr_conv2d_wgrad_f32 for k = 3, stride = 1, dilation = 1, W % 4 == 0 (gw accumulated, gbias nullable, alpha

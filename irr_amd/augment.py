@@ -103,8 +103,9 @@ def affine_warp(src, inv, window=None, noise=None, noise_std=0.0):
     B, C, H, W = src.shape
     y0, x0, OH, OW = window if window is not None else (0, 0, H, W)
     dst = src.new_empty(B, C, OH, OW)
-    hip.call("irr_affine_warp_f32", hip.ptr(src), hip.ptr(dst), hip.ptr(inv), hip.ptr(noise), float(noise_std), B, C, H, W, OH, OW, y0, x0,
-             C * H * W, C * OH * OW, hip.stream())
+    with hip.device_of(src):
+        hip.call("irr_affine_warp_f32", hip.ptr(src), hip.ptr(dst), hip.ptr(inv), hip.ptr(noise), float(noise_std), B, C, H, W, OH, OW,
+                 y0, x0, C * H * W, C * OH * OW, hip.stream())
     return dst
 
 
@@ -120,9 +121,10 @@ def affine_flow_occ(flow, occ, inv_a, theta_a, theta_b, window=None):
     if occ is not None:
         occ = occ.contiguous()
         occ_out = occ.new_empty(B, 1, OH, OW)
-    hip.call("irr_affine_flow_occ_f32", hip.ptr(flow), hip.ptr(occ), hip.ptr(flow_out), hip.ptr(occ_out), hip.ptr(inv_a),
-             hip.ptr(theta_a), hip.ptr(theta_b), B, H, W, OH, OW, y0, x0,
-             2 * H * W, H * W, 2 * OH * OW, OH * OW, hip.stream())
+    with hip.device_of(flow):
+        hip.call("irr_affine_flow_occ_f32", hip.ptr(flow), hip.ptr(occ), hip.ptr(flow_out), hip.ptr(occ_out), hip.ptr(inv_a),
+                 hip.ptr(theta_a), hip.ptr(theta_b), B, H, W, OH, OW, y0, x0,
+                 2 * H * W, H * W, 2 * OH * OW, OH * OW, hip.stream())
     return flow_out, occ_out
 
 

@@ -2,8 +2,11 @@
 
     python -m irr_amd.build [--force]
 
-One object per source (rebuilt when the source or a header is newer), linked into ONE C-ABI shared library whose
-exported symbols are exactly the functions declared in include/irr_hip.h.
+One object per source (rebuilt when the source, a header or the compiler flags changed), linked into ONE C-ABI shared
+library whose exported symbols are exactly the functions declared in include/irr_hip.h.
+
+Ablation / trace builds (the IRR_*_ABL, IRR_X3S_TRACE ... macro switches below) never overwrite the product library: they
+require ``IRR_BUILD_TAG=<name>`` and go to irr_amd/lib_<name>/; load one with ``IRR_HIP_LIB=<path to that .so>``.
 """
 from __future__ import annotations
 
@@ -15,7 +18,8 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
-LIBDIR = os.path.join(PKG, "lib")
+TAG = os.environ.get("IRR_BUILD_TAG", "")
+LIBDIR = os.path.join(PKG, "lib_" + TAG if TAG else "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libirr_hip.so")
 ARCH = "gfx950"
@@ -41,6 +45,10 @@ if os.environ.get("IRR_X3_ABL"):
     COMMON = COMMON + ["-DX3_ABL=" + os.environ["IRR_X3_ABL"]]
 if os.environ.get("IRR_WG_TR4"):
     COMMON = COMMON + ["-DWG_TR4=1"]
+_BASE_FLAGS = 7            # len(COMMON) without macro switches
+if len(COMMON) != _BASE_FLAGS and not TAG:
+    raise RuntimeError("ablation / trace macros change the kernels: set IRR_BUILD_TAG=<name> so the build goes to "
+                       "irr_amd/lib_<name>/ instead of replacing the product library")
 EXTRA = {"warp.hip": ["-ffp-contract=off"], "resize.hip": ["-ffp-contract=off"],
          "augment.hip": ["-ffp-contract=off"]}
 
@@ -62,6 +70,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
            [os.path.join(ROOT, "include", "irr_hip.h"), os.path.abspath(__file__)]
+    # the flag set is part of the build's identity: a library built with other flags is rebuilt from scratch
+    stamp = os.path.join(LIBDIR, "flags.stamp")
+    flags = " ".join(COMMON) + " | " + repr(sorted(EXTRA.items()))
+    if not os.path.exists(stamp) or open(stamp).read() != flags:
+        force = True
     jobs = []
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s[:-4] + ".o")
@@ -81,6 +94,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs = [os.path.join(OBJDIR, s[:-4] + ".o") for s in srcs]
     if force or jobs or not os.path.exists(LIB):
         run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+    with open(stamp, "w") as f:
+        f.write(flags)
     return LIB
 
 

@@ -7,8 +7,8 @@ Mirrors the reference helper ``conv(in_planes, out_planes, kernel_size, stride, 
 optionally followed by LeakyReLU(0.1).  All tensors may be channel-slice views of larger NCHW buffers
 (dense H*W planes, arbitrary batch stride), which is how the DenseNet decoders avoid ``torch.cat``.
 
-``IRR_CONV_BACKEND=miopen`` swaps in torch's GPU convolution (bring-up / A-B comparison only; it is not
-the product path and is never selected implicitly).
+There is no other backend in this module: every launch goes to libirr_hip.so (an A/B harness against torch's GPU
+convolution lives in tools/torch_conv_backend.py, outside the product).
 """
 from __future__ import annotations
 
@@ -16,12 +16,8 @@ import os
 from typing import Optional, Tuple
 
 import torch
-import torch.nn.functional as F
 
 from . import hip
-
-BACKEND = os.environ.get("IRR_CONV_BACKEND", "hip")
-
 
 class KernelTimer:
     """Optional per-launch HIP-event timing of the MFMA conv kernel (bench.py's ``roofline`` object).
@@ -59,13 +55,6 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
-
-
-def set_backend(name: str) -> None:
-    global BACKEND
-    if name not in ("hip", "miopen"):
-        raise ValueError(name)
-    BACKEND = name
 
 
 def out_hw(h: int, w: int, k: int, stride: int, dil: int) -> Tuple[int, int]:
@@ -117,7 +106,7 @@ _X3_ENV_DONE = [False]
 
 
 def x3_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, dil: int) -> int:
-    if MATH != "x3" or BACKEND != "hip":
+    if MATH != "x3":
         return 0
     if not _X3_ENV_DONE[0]:
         _X3_ENV_DONE[0] = True
@@ -174,17 +163,6 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     if out is None:
         out = torch.empty(B, cout, oh, ow, device=x.device, dtype=torch.float32)
     assert out.shape == (B, cout, oh, ow), (out.shape, (B, cout, oh, ow))
-    if BACKEND == "miopen":
-        v = F.conv2d(x, weight.detach(), bias.detach() if bias is not None else None, stride=stride,
-                     padding=((k - 1) * dil) // 2, dilation=dil)
-        if lrelu:
-            v = F.leaky_relu(v, 0.1)
-        v = v * alpha if res is None else res + alpha * v
-        if accumulate:
-            out += v
-        else:
-            out.copy_(v)
-        return out
     if cout <= 4 and stride == 1:
         wc = weight.detach().contiguous()
         hip.call("irr_conv2d_smallco_fwd_f32", hip.ptr(x), hip.ptr(wc), hip.ptr(bias.detach() if bias is not None else None),
@@ -230,18 +208,8 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
     if gx is None:
         gx = torch.empty(B, cin, H, W, device=gy.device, dtype=torch.float32)
         accumulate = False
-    if (res is not None or alpha != 1.0) and not (stride == 1 and cout >= 1 and BACKEND != "miopen"):
+    if (res is not None or alpha != 1.0) and stride != 1:
         raise ValueError("res/alpha epilogue is only wired for stride-1 data gradients")
-    if BACKEND == "miopen":
-        v = torch.nn.grad.conv2d_input((B, cin, H, W), weight.detach(), gy, stride=stride,
-                                       padding=((k - 1) * dil) // 2, dilation=dil)
-        if accumulate:
-            gx += v
-        else:
-            gx.copy_(v)
-        if mask is not None and nmask > 0:
-            gx[:, :nmask] *= torch.where(mask[:, :nmask] > 0, 1.0, 0.1)
-        return gx
     margs = (hip.ptr(mask), hip.bs(mask), int(nmask)) if (mask is not None and nmask > 0) else (None, 0, 0)
     if stride == 1 and cout <= 2 and k == 3 and res is None and alpha == 1.0:
         # tiny-Cout heads: a pure HBM stream over the Cin-channel gradient buffer (VALU kernel, csrc/conv_small.hip)
@@ -302,12 +270,6 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
     _, _, oh, ow = gy.shape
     if gw is None:
         gw = torch.zeros(cout, cin, k, k, device=x.device, dtype=torch.float32)
-    if BACKEND == "miopen":
-        gw += alpha * torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), gy, stride=stride,
-                                                  padding=((k - 1) * dil) // 2, dilation=dil)
-        if gbias is not None:
-            gbias += alpha * gy.sum(dim=(0, 2, 3))
-        return gw
     assert gw.is_contiguous()
     use_x3 = (MATH == "x3" and not (cout <= 4 and stride == 1)
               and bool(hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, k, stride, dil)))
@@ -337,7 +299,7 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
                  cout, hip.bs(x), hip.bs(gy), hip.stream())
         return gw
     hip.call("irr_conv2d_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W, cout, oh, ow, k, stride, dil,
-             hip.bs(x), hip.bs(gy), hip.stream())
+             hip.bs(x), hip.bs(gy), nws, hip.stream())
     return gw
 
 
@@ -412,7 +374,7 @@ def lrelu_bwd_bias(gy: torch.Tensor, y: Optional[torch.Tensor], lrelu: bool, gpr
 # ----------------------------------------------------------------------------------------------
 # autograd: one conv() block
 # ----------------------------------------------------------------------------------------------
-class _ConvBlock(torch.autograd.Function):
+class _ConvBlock(hip.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride: int, dil: int, lrelu: bool, res, alpha: float):
         if not x.is_cuda:
@@ -476,7 +438,7 @@ def conv_block(x, weight, bias, stride: int = 1, dil: int = 1, lrelu: bool = Tru
 # ----------------------------------------------------------------------------------------------
 # autograd: the whole DenseNet estimator (FlowEstimatorDense / OccEstimatorDense) as ONE node
 # ----------------------------------------------------------------------------------------------
-class _DenseEstimatorFn(torch.autograd.Function):
+class _DenseEstimatorFn(hip.Function):
     """conv1..conv5 (+LeakyReLU, outputs PREPENDED) and conv_last of models/pwc_modules.py:153-170 / 190-207
     on ONE preallocated NCHW buffer: every conv reads a channel suffix and writes the slice in front of it,
     so there is no torch.cat; the backward walks the same buffer layout with a gradient buffer G in which
@@ -627,7 +589,7 @@ def dense_estimator(x, base, weights_and_biases):
 # ----------------------------------------------------------------------------------------------
 # autograd: a sequential chain of conv() blocks as ONE node
 # ----------------------------------------------------------------------------------------------
-class _ConvChainFn(torch.autograd.Function):
+class _ConvChainFn(hip.Function):
     """y = [res +] conv_n(... conv_1(x)) for the purely sequential sub-networks (ContextNetwork /
     OccContextNetwork, models/pwc_modules.py:210-243; the 7-conv stacks of RefineFlow / RefineOcc,
     models/irr_modules.py:71-79,115-123; the (stride-2, stride-1) pairs of FeatureExtractor,
@@ -714,7 +676,7 @@ def conv_chain(x, layers, res=None):
 # ----------------------------------------------------------------------------------------------
 # autograd: OccUpsampleNetwork (models/irr_modules.py:30-56) as ONE node
 # ----------------------------------------------------------------------------------------------
-class _OccUpsampleFn(torch.autograd.Function):
+class _OccUpsampleFn(hip.Function):
     """x_in -> init_conv -> 3 x [x += 0.1 * res_convs(x)] (shared weights) -> x_init + res_end_conv(x) -> out_convs + occ.
 
     The network runs on 32-channel maps at 1/2 and full resolution (41 % of all conv activation traffic,

@@ -437,8 +437,9 @@ static int cu_count() {
 }
 
 // plan-only mode: the launch functions record their grid.x (= number of partial workspace images) and launch nothing
-static bool g_plan_only = false;
-static long g_parts = 0;
+// (thread-local: the hand-over is between two statements of one host thread; concurrent callers do not see each other)
+static thread_local bool g_plan_only = false;
+static thread_local long g_parts = 0;
 
 template <int MTB, int KS>
 int launch(WgArgs a, hipStream_t st) {
@@ -621,18 +622,27 @@ extern "C" long irr_conv2d_wgrad_ws_elems(int B, int Cin, int H, int W, int Cout
   a.stride = stride; a.dil = dil; a.pad = ((k - 1) * dil) / 2;
   const long per = wgrad_batch_per(B, Cin, H, W, Cout, x_bs, gy_bs);
   if (per < 1) return 0;
-  a.B = (int)per;                                  // the largest slice has the most block columns
-  g_plan_only = true;
-  g_parts = 0;
-  const int rc = wgrad_slice(a, k, stride, dil, nullptr);
-  g_plan_only = false;
-  return rc ? 0 : g_parts * (long)Cout * Cin * k * k;
+  // grid.x is not monotone in the slice size (ceil(nchunks / max(8, ceil(nchunks / xs)))): take the maximum over the slice
+  // sizes the launch loop will really use (the full slices and the remainder)
+  long parts = 0;
+  const int sizes[2] = {(int)per, (int)(B % per)};
+  for (int i = 0; i < 2; ++i) {
+    if (sizes[i] <= 0) continue;
+    a.B = sizes[i];
+    g_plan_only = true;
+    g_parts = 0;
+    const int rc = wgrad_slice(a, k, stride, dil, nullptr);
+    g_plan_only = false;
+    if (rc) return 0;
+    if (g_parts > parts) parts = g_parts;
+  }
+  return parts * (long)Cout * Cin * k * k;
 }
 
 extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
                                     int Cin, int H, int W,
                                     int Cout, int OH, int OW, int k, int stride, int dil, long x_bs, long gy_bs,
-                                    void* stream) {
+                                    long ws_elems, void* stream) {
   if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return IRR_EINVAL;
   if ((k != 1 && k != 3) || stride < 1 || dil < 1) return IRR_EINVAL;
   WgArgs a;
@@ -649,6 +659,16 @@ extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
     a.B = (B - b0) < per ? (B - b0) : (int)per;
     a.x = x + (long)b0 * x_bs;
     a.gy = gy + (long)b0 * gy_bs;
+    if (!atomic) {                                                   // the partial images of this slice must fit the caller's scratch
+      g_plan_only = true;
+      g_parts = 0;
+      const int prc = wgrad_slice(a, k, stride, dil, nullptr);
+      g_plan_only = false;
+      if (prc) return prc;
+      if (g_parts * n > ws_elems) return IRR_EINVAL;
+    } else if (n > ws_elems) {
+      return IRR_EINVAL;
+    }
     const int rc = wgrad_slice(a, k, stride, dil, (hipStream_t)stream);
     if (rc) return rc;
     if (!atomic) {

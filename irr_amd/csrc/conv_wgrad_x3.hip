@@ -346,7 +346,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   }
 }
 
-int g_last_parts = 0;             // grid.x of the last launch_wx3 (host-side hand-over to the reduce launch)
+thread_local int g_last_parts = 0;   // grid.x of this thread's last launch_wx3 (host-side hand-over to the reduce launch)
 
 int g_cu_count = 0;
 int cu_count() {

@@ -24,6 +24,7 @@
 //   * epilogue identical to conv_fwd.hip (bias, LeakyReLU, residual/scale, "+=", LeakyReLU'-mask).
 #include "x3_split.h"
 #include <stdlib.h>
+#include <atomic>
 
 #ifdef X3S_TRACE
 static unsigned long long* g_x3s_dbg = nullptr;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
   }
 }
 
-static int g_min_blocks = 384;     // launches with fewer blocks cannot fill 256 CUs x 2 blocks: they stay on the fp32 kernels
+static std::atomic<int> g_min_blocks{384};     // (the ONE process-wide routing policy, see irr_conv_x3_set_min_blocks) launches with fewer blocks cannot fill 256 CUs x 2 blocks: they stay on the fp32 kernels
 
 // ---------------------------------------------------------------------------------------------------------------
 // Streaming variant for the 32-channel layers (OccUpsampleNetwork at 1/2 and full resolution, models/irr_modules.py:30-56:
@@ -760,9 +761,7 @@ extern "C" int irr_x3s_trace_dump(unsigned long long* host) {
 #endif
 
 extern "C" int irr_conv_x3_set_min_blocks(int n) {
-  const int old = g_min_blocks;
-  if (n >= 0) g_min_blocks = n;
-  return old;
+  return n >= 0 ? g_min_blocks.exchange(n) : g_min_blocks.load();
 }
 
 extern "C" long irr_conv_x3_packed_bytes(int Cin, int Cout) {

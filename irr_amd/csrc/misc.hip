@@ -1,2 +1,2 @@
 #include "common.h"
-extern "C" int irr_abi_version(void) { return 1; }
+extern "C" int irr_abi_version(void) { return 2; }

@@ -45,7 +45,7 @@ def _need_cuda(*ts):
 # ----------------------------------------------------------------------------------------------
 # cost volume
 # ----------------------------------------------------------------------------------------------
-class _CostVolume(torch.autograd.Function):
+class _CostVolume(hip.Function):
     @staticmethod
     def forward(ctx, f1, f2, lrelu: bool):
         _need_cuda(f1, f2)
@@ -92,7 +92,7 @@ def compute_cost_volume(feat1, feat2, param_dict):
 # ----------------------------------------------------------------------------------------------
 # warp
 # ----------------------------------------------------------------------------------------------
-class _Warp(torch.autograd.Function):
+class _Warp(hip.Function):
     @staticmethod
     def forward(ctx, x, flow, height_im: int, width_im: int, div_flow: float, mask_thr: float):
         _need_cuda(x, flow)
@@ -132,7 +132,7 @@ def warp(x, flow, height_im: int, width_im: int, div_flow: float, mask_threshold
 # ----------------------------------------------------------------------------------------------
 # bilinear resize, align_corners=True
 # ----------------------------------------------------------------------------------------------
-class _ResizeAC(torch.autograd.Function):
+class _ResizeAC(hip.Function):
     @staticmethod
     def forward(ctx, x, oh: int, ow: int, alpha: float):
         _need_cuda(x)
@@ -170,7 +170,7 @@ def upsample2d_as(inputs, target_as, mode="bilinear"):
 # ----------------------------------------------------------------------------------------------
 # bilateral refinement tail
 # ----------------------------------------------------------------------------------------------
-class _RefineTail(torch.autograd.Function):
+class _RefineTail(hip.Function):
     @staticmethod
     def forward(ctx, feat, v, scale0: float, scale1: float):
         _need_cuda(feat, v)
@@ -206,7 +206,7 @@ def refine_tail(feat, v, scale=(1.0, 1.0)):
 # ----------------------------------------------------------------------------------------------
 # nearest x2
 # ----------------------------------------------------------------------------------------------
-class _Nearest2x(torch.autograd.Function):
+class _Nearest2x(hip.Function):
     @staticmethod
     def forward(ctx, x):
         _need_cuda(x)

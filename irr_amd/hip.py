@@ -16,7 +16,8 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_PKG), "include", "irr_hip.h")
-LIB_PATH = os.path.join(_PKG, "lib", "libirr_hip.so")
+# IRR_HIP_LIB: load another build of the SAME ABI (ablation / trace builds of irr_amd.build with IRR_BUILD_TAG)
+LIB_PATH = os.environ.get("IRR_HIP_LIB") or os.path.join(_PKG, "lib", "libirr_hip.so")
 
 _CTYPES = {
     "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
@@ -97,7 +98,46 @@ def ptr(t: torch.Tensor | None) -> int | None:
 
 
 def stream() -> int:
+    """hipStream_t of the CURRENT device's current stream.  Kernels are launched on the calling thread's current device, so
+    every entry into the library happens under ``device_of`` / ``Function`` below (the reference's counterpart is
+    ``with torch.cuda.device_of(input1)``, models/correlation_package/correlation.py:21,34)."""
     return torch.cuda.current_stream().cuda_stream
+
+
+class device_of:
+    """``with hip.device_of(t):`` -- makes t's device current for the launches inside (no-op when it already is, or when t
+    is not a HIP tensor: the operators then raise their own 'no CPU fallback' error)."""
+
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, t):
+        self.idx = t.device.index if (isinstance(t, torch.Tensor) and t.is_cuda) else -1
+        self.prev = -1
+
+    def __enter__(self):
+        if self.idx >= 0 and self.idx != torch.cuda.current_device():
+            self.prev = torch.cuda._exchange_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda._maybe_exchange_device(self.prev)
+        return False
+
+
+class Function(torch.autograd.Function):
+    """autograd.Function whose forward runs with the device of its first HIP tensor argument current (the autograd engine
+    already does the same for backward: its worker threads are per device)."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with device_of(a):
+                        return super().apply(*args, **kwargs)
+                break
+        return super().apply(*args, **kwargs)
 
 
 def check_plane_dense(t: torch.Tensor) -> int:

@@ -41,11 +41,12 @@ def avg_pool_to(t: torch.Tensor, h: int, w: int, scale: float = 1.0) -> torch.Te
         raise ValueError(f"target {H}x{W} is not an integer multiple of level size {h}x{w}")
     t = t.contiguous()
     out = torch.empty(B, C, h, w, device=t.device, dtype=torch.float32)
-    hip.call("irr_avgpool_f32", hip.ptr(t), hip.ptr(out), B * C, h, w, H // h, float(scale), hip.stream())
+    with hip.device_of(t):
+        hip.call("irr_avgpool_f32", hip.ptr(t), hip.ptr(out), B * C, h, w, H // h, float(scale), hip.stream())
     return out
 
 
-class _EpeSum(torch.autograd.Function):
+class _EpeSum(hip.Function):
     """weight * sum_p ||tgt - flow||_2  (losses.py:8-10 with .sum())."""
 
     @staticmethod
@@ -71,7 +72,7 @@ class _EpeSum(torch.autograd.Function):
         return gf, None, None
 
 
-class _F1BalLoss(torch.autograd.Function):
+class _F1BalLoss(hip.Function):
     """weight * f1_score_bal_loss(sigmoid(logit), target)  (losses.py:39-48, 553-556)."""
 
     @staticmethod

@@ -37,9 +37,10 @@ class FusedAdam:
     def step(self):
         self.t += 1
         b1, b2 = self.betas
-        hip.call("irr_adam_step_f32", hip.ptr(self.param_flat), hip.ptr(self.arena.flat), hip.ptr(self.exp_avg),
-                 hip.ptr(self.exp_avg_sq), self.param_flat.numel(), self.lr, b1, b2, self.eps, self.weight_decay,
-                 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, 1.0, hip.stream())
+        with hip.device_of(self.param_flat):
+            hip.call("irr_adam_step_f32", hip.ptr(self.param_flat), hip.ptr(self.arena.flat), hip.ptr(self.exp_avg),
+                     hip.ptr(self.exp_avg_sq), self.param_flat.numel(), self.lr, b1, b2, self.eps, self.weight_decay,
+                     1.0 - b1 ** self.t, 1.0 - b2 ** self.t, 1.0, hip.stream())
         # the kernel updates the parameters behind autograd's back: invalidate cached packed weights
         conv.WEIGHT_EPOCH[0] += 1
 

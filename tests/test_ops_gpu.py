@@ -29,6 +29,25 @@ def test_cost_volume(golden_dir, case):
     np.testing.assert_allclose(f2.grad.cpu().numpy(), g[f"corr_{case}_g2"], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_correlation_module_operator_signature(golden_dir, case):
+    """The drop-in operator itself: Correlation(pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply)
+    (models/correlation_package/correlation.py:47-61) called like the reference calls it, values and both gradients
+    against the reference fixtures; the native op divides by the channel count exactly like compute_cost_volume's mean."""
+    import irr_amd
+    g = _g(golden_dir)
+    corr = irr_amd.Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1)
+    f1, f2 = D(g[f"corr_{case}_f1"], True), D(g[f"corr_{case}_f2"], True)
+    out = corr(f1, f2)
+    assert out.shape == (f1.shape[0], 81, f1.shape[2], f1.shape[3])
+    out.backward(D(g[f"corr_{case}_go"]))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"corr_{case}_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(f1.grad.cpu().numpy(), g[f"corr_{case}_g1"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(f2.grad.cpu().numpy(), g[f"corr_{case}_g2"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        irr_amd.Correlation(3, 1, 3, 1, 1, 1)
+
+
 def test_cost_volume_fused_lrelu(golden_dir):
     from irr_amd import functional as Fn
     g = _g(golden_dir)

@@ -8,6 +8,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from irr_amd import conv as C  # noqa: E402
+from tools import torch_conv_backend as TB  # noqa: E402
+import contextlib  # noqa: E402
 
 SHAPES = [  # name, Cin, Cout, k, stride, dil, H, W
     ("dense.conv1 L4", 115, 128, 3, 1, 1, 96, 112),
@@ -57,14 +59,13 @@ def main():
         gf = 2.0 * B * oh * ow * cout * cin * k * k / 1e9
         row = f"{name:22s} {gf:8.1f} "
         for be in backends:
-            C.set_backend(be)
-            t_f = timeit(lambda: C.conv_forward(x, w, bias, st, dil, True))
-            t_d = timeit(lambda: C.conv_dgrad(gy, w, st, dil, (H, W)))
-            gw = torch.zeros_like(w)
-            t_w = timeit(lambda: C.conv_wgrad(x, gy, w.shape, st, dil, gw))
+            with (TB.torch_convs() if be == "miopen" else contextlib.nullcontext()):
+                t_f = timeit(lambda: C.conv_forward(x, w, bias, st, dil, True))
+                t_d = timeit(lambda: C.conv_dgrad(gy, w, st, dil, (H, W)))
+                gw = torch.zeros_like(w)
+                t_w = timeit(lambda: C.conv_wgrad(x, gy, w.shape, st, dil, gw))
             row += " ".join(f"{t:6.2f}ms{gf / t:5.1f}TF" for t in (t_f, t_d, t_w)) + " "
         print(row, flush=True)
-    C.set_backend("hip")
 
 
 if __name__ == "__main__":

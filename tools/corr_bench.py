@@ -2,7 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from irr_amd import functional as Fn
-from tools.test_x3 import timeit
+from tools.x3_check import timeit
 for C, H, W in [(32, 96, 112), (32, 48, 56), (32, 24, 28)]:
     B = 64
     f1 = torch.randn(B, C, H, W, device="cuda", requires_grad=True); f2 = torch.randn(B, C, H, W, device="cuda", requires_grad=True)

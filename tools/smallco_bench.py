@@ -2,7 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from irr_amd import conv as C
-from tools.test_x3 import timeit
+from tools.x3_check import timeit
 for (B, cin, H, W, co) in ((64, 563, 96, 112, 2), (64, 562, 96, 112, 1), (64, 563, 48, 56, 2), (64, 563, 24, 28, 2), (64, 32, 96, 112, 2)):
     x = torch.randn(B, cin, H, W, device="cuda"); w = torch.randn(co, cin, 3, 3, device="cuda") * 0.05; b = torch.randn(co, device="cuda")
     gy = torch.randn(B, co, H, W, device="cuda"); gw = torch.zeros(co, cin, 3, 3, device="cuda"); gb = torch.zeros(co, device="cuda")

@@ -6,7 +6,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from irr_amd import conv as C, hip  # noqa: E402
-from tools.test_x3 import timeit  # noqa: E402
+from tools.x3_check import timeit  # noqa: E402
 
 ACC = [  # cin, cout, B, H, W
     (115, 128, 2, 24, 32), (40, 128, 1, 16, 48), (371, 96, 1, 12, 56), (64, 128, 2, 8, 40), (35, 96, 1, 20, 64), (565, 128, 1, 8, 112),

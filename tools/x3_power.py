@@ -2,7 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from irr_amd import conv as C
-from tools.test_x3 import timeit
+from tools.x3_check import timeit
 B, cin, cout, H, W = 64, 565, 128, 96, 112
 gf = 2.0 * B * H * W * cout * cin * 9 / 1e9
 for name, fx, fw in (("random", torch.randn, torch.randn), ("zeros", torch.zeros, torch.zeros), ("ones", torch.ones, torch.ones)):
