@@ -12,6 +12,7 @@ convolution lives in tools/torch_conv_backend.py, outside the product).
 """
 from __future__ import annotations
 
+import collections
 import os
 from typing import Optional, Tuple
 
@@ -55,6 +56,9 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
+
+# launches per kernel family since the last clear() -- what a step was ROUTED to (tests assert on it, bench.py reports it)
+LAUNCHES: "collections.Counter[str]" = collections.Counter()
 
 
 def out_hw(h: int, w: int, k: int, stride: int, dil: int) -> Tuple[int, int]:
@@ -165,6 +169,7 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     assert out.shape == (B, cout, oh, ow), (out.shape, (B, cout, oh, ow))
     if cout <= 4 and stride == 1:
         wc = weight.detach().contiguous()
+        LAUNCHES["fwd_smallco"] += 1
         hip.call("irr_conv2d_smallco_fwd_f32", hip.ptr(x), hip.ptr(wc), hip.ptr(bias.detach() if bias is not None else None),
                  hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, k, dil, hip.bs(x), hip.bs(out),
                  hip.bs(res) if res is not None else 0, int(lrelu), float(alpha), int(accumulate), hip.stream())
@@ -177,7 +182,9 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                 hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
                 int(lrelu), float(alpha), int(accumulate), None, 0, 0, hip.stream())
         variant = 100000 + code
+        LAUNCHES["fwd_x3s" if code == 9001 else "fwd_x3"] += 1
     else:
+        LAUNCHES["fwd_f32"] += 1
         wp = packed_weights(weight, False)
         args = ("irr_conv2d_fwd_f32", hip.ptr(x), hip.ptr(wp), hip.ptr(bias.detach() if bias is not None else None),
                 hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, oh, ow, k, stride, dil,
@@ -214,6 +221,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
     if stride == 1 and cout <= 2 and k == 3 and res is None and alpha == 1.0:
         # tiny-Cout heads: a pure HBM stream over the Cin-channel gradient buffer (VALU kernel, csrc/conv_small.hip)
         wc = weight.detach().contiguous()
+        LAUNCHES["dgrad_smallco"] += 1
         hip.call("irr_conv2d_smallco_dgrad_f32", hip.ptr(gy), hip.ptr(wc), hip.ptr(gx), margs[0], B, cin, H, W, cout, dil,
                  hip.bs(gy), hip.bs(gx), margs[1], margs[2], int(accumulate), hip.stream())
         return gx
@@ -230,7 +238,9 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                     dil, hip.bs(gy), hip.bs(gx), hip.bs(res) if res is not None else 0, 0, float(alpha),
                     int(accumulate), *margs, hip.stream())
             variant = 100000 + code
+            LAUNCHES["dgrad_x3s" if code == 9001 else "dgrad_x3"] += 1
         else:
+            LAUNCHES["dgrad_f32"] += 1
             wp = packed_weights(weight, True)
             args = ("irr_conv2d_fwd_f32", hip.ptr(gy), hip.ptr(wp), None, hip.ptr(res), hip.ptr(gx), B, cout, oh, ow, cin, H, W,
                     k, 1, dil, hip.bs(gy), hip.bs(gx), hip.bs(res) if res is not None else 0, 0, float(alpha),
@@ -282,6 +292,8 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
     else:
         nws = hip.lib().irr_conv2d_wgrad_ws_elems(B, cin, H, W, cout, oh, ow, k, stride, dil, hip.bs(x), hip.bs(gy))
     ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+    LAUNCHES["wgrad_smallci" if smallci else "wgrad_smallco" if (cout <= 4 and stride == 1) else
+             "wgrad_x3_dil" if (use_x3 and dil > 1) else "wgrad_x3" if use_x3 else "wgrad_f32"] += 1
     if smallci:
         hip.call("irr_conv2d_smallci_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
                  cout, oh, ow, stride, dil, hip.bs(x), hip.bs(gy), hip.stream())
@@ -316,6 +328,8 @@ class WgradSide:
         self.views = views                      # id(parameter) -> flat-arena view with the parameter's shape
         dev = next(iter(views.values())).device
         self.stream = torch.cuda.Stream(device=dev)
+        self._inflight = collections.deque()    # (event on the lane, tensors its launch reads)
+        self.on_launch = None                   # optional hook(weight, bias) after each routed launch (ddp: early buckets)
 
     def route(self, weight, bias):
         gw = self.views.get(id(weight))
@@ -325,18 +339,30 @@ class WgradSide:
         return gw, gb
 
     def launch(self, fn, tensors):
+        """Run ``fn`` on the lane after everything enqueued so far on the current stream.  The tensors it reads are kept
+        ALIVE (strong references) until the lane has passed the launch: (a) the caching allocator cannot recycle them
+        (``record_stream`` as well, for the time after the reference is dropped), and (b) a tensor with a second owner is
+        never accumulated into IN PLACE by the autograd engine (InputBuffer::accumulate only steals a gradient whose
+        use_count is 1), nor handed to a consumer as its exclusive property -- whatever the model code around the node
+        does with the same gradient tensor (``a = a + b`` feeding two nodes, models/pwcnet_irr*.py)."""
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(main)
         self.stream.wait_event(ev)
         with torch.cuda.stream(self.stream):
             fn()
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self.stream)     # keep the caching allocator from recycling them too early
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        keep = [t for t in tensors if t is not None]
+        for t in keep:
+            t.record_stream(self.stream)
+        self._inflight.append((done, keep))
+        while self._inflight and self._inflight[0][0].query():
+            self._inflight.popleft()
 
     def join(self):
         torch.cuda.current_stream().wait_stream(self.stream)
+        self._inflight.clear()                   # later work on the current stream is ordered after the lane
 
 
 SIDE: Optional[WgradSide] = None
@@ -517,6 +543,7 @@ class _DenseEstimatorFn(hip.Function):
             if last and not ctx.needs_input_grad[0]:
                 break
             margs = (None if last else hip.ptr(buf[:, t0:t1]), 0 if last else hip.bs(buf), 0 if last else t1 - t0)
+            LAUNCHES["dense_column_x3" if use_x3[k_] else "dense_column_f32"] += 1
             if use_x3[k_]:
                 args = ("irr_conv2d_fwd_x3", hip.ptr(G), hip.ptr(packs[k_]), None, None, hip.ptr(G[:, t0:t1]), B, t0, H, W,
                         t1 - t0, 1, hip.bs(G), hip.bs(G), 0, 0, 1.0, 1, *margs, hip.stream())

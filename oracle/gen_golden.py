@@ -268,6 +268,39 @@ def gen_e2e_big(out_dir, B=1, H=384, W=448):
     np.savez_compressed(os.path.join(out_dir, f"e2e_B{B}_{H}x{W}.npz"), **d)
 
 
+def gen_e2e_train_x3(out_dir, B=4, H=384, W=448):
+    """Train step at a size where the build's DEFAULT routing sends the level-4 decoder / context / refine layers to the
+    bf16x3-split kernels (2B = 8 samples of 96x112: 384 blocks, 86 016 pixels) -- robust-mask mode: losses, 124 gradient
+    norms / sums, post-Adam parameter checksums, and the level-4 / full-resolution outputs of sample 0."""
+    P = O.synthetic_params(0)
+    batch = O.synthetic_batch(B, H, W, 1234)
+    names = sorted(P.keys())
+    d = {"param_names": np.array(names)}
+    set_mode(True, True)
+    m, args = ref_model(P)
+    args.batch_size = B
+    m.train()
+    lossm = losses.MultiScaleEPE_PWC_Bi_Occ_upsample(args)
+    lossm.train()
+    out = m({"input1": batch["input1"].clone().requires_grad_(True), "input2": batch["input2"].clone().requires_grad_(True)})
+    ld = lossm(out, batch)
+    ld["total_loss"].backward()
+    sd = dict(m.named_parameters())
+    d["robust_train_losses"] = np.array([float(ld["flow_loss"]), float(ld["occ_loss"]), float(ld["total_loss"])])
+    d["robust_train_gradnorm"] = np.array([float(sd[n].grad.double().norm()) for n in names])
+    d["robust_train_gradsum"] = np.array([float(sd[n].grad.double().sum()) for n in names])
+    d["robust_train_l4_flow_f"] = npf(out["flow"][4][2][:1])
+    d["robust_train_l4_occ_f"] = npf(out["occ"][4][2][:1])
+    d["robust_train_l6_flow_f"] = npf(out["flow"][6][0][:1, :, ::4, ::4])
+    d["robust_train_l6_occ_f"] = npf(out["occ"][6][0][:1, :, ::4, ::4])
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=4e-4)
+    opt.step()
+    d["robust_poststep_sum"] = np.array([float(sd[n].detach().double().sum()) for n in names])
+    set_mode(False, False)
+    print("train losses", d["robust_train_losses"], "grad-L2", float(np.sqrt((d["robust_train_gradnorm"] ** 2).sum())))
+    np.savez_compressed(os.path.join(out_dir, f"e2e_train_B{B}_{H}x{W}.npz"), **d)
+
+
 def gen_init(out_dir):
     """Fingerprint of the reference's own MSRA init under torch.manual_seed(0)."""
     m, _ = ref_model(None, seed=0)
@@ -466,7 +499,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
-    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "pwcnet": gen_pwcnet_plumbing, "noise": gen_noise_floor, "augment": gen_augment, "variants": gen_variants, "flowvis": gen_flowvis}
+    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "trainx3": gen_e2e_train_x3, "pwcnet": gen_pwcnet_plumbing, "noise": gen_noise_floor, "augment": gen_augment, "variants": gen_variants, "flowvis": gen_flowvis}
     for k, fn in steps.items():
         if a.only and k not in a.only.split(","):
             continue

@@ -25,3 +25,26 @@ def _built_library():
     if not os.path.exists(hip.LIB_PATH):
         build.build(verbose=False)
     yield
+
+
+@pytest.fixture(params=["default", "x3_all"])
+def routing(request):
+    """Kernel-family routing of the conv layers for the reference-fixture tests.  ``default``: what the library picks for
+    the (small) test shapes -- mostly the fp32-MFMA family.  ``x3_all``: irr_conv_x3_set_min_blocks(0), i.e. every layer
+    the bf16x3-split family ACCEPTS runs on it (conv_x3 / conv_x3s forward and data gradient incl. the combined DenseNet
+    column packs, conv_wgrad_x3) -- the routing bench.py's BASELINE-size step gets by default."""
+    from irr_amd import conv as C, hip
+    C.x3_code(1, 64, 8, 8, 64, 3, 1, 1)                  # applies IRR_X3_MIN_BLOCKS once, if set
+    C.LAUNCHES.clear()
+    if request.param == "default":
+        yield "default"
+        return
+    old = hip.lib().irr_conv_x3_set_min_blocks(0)
+    C.set_math("x3")
+    try:
+        yield "x3_all"
+        x3 = sum(v for k, v in C.LAUNCHES.items() if "x3" in k)
+        assert x3 > 0, f"x3_all routing launched no x3 kernel: {dict(C.LAUNCHES)}"
+    finally:
+        hip.lib().irr_conv_x3_set_min_blocks(old)
+        C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))

@@ -572,3 +572,103 @@ def test_conv_x3s_two_cotiles(nmask, x3_everywhere):
     if nmask:
         ref[:, :nmask] *= torch.where(m2[:, :nmask] > 0, 1.0, 0.1).double()
     assert (gx.cpu().double() - ref).abs().max().item() <= 2e-6 * float(ref.abs().max())
+
+
+# ---- the DenseNet estimators on the x3 family: combined-column data gradient (irr_conv_pack_weights_x3_sub) -----------
+def _dense_ref64(x, base, ws, bs):
+    """models/pwc_modules.py:153-170 / 190-207 in fp64 torch: (cat([x5, est]), est), est = base + conv_last(x5)"""
+    cur = x
+    for i in range(5):
+        cur = torch.cat([F.leaky_relu(F.conv2d(cur, ws[i], bs[i], padding=1), 0.1), cur], dim=1)
+    est = base + F.conv2d(cur, ws[5], bs[5], padding=1)
+    return torch.cat([cur, est], dim=1), est
+
+
+@pytest.mark.parametrize("which,B,H,W", [("flow_estimators", 2, 32, 48), ("occ_estimators", 1, 40, 56), ("flow_estimators", 3, 24, 28)])
+def test_dense_estimator_on_x3_vs_fp64(which, B, H, W, x3_everywhere):
+    """FlowEstimatorDense / OccEstimatorDense ``forward_residual`` (the model's fast path) forward AND backward with every
+    layer on the x3 family -- five forward launches into channel slices, conv_last head, and the column-wise backward:
+    pack mode 2 (``irr_conv_pack_weights_x3_sub``) -> conv_x3 with accumulate + LeakyReLU'-mask epilogue on slices of the
+    gradient buffer, conv_wgrad_x3 for dW / db -- against an fp64 torch restatement of the reference module."""
+    import irr_amd
+    from irr_amd import conv as C
+    import types
+    torch.manual_seed(0)
+    m = irr_amd.PWCNet(types.SimpleNamespace(batch_size=B, model_div_flow=0.05)).cuda().train()
+    est = getattr(m, which)
+    E = 2 if which == "flow_estimators" else 1
+    cin0 = 81 + 32 + E
+    g = torch.Generator().manual_seed(B * 100 + H)
+    for layer in (est.conv1, est.conv2, est.conv3, est.conv4, est.conv5, est.conv_last):     # MSRA biases are zero: randomise them
+        with torch.no_grad():
+            layer.bias.copy_(torch.randn(layer.bias.shape, generator=g) * 0.1)
+    x = torch.randn(B, cin0, H, W, generator=g)
+    base = torch.randn(B, E, H, W, generator=g)
+    gi = torch.randn(B, 448 + cin0 + E, H, W, generator=g)
+    gf = torch.randn(B, E, H, W, generator=g)
+    layers = (est.conv1, est.conv2, est.conv3, est.conv4, est.conv5, est.conv_last)
+    ws = [l.weight.detach().cpu().double().requires_grad_(True) for l in layers]
+    bs = [l.bias.detach().cpu().double().requires_grad_(True) for l in layers]
+    x64, b64 = x.double().requires_grad_(True), base.double().requires_grad_(True)
+    buf_r, est_r = _dense_ref64(x64, b64, ws, bs)
+    ((buf_r * gi.double()).sum() + (est_r * gf.double()).sum()).backward()
+    C.LAUNCHES.clear()
+    xd, bd = x.cuda().requires_grad_(True), base.cuda().requires_grad_(True)
+    buf, out = est.forward_residual(xd, bd)
+    ((buf * gi.cuda()).sum() + (out * gf.cuda()).sum()).backward()
+    assert C.LAUNCHES["dense_column_x3"] == 5 and C.LAUNCHES["dense_column_f32"] == 0, dict(C.LAUNCHES)
+    assert C.LAUNCHES["fwd_x3"] + C.LAUNCHES["fwd_x3s"] >= 5 and C.LAUNCHES["fwd_f32"] == 0, dict(C.LAUNCHES)
+    if W % 4 == 0 and W >= 24:
+        assert C.LAUNCHES["wgrad_x3"] == 5 and C.LAUNCHES["wgrad_f32"] == 0, dict(C.LAUNCHES)
+
+    def close(a, r, tol, what):
+        e = (a.detach().cpu().double() - r.detach()).abs().max().item() / max(r.detach().abs().max().item(), 1e-30)
+        assert e <= tol, (what, e)
+
+    close(buf, buf_r, 1e-5, "buf")
+    close(out, est_r, 1e-5, "est")
+    close(xd.grad, x64.grad, 2e-5, "gx")
+    close(bd.grad, b64.grad, 2e-5, "gbase")
+    for i, l in enumerate(layers):
+        close(l.weight.grad, ws[i].grad, 2e-5, f"dW{i}")
+        close(l.bias.grad, bs[i].grad, 2e-5, f"db{i}")
+
+
+def test_x3_sub_pack_combined_column_launch_vs_fp64(x3_everywhere):
+    """ONE combined-column launch in isolation: rows of the packed matrix come from several layers' transposed + flipped
+    weights (pack mode 2), the launch accumulates into its target slice and applies LeakyReLU'(mask) -- the dominant
+    kernel of the BASELINE step (conv_x3_kernel<4,1,7,352> on the c1 / x columns)."""
+    from irr_amd import conv as C, hip
+    g = torch.Generator().manual_seed(17)
+    B, H, W, cin0 = 2, 32, 48, 115
+    ctot = 448 + cin0
+    grow = (128, 128, 96, 64, 32)
+    in0 = [448, 320, 192, 96, 32]
+    row0 = {5: 0, 4: 32, 3: 96, 2: 192, 1: 320}
+    ws = [torch.randn(grow[i], ctot - in0[i], 3, 3, generator=g) * (2.0 / (9 * (ctot - in0[i]))) ** 0.5 for i in range(5)]
+    G0 = torch.randn(B, ctot, H, W, generator=g)
+    act = torch.randn(B, ctot, H, W, generator=g)
+    bounds = [(32, 96), (96, 192), (192, 320), (320, 448), (448, ctot)]
+    packs = C._dense_column_packs([w.cuda() for w in ws], cin0, (True,) * 5)
+    for k_, (t0, t1) in enumerate(bounds):
+        n = t1 - t0
+        last = k_ == 4
+        ref = G0[:, t0:t1].double().clone()
+        for i in (5, 4, 3, 2, 1):
+            if in0[i - 1] > t0:
+                continue
+            w = ws[i - 1].double()
+            gy = G0[:, row0[i]:row0[i] + w.shape[0]].double()
+            full = torch.nn.grad.conv2d_input((B, w.shape[1], H, W), w, gy, padding=1)
+            ref += full[:, t0 - in0[i - 1]:t1 - in0[i - 1]]
+        if not last:
+            ref *= torch.where(act[:, t0:t1] > 0, 1.0, 0.1).double()
+        Gd = G0.clone().cuda()
+        ad = act.cuda()
+        assert C.x3_code(B, t0, H, W, n, 3, 1, 1) != 0
+        margs = (None, 0, 0) if last else (hip.ptr(ad[:, t0:t1]), hip.bs(ad), n)
+        C._call_conv(("irr_conv2d_fwd_x3", hip.ptr(Gd), hip.ptr(packs[k_]), None, None, hip.ptr(Gd[:, t0:t1]), B, t0, H, W, n, 1,
+                      hip.bs(Gd), hip.bs(Gd), 0, 0, 1.0, 1, *margs, hip.stream()))
+        e = (Gd[:, t0:t1].cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        assert e <= 5e-6, (k_, e)
+        assert torch.equal(Gd[:, :t0].cpu(), G0[:, :t0]) and torch.equal(Gd[:, t1:].cpu(), G0[:, t1:])      # nothing else touched

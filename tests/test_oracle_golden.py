@@ -120,3 +120,20 @@ def test_e2e_big_samples(golden_dir):
     fl = ev["flow"].reshape(1, 2, -1)[:, :, idx]
     epe = torch.norm(fl - T(g["robust_flow_samples"]), dim=1).mean().item()
     assert epe <= 1e-4, epe
+
+
+def test_e2e_train_B4_384x448_robust(golden_dir):
+    """the oracle against the reference's train step at the size where the build's default routing uses the x3 kernels"""
+    g = _load(golden_dir, "e2e_train_B4_384x448.npz")
+    names = [str(n) for n in g["param_names"]]
+    P = O.make_trainable(O.synthetic_params(0))
+    opt = O.make_adam(P)
+    ld = O.train_step(P, opt, O.synthetic_batch(4, 384, 448, 1234), mask_threshold=0.9999)
+    np.testing.assert_allclose([ld["flow_loss"], ld["occ_loss"], ld["total_loss"]], g["robust_train_losses"], rtol=1e-5)
+    gn = np.array([float(P[n].grad.double().norm()) for n in names])
+    ref = g["robust_train_gradnorm"]
+    tot_ref = np.sqrt((ref ** 2).sum())
+    assert abs(np.sqrt((gn ** 2).sum()) - tot_ref) / tot_ref < 1e-4
+    np.testing.assert_allclose(gn, ref, rtol=2e-3, atol=1e-4 * tot_ref)
+    post = np.array([float(P[n].detach().double().sum()) for n in names])
+    np.testing.assert_allclose(post, g["robust_poststep_sum"], rtol=1e-5, atol=1e-3)

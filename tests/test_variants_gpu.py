@@ -82,3 +82,38 @@ def test_kitti_eval_metrics(golden_dir):
     pred = {"flow": torch.from_numpy(g["kitti_eval_pred_flow"]).cuda(), "occ": torch.zeros(1, 1, 128, 192).cuda()}
     le = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample_KITTI(_args()).eval()(pred, batch)
     np.testing.assert_allclose([float(le["epe"]), float(le["outlier"])], g["kitti_eval"], rtol=1e-5)
+
+
+def test_async_wgrad_lane_is_race_free_on_irr_variant():
+    """PWCNet_irr_occ_bi adds residuals OUTSIDE the decoder nodes (``flow = flow + flow_res``), so one gradient tensor
+    reaches the dense-estimator node (whose conv_last weight gradient the asynchronous lane reads) AND the previous level's
+    producer, into which the autograd engine accumulates in place when it owns the last reference.  The lane keeps its
+    operands alive until it has passed them; every gradient of repeated two-stream backward passes must equal the
+    single-stream gradients of the same inputs."""
+    import irr_amd
+    from irr_amd import ddp
+    torch.manual_seed(0)
+    m = irr_amd.PWCNet_irr_occ_bi(_args(), mask_threshold=0.9999).cuda().train()
+    loss = irr_amd.MultiScaleEPE_PWC_Bi_Occ(_args()).train()
+    arena = ddp.GradArena(m.named_parameters())
+    b = _batch(B=2)
+
+    def grads(lane):
+        if lane:
+            arena.enable_async_wgrad()
+        try:
+            arena.zero_grad()
+            loss(m(b), b)["total_loss"].backward()
+            arena.sync()
+            torch.cuda.synchronize()
+            return {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+        finally:
+            if lane:
+                arena.disable_async_wgrad()
+
+    ref = grads(False)
+    for it in range(8):
+        g = grads(True)
+        for n, r in ref.items():
+            d = (g[n] - r).double().norm().item()
+            assert d <= 1e-3 * r.double().norm().item() + 1e-7, (it, n, d)
