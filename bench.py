@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- IRR-PWC train-step throughput on MI355X (BASELINE.json metric: image-pairs/sec fwd+bwd).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Either started by ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment), or from a plain shell: the script then starts those N ranks itself as
+child processes (before anything touches the GPU in the parent), relays rank 0's JSON line and exits with their return code.
 
 A "step" is one pass of the hot path over one synthetic batch: zero_grad -> PWCNet forward (train mode) ->
 MultiScaleEPE_PWC_Bi_Occ_upsample -> NaN check -> backward -> [RCCL gradient all-reduce] -> Adam step,
@@ -88,6 +92,22 @@ def cpu_baseline(height, width, quick=False):
                       f"leg (batch {top['batch']}, {top['threads']} threads; {ncpu} host CPUs visible, more threads are slower)"}
 
 
+def launch_ranks(n):
+    """``python bench.py --gpus N`` from a cold shell: start N ranks with torch.distributed.run as a CHILD process (this
+    process has not touched the GPU and never re-execs), pass their output through, return their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC for RCCL (see the task environment notes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,12 +125,13 @@ def main():
     ap.add_argument("--no-async-wgrad", action="store_true", help="keep weight gradients on the main stream")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE={world} of the launcher")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist

@@ -338,7 +338,7 @@ class WgradSide:
         gb = self.views.get(id(bias)) if bias is not None else None
         return gw, gb
 
-    def launch(self, fn, tensors):
+    def launch(self, fn, tensors, params=(None, None)):
         """Run ``fn`` on the lane after everything enqueued so far on the current stream.  The tensors it reads are kept
         ALIVE (strong references) until the lane has passed the launch: (a) the caching allocator cannot recycle them
         (``record_stream`` as well, for the time after the reference is dropped), and (b) a tensor with a second owner is
@@ -359,6 +359,8 @@ class WgradSide:
         self._inflight.append((done, keep))
         while self._inflight and self._inflight[0][0].query():
             self._inflight.popleft()
+        if self.on_launch is not None:
+            self.on_launch(*params)
 
     def join(self):
         torch.cuda.current_stream().wait_stream(self.stream)
@@ -377,7 +379,7 @@ def wgrad_param(x, gy, weight, bias, stride: int, dil: int, want_bias: bool = Tr
     if routed is not None:
         gwv, gbv = routed
         SIDE.launch(lambda: conv_wgrad(x, gy, weight.shape, stride, dil, gw=gwv, gbias=gbv if want_bias else None,
-                                       alpha=alpha), (x, gy))
+                                       alpha=alpha), (x, gy), (weight, bias if (want_bias and gbv is not None) else None))
         return None, None
     if acc is not None:
         gw, gb = acc

@@ -6,11 +6,11 @@ MI355X-side addition required by BASELINE.json.  Design:
 
 * all 124 gradients live in ONE flat fp32 arena (25.45 MB); ``param.grad`` are views into it, so a bucket
   is a contiguous slice and needs no flatten/unflatten copies;
-* buckets are ordered by when their gradients become final during backward.  IRR-PWC shares its decoder
-  weights over all pyramid levels, so almost every gradient is final only when the coarsest level has been
-  back-propagated; the exceptions are the occlusion upsampler and ``conv_1x1_1`` (levels 5-6 only), which
-  finish first and are reduced on a side stream while the rest of backward (incl. the correlation-backward
-  kernels of levels 4..0) is still running;
+* three buckets, ordered by when their gradients become final during backward: the occlusion upsampler and
+  ``conv_1x1_1`` (levels 5-6 only) finish first and are reduced on a communication stream while the rest of backward
+  (incl. the correlation-backward kernels of levels 4..0) is still running; the shared decoders / context / refinement
+  networks are final after the coarsest level and are reduced under the backward of the feature pyramid; the pyramid
+  itself is reduced at ``sync()``;
 * the two detached loss scalars are all-reduced inside the loss (``reduce_losses``) so the flow/occ balancing
   weights (losses.py:560-567) equal those of a single process on the global batch.
 """
@@ -21,7 +21,12 @@ from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
+# Buckets in the order in which their gradients become FINAL during backward (IRR-PWC shares its decoders over the levels):
+#   0 "early":   the occlusion upsampler and conv_1x1_1 are only used at levels 5-6, which backward visits first;
+#   1 "shared":  everything else (decoders, context networks, refinement, conv_1x1) is final after the coarsest level;
+#   2 "late":    the feature pyramid is back-propagated last (its nodes are the oldest of the tape).
 EARLY_PREFIXES = ("occ_shuffle_upsample.", "conv_1x1_1.")
+LATE_PREFIXES = ("feature_pyramid_extractor.",)
 
 
 def shard_batch(batch: dict, rank: int, world: int) -> dict:
@@ -50,47 +55,76 @@ def reduce_losses(group=None) -> Callable:
 
 
 class GradArena:
-    """Flat gradient storage + bucketed, overlapped all-reduce."""
+    """Flat gradient storage + bucketed all-reduce that starts while backward is still running.
+
+    A bucket's all-reduce is enqueued on a communication stream the moment its LAST gradient contribution of the step has
+    been enqueued -- wherever that contribution is produced: by autograd (``post_accumulate_grad`` hooks, main stream) or by
+    the asynchronous weight-gradient lane (irr_amd.conv.WgradSide, its own stream, bypassing autograd).  How many
+    contributions each parameter receives per step is a property of the model graph (shared decoders: one per level and
+    use); it is LEARNED from the first backward pass (which reduces everything at ``sync()``) and counted down from then
+    on.  With IRR-PWC that puts the occlusion-upsampler bucket under the backward of levels 4..0 (correlation backward,
+    decoders) and the 21 MB shared-decoder bucket under the backward of the feature pyramid; only the pyramid's own 4 MB
+    are reduced after the last kernel of backward."""
 
     def __init__(self, named_params: Iterable[Tuple[str, torch.nn.Parameter]], group=None,
-                 early_prefixes: Sequence[str] = EARLY_PREFIXES, overlap: bool = True):
+                 early_prefixes: Sequence[str] = EARLY_PREFIXES, late_prefixes: Sequence[str] = LATE_PREFIXES,
+                 overlap: bool = True):
         named = [(n, p) for n, p in named_params if p.requires_grad]
         early = [(n, p) for n, p in named if n.startswith(tuple(early_prefixes))]
-        late = [(n, p) for n, p in named if not n.startswith(tuple(early_prefixes))]
+        late = [(n, p) for n, p in named if n.startswith(tuple(late_prefixes)) and not n.startswith(tuple(early_prefixes))]
+        taken = {id(p) for _, p in early + late}
+        mid = [(n, p) for n, p in named if id(p) not in taken]
         self.group = group
-        self.order = early + late
+        self.order = early + mid + late
         dev = self.order[0][1].device
         total = sum(p.numel() for _, p in self.order)
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.buckets: List[Tuple[int, int]] = []
         self._bucket_of = {}
-        self._pending: List[int] = []
+        self._members: List[List[int]] = []
         off = 0
-        for bi, grp in enumerate((early, late)):
+        for bi, grp in enumerate((early, mid, late)):
             start = off
+            ids = []
             for _, p in grp:
                 n = p.numel()
                 p.grad = self.flat[off:off + n].view_as(p)
                 self._bucket_of[id(p)] = bi
+                ids.append(id(p))
                 off += n
             self.buckets.append((start, off))
-        self._counts = [len(early), len(late)]
+            self._members.append(ids)
         self._works = []
         self.overlap = overlap and dev.type == "cuda"
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
+        self._side_lane = None
         self._hooks = []
+        self._expected: Optional[dict] = None          # id(param) -> contributions per step (None: not calibrated yet)
+        self._seen = {}
+        self.launch_log: List[Tuple[int, str]] = []    # (bucket, "backward" | "sync") of the last step -- tests / diagnostics
         self._reset()
         if self.world > 1:
             for _, p in self.order:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda p_: self._contribution(id(p_))))
 
     @property
     def world(self) -> int:
         return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
 
     def _reset(self):
-        self._pending = list(self._counts)
-        self._launched = [False, False]
+        self._seen = {pid: 0 for pid in self._bucket_of}
+        self._launched = [False] * len(self.buckets)
+        self._in_sync = False
+        if self._expected is not None:
+            self._remaining = [sum(1 for pid in ids if self._expected.get(pid, 0) > 0) for ids in self._members]
+        else:
+            self._remaining = [-1] * len(self.buckets)
+        self.launch_log = []
+
+    def recalibrate(self):
+        """forget the learned contribution counts (call when the model graph changes: other loss heads, frozen layers)"""
+        self._expected = None
+        self._reset()
 
     def zero_grad(self):
         """replaces optimizer.zero_grad(): one memset, gradients stay views of the arena"""
@@ -113,43 +147,67 @@ class GradArena:
         if self._launched[bi] or self.world == 1:
             return
         self._launched[bi] = True
+        self.launch_log.append((bi, "sync" if self._in_sync else "backward"))
         s, e = self.buckets[bi]
         if e == s:
             return
         chunk = self.flat[s:e]
         if self.overlap:
+            # the bucket's contributions were enqueued on the main stream (autograd) and / or on the weight-gradient lane
             self._side.wait_stream(torch.cuda.current_stream())
+            if self._side_lane is not None:
+                self._side.wait_stream(self._side_lane.stream)
             with torch.cuda.stream(self._side):
                 self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def _on_grad(self, p):
-        bi = self._bucket_of[id(p)]
-        self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._launch(bi)
+    def _contribution(self, pid: int):
+        """one gradient contribution to parameter ``pid`` has just been enqueued (autograd hook or lane launch)"""
+        bi = self._bucket_of.get(pid)
+        if bi is None:
+            return
+        self._seen[pid] += 1
+        if self._expected is None:
+            return
+        if self._launched[bi]:
+            raise RuntimeError("a gradient contribution arrived after its bucket's all-reduce was started: the model graph "
+                               "differs from the calibrated one -- call GradArena.recalibrate() before this step")
+        if self._seen[pid] == self._expected.get(pid, 0):
+            self._remaining[bi] -= 1
+            if self._remaining[bi] == 0:
+                self._launch(bi)
+
+    def _on_lane(self, weight, bias):
+        self._contribution(id(weight))
+        if bias is not None:
+            self._contribution(id(bias))
 
     def enable_async_wgrad(self):
         """Route every weight/bias gradient of the MFMA conv nodes straight into this arena on a second HIP stream
         (irr_amd.conv.WgradSide): the wgrad launches then overlap the data-gradient chain instead of sitting on
-        its critical path.  Autograd no longer sees those gradients, so buckets are reduced at sync()."""
+        its critical path.  Autograd no longer sees those gradients; the lane reports each contribution instead."""
         from . import conv
         self._side_lane = conv.WgradSide({id(p): p.grad for _, p in self.order})
+        if self.world > 1:
+            self._side_lane.on_launch = self._on_lane
         conv.SIDE = self._side_lane
+        self.recalibrate()
 
     def disable_async_wgrad(self):
         from . import conv
-        if getattr(self, "_side_lane", None) is not None and conv.SIDE is self._side_lane:
+        if self._side_lane is not None and conv.SIDE is self._side_lane:
             conv.SIDE = None
         self._side_lane = None
+        self.recalibrate()
 
     def sync(self):
         """call between backward() and optimizer.step(): flush, wait, average."""
-        if getattr(self, "_side_lane", None) is not None:
+        if self._side_lane is not None:
             self._side_lane.join()
         if self.world == 1:
             return
+        self._in_sync = True
         for bi in range(len(self.buckets)):
             self._launch(bi)
         for w in self._works:
@@ -158,6 +216,8 @@ class GradArena:
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self._side)
         self.flat.mul_(1.0 / self.world)
+        if self._expected is None:
+            self._expected = dict(self._seen)           # calibration step: every bucket was reduced here
 
 
 def broadcast_params(module: torch.nn.Module, src: int = 0, group=None) -> None:

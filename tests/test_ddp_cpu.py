@@ -10,15 +10,43 @@ import torch.multiprocessing as mp
 import torch.nn as nn
 
 
+class _LaneConv(torch.autograd.Function):
+    """CPU stand-in for the asynchronous weight-gradient lane (irr_amd.conv.WgradSide): the weight / bias gradients are
+    added straight into the arena views, autograd gets None, and the arena is told about the contribution."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, arena_box):
+        ctx.save_for_backward(x, w)
+        ctx.objs = (w, b, arena_box)
+        return torch.nn.functional.conv2d(x, w, b, padding=1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        wobj, bobj, arena_box = ctx.objs
+        with torch.no_grad():
+            wobj.grad += torch.nn.grad.conv2d_weight(x, w.shape, gy, padding=1)
+            bobj.grad += gy.sum(dim=(0, 2, 3))
+        arena = arena_box[0]
+        if arena is not None and arena.world > 1:
+            arena._on_lane(wobj, bobj)
+        gx = torch.nn.grad.conv2d_input(x.shape, w, gy, padding=1) if ctx.needs_input_grad[0] else None
+        return gx, None, None, None
+
+
 class Toy(nn.Module):
     def __init__(self):
         super().__init__()
-        self.body = nn.Conv2d(3, 4, 3, padding=1)
-        self.occ_shuffle_upsample = nn.Conv2d(4, 1, 3, padding=1)     # lands in the "early" bucket
+        self.feature_pyramid_extractor = nn.Conv2d(3, 4, 3, padding=1)   # "late" bucket (back-propagated last)
+        self.body = nn.Conv2d(4, 4, 3, padding=1)                         # "shared" bucket: used TWICE, gradients via the lane
+        self.occ_shuffle_upsample = nn.Conv2d(4, 1, 3, padding=1)         # "early" bucket
         self.conv_1x1_1 = nn.Conv2d(4, 2, 1)
+        self.arena_box = [None]
 
     def forward(self, x):
-        h = torch.tanh(self.body(x))
+        f = torch.tanh(self.feature_pyramid_extractor(x))
+        h = torch.tanh(_LaneConv.apply(f, self.body.weight, self.body.bias, self.arena_box))
+        h = torch.tanh(_LaneConv.apply(h, self.body.weight, self.body.bias, self.arena_box))
         return self.conv_1x1_1(h), self.occ_shuffle_upsample(h)
 
 
@@ -49,15 +77,26 @@ def _worker(rank, world, port, q):
     model = Toy()
     ddp.broadcast_params(model)
     arena = ddp.GradArena(model.named_parameters())
-    assert [n for n, _ in arena.order][:4] == ["occ_shuffle_upsample.weight", "occ_shuffle_upsample.bias",
-                                              "conv_1x1_1.weight", "conv_1x1_1.bias"]
+    model.arena_box[0] = arena
+    assert [n for n, _ in arena.order] == ["occ_shuffle_upsample.weight", "occ_shuffle_upsample.bias", "conv_1x1_1.weight",
+                                           "conv_1x1_1.bias", "body.weight", "body.bias",
+                                           "feature_pyramid_extractor.weight", "feature_pyramid_extractor.bias"]
     full = _make_batch(4)
     mine = ddp.shard_batch(full, rank, world)
-    for _ in range(2):                       # two rounds: the arena must be reusable
+    logs = []
+    for _ in range(3):                       # three rounds: calibration, then two with the all-reduces started in backward
         arena.zero_grad()
         ld = _loss(model, mine, ddp.reduce_losses())
         ld["total_loss"].backward()
         arena.sync()
+        logs.append(list(arena.launch_log))
+    # step 1 learns the contribution counts (body: 2 lane contributions per step) and reduces everything at sync();
+    # afterwards every bucket starts its all-reduce the moment its last contribution is in, in finalisation order
+    assert logs[0] == [(0, "sync"), (1, "sync"), (2, "sync")], logs
+    assert logs[1] == logs[2] == [(0, "backward"), (1, "backward"), (2, "backward")], logs
+    exp = {n: arena._expected[id(p)] for n, p in model.named_parameters()}
+    # (2 lane contributions; torch additionally runs the AccumulateGrad hook once for a parameter whose Function returned None)
+    assert exp["body.weight"] in (2, 3) and exp["body.bias"] in (2, 3) and exp["conv_1x1_1.weight"] == 1, exp
     # plain lists, not tensors: a tensor travels by file-descriptor passing and is lost if this process exits first
     q.put((rank, arena.flat.tolist(), float(ld["total_loss"].detach())))
     dist.destroy_process_group()
@@ -83,9 +122,10 @@ def test_two_rank_gloo_matches_single_process():
     torch.manual_seed(0)
     model = Toy()
     arena = ddp.GradArena(model.named_parameters())
+    model.arena_box[0] = arena
     full = _make_batch(4)
-    ld = _loss(model, full, None)
     arena.zero_grad()
+    ld = _loss(model, full, None)
     ld["total_loss"].backward()
     assert torch.allclose(arena.flat, res[0][1], rtol=1e-4, atol=1e-6), (arena.flat - res[0][1]).abs().max()
 

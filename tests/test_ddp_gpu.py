@@ -1,0 +1,58 @@
+"""The real multi-GPU path (BASELINE configs[3]): needs >= 2 GPUs on the box, skipped otherwise."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return env
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_two_rank_nccl_lane_sync_matches_global_batch():
+    """2 ranks x (lane + GradArena.sync() + RCCL all-reduce started inside backward) == 1 process on the global batch"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_lane_worker.py")]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DDP_LANE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_two_ranks_on_one_gpu_lane_sync_matches_global_batch():
+    """The same worker on a single-GPU box: two processes share cuda:0 and exchange their gradients through gloo (RCCL
+    refuses two ranks on one device).  Everything but the transport is the benched path: lane, contribution counting,
+    all-reduces started inside backward on the communication stream, loss-scalar reduction."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_lane_worker.py")]
+    env = _env()
+    env["IRR_DDP_BACKEND"] = "gloo"
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DDP_LANE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` from a cold shell: the script starts its own ranks and prints ONE JSON line"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["value"] > 0
