@@ -90,6 +90,13 @@ int irr_resize_bilinear_ac_fwd_f32(const float* x, float* out, int B, int C, int
 /* gx = alpha * resize^T(gout); gx fully overwritten (gather form, deterministic). */
 int irr_resize_bilinear_ac_bwd_f32(const float* gout, float* gx, int B, int C, int H, int W, int OH, int OW,
                                    long gout_bs, long gx_bs, float alpha, void* stream);
+/* The same with align_corners=False (half-pixel centres, ATen's F.interpolate(x, [OH, OW], mode="bilinear")): the fallback
+ * of upsample_factor2 when the nearest-x2 map does not have the guide's size, i.e. odd pyramid sizes
+ * (models/irr_modules.py:21-27; Sintel 436x1024 -> 218, 109, 55, ...). */
+int irr_resize_bilinear_hp_fwd_f32(const float* x, float* out, int B, int C, int H, int W, int OH, int OW,
+                                   long x_bs, long out_bs, float alpha, void* stream);
+int irr_resize_bilinear_hp_bwd_f32(const float* gout, float* gx, int B, int C, int H, int W, int OH, int OW,
+                                   long gout_bs, long gx_bs, float alpha, void* stream);
 
 /* ---- convolution family (fp32 MFMA implicit GEMM) -----------------------------------------------
  * conv() helper (models/pwc_modules.py:8-19, models/irr_modules.py:7-18): Conv2d(k in {1,3}, stride in {1,2},
@@ -265,6 +272,9 @@ int irr_upsample_nearest2x_bwd_f32(const float* gout, float* gx, int B, int C, i
  *   irr_f1bal_bwd        glogit = gscale[0]*weight * d/dlogit [ tp/(st+sp+eps) + fn/((N-st)+(N-sp)+eps) ]
  * gscale is a 1-element DEVICE array (the upstream gradient times the balancing weight), so nothing syncs. */
 int irr_avgpool_f32(const float* in, float* out, int BC, int h, int w, int s, float scale, void* stream);
+/* the general case of losses.py:16-18: out (BC,h,w) = scale * adaptive_avg_pool2d(in (BC,H,W), [h, w]) for level sizes that do
+ * not divide the target size (window [floor(o*H/h), ceil((o+1)*H/h)) per axis, as ATen) -- odd pyramid sizes */
+int irr_adaptive_avgpool_f32(const float* in, float* out, int BC, int H, int W, int h, int w, float scale, void* stream);
 int irr_epe_sum_fwd_f32(const float* flow, const float* tgt, float* out, int B, int HW, long flow_bs, long tgt_bs,
                         float weight, void* stream);
 int irr_epe_sum_bwd_f32(const float* flow, const float* tgt, const float* gscale, float* gflow, int B, int HW,

@@ -34,6 +34,25 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
   out[i] = scale * acc / (float)(s * s);
 }
 
+// general adaptive_avg_pool2d (ATen: window [floor(o*H/h), ceil((o+1)*H/h)) per axis) for level sizes that do not divide the
+// target size (odd pyramid sizes: 436x1024 -> 218x512, 109x256, 55x128, ...)
+__global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                              int h, int w, float scale, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % w);
+  const long r = i / w;
+  const int y = (int)(r % h);
+  const long bc = r / h;
+  const int y0 = (int)(((long)y * H) / h), y1 = (int)(((long)(y + 1) * H + h - 1) / h);
+  const int x0 = (int)(((long)x * W) / w), x1 = (int)(((long)(x + 1) * W + w - 1) / w);
+  const float* p = in + bc * (long)H * W;
+  float acc = 0.f;
+  for (int a = y0; a < y1; ++a)
+    for (int b = x0; b < x1; ++b) acc += p[(long)a * W + b];
+  out[i] = scale * (acc / (float)((y1 - y0) * (x1 - x0)));
+}
+
 // flow, tgt: (B,2,h,w) ; *out += weight * sum_p sqrt(du^2 + dv^2)
 __global__ __launch_bounds__(256) void epe_fwd_kernel(const float* __restrict__ flow, const float* __restrict__ tgt,
                                                      float* __restrict__ out, long hw, long flow_bs, long tgt_bs, float weight) {
@@ -120,6 +139,14 @@ extern "C" int irr_avgpool_f32(const float* in, float* out, int BC, int h, int w
   if (!in || !out || BC <= 0 || h <= 0 || w <= 0 || s <= 0) return IRR_EINVAL;
   const long n = (long)BC * h * w;
   hipLaunchKernelGGL(avgpool_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, h, w, s, scale, n);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_adaptive_avgpool_f32(const float* in, float* out, int BC, int H, int W, int h, int w, float scale, void* stream) {
+  if (!in || !out || BC <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return IRR_EINVAL;
+  const long n = (long)BC * h * w;
+  hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, H, W, h, w, scale, n);
   IRR_LAUNCH_CHECK();
   return 0;
 }

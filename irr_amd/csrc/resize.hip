@@ -6,12 +6,26 @@
 // i1 = min(i0+1, in-1); l1 = src-i0; l0 = 1-l1;  out = l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11).
 // Backward is written as a gather over the (few) output pixels that touch an input pixel, so it is
 // deterministic and needs no atomics.
+//
+// HP = true: align_corners=False ("half-pixel") -- the fallback of upsample_factor2 for odd pyramid sizes
+// (models/irr_modules.py:21-27: nearest x2, then bilinear to the guide's size).  ATen: scale = in/out;
+// src = max(scale*(dst+0.5)-0.5, 0); i0 = floor(src); i1 = i0 + (i0 < in-1); same blend.
 #include "common.h"
 
 namespace {
 
-__device__ __forceinline__ float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+template <bool HP>
+__device__ __forceinline__ float rs_scale(int in, int out) {
+  if (HP) return (float)in / (float)out;
+  return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+}
+template <bool HP>
+__device__ __forceinline__ float rs_src(float scale, int dst) {
+  if (HP) return fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+  return scale * dst;
+}
 
+template <bool HP>
 __global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int C,
                                                         int H, int W, int OH, int OW, long x_bs, long out_bs,
                                                         float alpha) {
@@ -20,7 +34,7 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict
   if (p >= oplane) return;
   const int b = blockIdx.z;
   const int oy = (int)(p / OW), ox = (int)(p - (long)oy * OW);
-  const float sy = ac_scale(H, OH) * oy, sx = ac_scale(W, OW) * ox;
+  const float sy = rs_src<HP>(rs_scale<HP>(H, OH), oy), sx = rs_src<HP>(rs_scale<HP>(W, OW), ox);
   const int y0 = (int)sy, x0 = (int)sx;
   const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
   const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
@@ -36,8 +50,9 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict
 }
 
 // 1-D contribution of output index o to input index i (hat function sampled on the output lattice)
+template <bool HP>
 __device__ __forceinline__ float tap_weight(int i, int o, int in, float scale) {
-  const float s = scale * o;
+  const float s = rs_src<HP>(scale, o);
   const int i0 = (int)s;
   const int i1 = min(i0 + 1, in - 1);
   const float l1 = s - i0;
@@ -47,6 +62,7 @@ __device__ __forceinline__ float tap_weight(int i, int o, int in, float scale) {
   return w;
 }
 
+template <bool HP>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gx, int C,
                                                         int H, int W, int OH, int OW, long gout_bs, long gx_bs,
                                                         float alpha) {
@@ -55,22 +71,25 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
   if (p >= plane) return;
   const int b = blockIdx.z;
   const int iy = (int)(p / W), ix = (int)(p - (long)iy * W);
-  const float scy = ac_scale(H, OH), scx = ac_scale(W, OW);
-  // candidate output range touching input row iy: src in (iy-1, iy+1)
+  const float scy = rs_scale<HP>(H, OH), scx = rs_scale<HP>(W, OW);
+  // candidate output range touching input row iy: src in (iy-1, iy+1), i.e. o in ((iy-1)/s, (iy+1)/s) for src = s*o and
+  // o in ((iy-0.5)/s - 0.5, (iy+1.5)/s - 0.5) for the half-pixel lattice src = s*(o+0.5) - 0.5 (outputs clamped to src = 0
+  // only touch iy = 0, whose range starts at 0 anyway); one spare candidate each side, tap_weight() decides
   int oy_lo, oy_hi, ox_lo, ox_hi;
-  if (scy > 0.f) { oy_lo = max(0, (int)floorf((iy - 1) / scy) - 1); oy_hi = min(OH - 1, (int)ceilf((iy + 1) / scy) + 1); }
+  const float ha = HP ? 0.5f : 1.f, hb = HP ? 1.5f : 1.f, hc = HP ? 0.5f : 0.f;
+  if (scy > 0.f) { oy_lo = max(0, (int)floorf((iy - ha) / scy - hc) - 1); oy_hi = min(OH - 1, (int)ceilf((iy + hb) / scy - hc) + 1); }
   else { oy_lo = 0; oy_hi = OH - 1; }
-  if (scx > 0.f) { ox_lo = max(0, (int)floorf((ix - 1) / scx) - 1); ox_hi = min(OW - 1, (int)ceilf((ix + 1) / scx) + 1); }
+  if (scx > 0.f) { ox_lo = max(0, (int)floorf((ix - ha) / scx - hc) - 1); ox_hi = min(OW - 1, (int)ceilf((ix + hb) / scx - hc) + 1); }
   else { ox_lo = 0; ox_hi = OW - 1; }
   const long oplane = (long)OH * OW;
   for (int c = blockIdx.y; c < C; c += gridDim.y) {
     const float* gc = gout + (long)b * gout_bs + (long)c * oplane;
     float acc = 0.f;
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-      const float wy = tap_weight(iy, oy, H, scy);
+      const float wy = tap_weight<HP>(iy, oy, H, scy);
       if (wy == 0.f) continue;
       for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        const float wx = tap_weight(ix, ox, W, scx);
+        const float wx = tap_weight<HP>(ix, ox, W, scx);
         if (wx != 0.f) acc += wy * wx * gc[(long)oy * OW + ox];
       }
     }
@@ -84,7 +103,7 @@ extern "C" int irr_resize_bilinear_ac_fwd_f32(const float* x, float* out, int B,
                                               long x_bs, long out_bs, float alpha, void* stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || !x || !out || B > 65535) return IRR_EINVAL;
   dim3 grid(irr_cdiv((long)OH * OW, 256), C < 8 ? C : 8, B);
-  hipLaunchKernelGGL(resize_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, C, H, W, OH, OW, x_bs, out_bs,
+  hipLaunchKernelGGL(resize_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, out, C, H, W, OH, OW, x_bs, out_bs,
                      alpha);
   IRR_LAUNCH_CHECK();
   return 0;
@@ -94,7 +113,27 @@ extern "C" int irr_resize_bilinear_ac_bwd_f32(const float* gout, float* gx, int 
                                               long gout_bs, long gx_bs, float alpha, void* stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || !gout || !gx || B > 65535) return IRR_EINVAL;
   dim3 grid(irr_cdiv((long)H * W, 256), C < 8 ? C : 8, B);
-  hipLaunchKernelGGL(resize_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs,
+  hipLaunchKernelGGL(resize_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs,
+                     gx_bs, alpha);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_resize_bilinear_hp_fwd_f32(const float* x, float* out, int B, int C, int H, int W, int OH, int OW,
+                                              long x_bs, long out_bs, float alpha, void* stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || !x || !out || B > 65535) return IRR_EINVAL;
+  dim3 grid(irr_cdiv((long)OH * OW, 256), C < 8 ? C : 8, B);
+  hipLaunchKernelGGL(resize_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, out, C, H, W, OH, OW, x_bs, out_bs,
+                     alpha);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_resize_bilinear_hp_bwd_f32(const float* gout, float* gx, int B, int C, int H, int W, int OH, int OW,
+                                              long gout_bs, long gx_bs, float alpha, void* stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || !gout || !gx || B > 65535) return IRR_EINVAL;
+  dim3 grid(irr_cdiv((long)H * W, 256), C < 8 ? C : 8, B);
+  hipLaunchKernelGGL(resize_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs,
                      gx_bs, alpha);
   IRR_LAUNCH_CHECK();
   return 0;

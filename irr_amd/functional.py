@@ -134,30 +134,45 @@ def warp(x, flow, height_im: int, width_im: int, div_flow: float, mask_threshold
 # ----------------------------------------------------------------------------------------------
 class _ResizeAC(hip.Function):
     @staticmethod
-    def forward(ctx, x, oh: int, ow: int, alpha: float):
+    def forward(ctx, x, oh: int, ow: int, alpha: float, mode: str = "ac"):
         _need_cuda(x)
         x = _pd(x)
         B, C, H, W = x.shape
         out = torch.empty(B, C, oh, ow, device=x.device, dtype=torch.float32)
-        hip.call("irr_resize_bilinear_ac_fwd_f32", hip.ptr(x), hip.ptr(out), B, C, H, W, oh, ow,
+        hip.call(f"irr_resize_bilinear_{mode}_fwd_f32", hip.ptr(x), hip.ptr(out), B, C, H, W, oh, ow,
                  hip.bs(x), hip.bs(out), alpha, hip.stream())
-        ctx.cfg = (H, W, oh, ow, alpha)
+        ctx.cfg = (H, W, oh, ow, alpha, mode)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        H, W, oh, ow, alpha = ctx.cfg
+        H, W, oh, ow, alpha, mode = ctx.cfg
         gout = _pd(gout)
         B, C = gout.shape[:2]
         gx = torch.empty(B, C, H, W, device=gout.device, dtype=torch.float32)
-        hip.call("irr_resize_bilinear_ac_bwd_f32", hip.ptr(gout), hip.ptr(gx), B, C, H, W, oh, ow,
+        hip.call(f"irr_resize_bilinear_{mode}_bwd_f32", hip.ptr(gout), hip.ptr(gx), B, C, H, W, oh, ow,
                  hip.bs(gout), hip.bs(gx), alpha, hip.stream())
-        return gx, None, None, None
+        return gx, None, None, None, None
 
 
 def resize_bilinear_ac(x, oh: int, ow: int, alpha: float = 1.0):
     """alpha * F.interpolate(x, [oh, ow], mode='bilinear', align_corners=True)."""
-    return _ResizeAC.apply(x, int(oh), int(ow), float(alpha))
+    return _ResizeAC.apply(x, int(oh), int(ow), float(alpha), "ac")
+
+
+def resize_bilinear(x, oh: int, ow: int):
+    """F.interpolate(x, [oh, ow], mode='bilinear', align_corners=False) (half-pixel centres)."""
+    return _ResizeAC.apply(x, int(oh), int(ow), 1.0, "hp")
+
+
+def upsample_factor2(inputs, target_as):
+    """models/irr_modules.py:21-27: nearest x2; when that is not the guide's size (odd pyramid sizes), bilinear
+    (align_corners=False) to the guide's size."""
+    up = upsample_nearest2x(inputs)
+    h, w = target_as.shape[2], target_as.shape[3]
+    if up.shape[2] != h or up.shape[3] != w:
+        up = resize_bilinear(up, h, w)
+    return up
 
 
 def upsample2d_as(inputs, target_as, mode="bilinear"):

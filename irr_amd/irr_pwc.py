@@ -145,8 +145,6 @@ class PWCNet(nn.Module):
     def forward(self, input_dict):
         x1_raw, x2_raw = input_dict['input1'], input_dict['input2']
         B, _, H, W = x1_raw.shape
-        if H % 64 or W % 64:
-            raise ValueError("IRR-PWC needs height and width that are multiples of 64")
         div = self._div_flow
         dev = x1_raw.device
 

@@ -34,15 +34,17 @@ def _dense(t):
 
 
 def avg_pool_to(t: torch.Tensor, h: int, w: int, scale: float = 1.0) -> torch.Tensor:
-    """scale * adaptive_avg_pool2d(t, [h, w]) for integer ratios (losses.py:16-18)."""
+    """scale * adaptive_avg_pool2d(t, [h, w]) (losses.py:16-18): s x s block means for the integer ratios of the /64 sizes,
+    ATen's general windows otherwise (odd pyramid sizes)."""
     _need_cuda(t)
     B, C, H, W = t.shape
-    if H % h or W % w or H // h != W // w:
-        raise ValueError(f"target {H}x{W} is not an integer multiple of level size {h}x{w}")
     t = t.contiguous()
     out = torch.empty(B, C, h, w, device=t.device, dtype=torch.float32)
     with hip.device_of(t):
-        hip.call("irr_avgpool_f32", hip.ptr(t), hip.ptr(out), B * C, h, w, H // h, float(scale), hip.stream())
+        if H % h == 0 and W % w == 0 and H // h == W // w:
+            hip.call("irr_avgpool_f32", hip.ptr(t), hip.ptr(out), B * C, h, w, H // h, float(scale), hip.stream())
+        else:
+            hip.call("irr_adaptive_avgpool_f32", hip.ptr(t), hip.ptr(out), B * C, H, W, h, w, float(scale), hip.stream())
     return out
 
 

@@ -182,10 +182,7 @@ class OccUpsampleNetwork(nn.Module):
         self.out_convs = conv(self.feat_dim, ch_out)
 
     def forward(self, occ, x):
-        occ = Fn.upsample_nearest2x(occ)
-        if occ.shape[2:] != x.shape[2:]:
-            raise ValueError("IRR-PWC input height/width must be multiples of 64 (models/irr_modules.py:24-25 "
-                             "bilinear fallback is not implemented)")
+        occ = Fn.upsample_factor2(occ, x)
         return C.occ_upsample_net(occ, torch.cat([occ, x], dim=1), self)
 
 

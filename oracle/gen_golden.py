@@ -301,6 +301,57 @@ def gen_e2e_train_x3(out_dir, B=4, H=384, W=448):
     np.savez_compressed(os.path.join(out_dir, f"e2e_train_B{B}_{H}x{W}.npz"), **d)
 
 
+def gen_oddsize(out_dir):
+    """Inputs whose height / width are NOT multiples of 64 (the reference evaluates Sintel 436x1024 and KITTI ~375x1242 as
+    they come, scripts/validation/IRR-PWC_sintel.sh:17-29): odd pyramid sizes (436 -> 218, 109, 55, 28, 14, 7), the
+    bilinear align_corners=False fallback of upsample_factor2 (models/irr_modules.py:21-27) and adaptive_avg_pool2d with
+    non-integer ratios in the loss (losses.py:16-18).  Robust-mask mode.
+    (i) 436x1024 and 375x1242, B = 1, eval: 4096 sampled output pixels + stats; (ii) 100x132, B = 2: eval outputs in full,
+    one train step (losses, 124 gradient norms, post-Adam checksums)."""
+    P = O.synthetic_params(0)
+    d = {}
+    set_mode(False, True)
+    for H, W in ((436, 1024), (375, 1242)):
+        batch = O.synthetic_batch(1, H, W, 1234)
+        idx = torch.randperm(H * W, generator=torch.Generator().manual_seed(99))[:4096]
+        m, _ = ref_model(P)
+        m.eval()
+        with torch.no_grad():
+            ev = m({"input1": batch["input1"], "input2": batch["input2"]})
+        k = f"{H}x{W}"
+        d[k + "_idx"] = idx.numpy()
+        d[k + "_flow_samples"] = npf(ev["flow"].reshape(1, 2, -1)[:, :, idx])
+        d[k + "_occ_samples"] = npf(ev["occ"].reshape(1, 1, -1)[:, :, idx])
+        d[k + "_stats"] = np.array([float(ev["flow"].mean()), float(ev["flow"].abs().mean()), float(ev["occ"].mean())])
+        print(k, d[k + "_stats"], flush=True)
+    B, H, W = 2, 100, 132
+    batch = O.synthetic_batch(B, H, W, 1234)
+    names = sorted(P.keys())
+    d["param_names"] = np.array(names)
+    m, args = ref_model(P)
+    m.eval()
+    with torch.no_grad():
+        ev = m({"input1": batch["input1"], "input2": batch["input2"]})
+    d["small_eval_flow"], d["small_eval_occ"] = npf(ev["flow"]), npf(ev["occ"])
+    set_mode(True, True)
+    m.train()
+    lossm = losses.MultiScaleEPE_PWC_Bi_Occ_upsample(args)
+    lossm.train()
+    out = m({"input1": batch["input1"].clone().requires_grad_(True), "input2": batch["input2"].clone().requires_grad_(True)})
+    d["small_train_sizes"] = np.array([list(lv[0].shape[2:]) for lv in out["flow"]])
+    ld = lossm(out, batch)
+    ld["total_loss"].backward()
+    sd = dict(m.named_parameters())
+    d["small_train_losses"] = np.array([float(ld["flow_loss"].detach()), float(ld["occ_loss"].detach()), float(ld["total_loss"].detach())])
+    d["small_train_gradnorm"] = np.array([float(sd[n].grad.double().norm()) for n in names])
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=4e-4)
+    opt.step()
+    d["small_poststep_sum"] = np.array([float(sd[n].detach().double().sum()) for n in names])
+    set_mode(False, False)
+    print("small", d["small_train_sizes"].tolist(), d["small_train_losses"])
+    np.savez_compressed(os.path.join(out_dir, "oddsize.npz"), **d)
+
+
 def gen_init(out_dir):
     """Fingerprint of the reference's own MSRA init under torch.manual_seed(0)."""
     m, _ = ref_model(None, seed=0)
@@ -499,7 +550,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
-    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "trainx3": gen_e2e_train_x3, "pwcnet": gen_pwcnet_plumbing, "noise": gen_noise_floor, "augment": gen_augment, "variants": gen_variants, "flowvis": gen_flowvis}
+    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "trainx3": gen_e2e_train_x3, "oddsize": gen_oddsize, "pwcnet": gen_pwcnet_plumbing, "noise": gen_noise_floor, "augment": gen_augment, "variants": gen_variants, "flowvis": gen_flowvis}
     for k, fn in steps.items():
         if a.only and k not in a.only.split(","):
             continue

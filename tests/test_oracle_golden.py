@@ -137,3 +137,24 @@ def test_e2e_train_B4_384x448_robust(golden_dir):
     np.testing.assert_allclose(gn, ref, rtol=2e-3, atol=1e-4 * tot_ref)
     post = np.array([float(P[n].detach().double().sum()) for n in names])
     np.testing.assert_allclose(post, g["robust_poststep_sum"], rtol=1e-5, atol=1e-3)
+
+
+def test_oddsize_vs_reference(golden_dir):
+    """the oracle at sizes that are not multiples of 64 (odd pyramid sizes, half-pixel resize fallback, general adaptive
+    pooling): Sintel-sized eval samples and a 100x132 train step against the imported reference"""
+    g = _load(golden_dir, "oddsize.npz")
+    P = O.synthetic_params(0)
+    batch = O.synthetic_batch(1, 436, 1024, 1234)
+    with torch.no_grad():
+        ev = O.irr_pwc_forward(P, batch["input1"], batch["input2"], False, mask_threshold=0.9999)
+    idx = torch.from_numpy(g["436x1024_idx"])
+    epe = torch.norm(ev["flow"].reshape(1, 2, -1)[:, :, idx] - T(g["436x1024_flow_samples"]), dim=1).mean().item()
+    assert epe <= 1e-5, epe
+    names = [str(n) for n in g["param_names"]]
+    Pt = O.make_trainable(O.synthetic_params(0))
+    ld = O.train_step(Pt, O.make_adam(Pt), O.synthetic_batch(2, 100, 132, 1234), mask_threshold=0.9999)
+    np.testing.assert_allclose([ld["flow_loss"], ld["occ_loss"], ld["total_loss"]], g["small_train_losses"], rtol=1e-5)
+    gn = np.array([float(Pt[n].grad.double().norm()) for n in names])
+    np.testing.assert_allclose(gn, g["small_train_gradnorm"], rtol=2e-3, atol=1e-4 * np.sqrt((g["small_train_gradnorm"] ** 2).sum()))
+    post = np.array([float(Pt[n].detach().double().sum()) for n in names])
+    np.testing.assert_allclose(post, g["small_poststep_sum"], rtol=1e-5, atol=1e-3)
