@@ -43,6 +43,8 @@ if os.environ.get("IRR_X3S_TRACE"):
     COMMON = COMMON + ["-DX3S_TRACE=1"]
 if os.environ.get("IRR_X3_ABL"):
     COMMON = COMMON + ["-DX3_ABL=" + os.environ["IRR_X3_ABL"]]
+if os.environ.get("IRR_CORR_ABL"):
+    COMMON = COMMON + ["-DCORR_ABL=" + os.environ["IRR_CORR_ABL"]]
 if os.environ.get("IRR_WG_TR4"):
     COMMON = COMMON + ["-DWG_TR4=1"]
 _BASE_FLAGS = 7            # len(COMMON) without macro switches

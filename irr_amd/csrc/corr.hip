@@ -112,13 +112,21 @@ constexpr int QX = 32, QY = 8;                     // tile
 constexpr int QTX = QX + 2 * HALO, QTY = QY + 2 * HALO;   // 40 x 16 halo tile
 constexpr int QP = QTX;                            // LDS row pitch (floats; 16-B aligned rows)
 constexpr int QC = 8;                              // channels per LDS stage
+// Forward tile pitch: a 16-lane pass of ds_read_b128 covers two tile rows (8 quads = 128 B each); with the natural 160-B
+// pitch the second row's window wraps onto the first row's banks (2-way conflict on every window read).  384 B = 128 B
+// (mod 256 B) puts consecutive rows on disjoint bank halves.
+constexpr int FP = 96;
 
+#ifndef CORR_ABL
+#define CORR_ABL 0      // ablation builds (timing only): 1 = no output stores, 2 = no FMA loop, 3 = no global loads in the staging
+#endif
 typedef float f32x4c __attribute__((ext_vector_type(4)));
+typedef float f32x2c __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(192) void corr81_fwd4_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                          float* __restrict__ out, int C, int H, int W, long f1_bs,
                                                          long f2_bs, long out_bs, int fuse_lrelu) {
-  __shared__ __attribute__((aligned(16))) float tile[QC][QTY][QP];
+  __shared__ __attribute__((aligned(16))) float tile[QC][QTY][FP];
   __shared__ __attribute__((aligned(16))) float t1[QC][QY][QX];      // the block's own f1 pixels
   const int tid = threadIdx.x;
   const int grp = tid / 64;                       // vertical displacements 3*grp .. 3*grp + 2
@@ -131,83 +139,133 @@ __global__ __launch_bounds__(192) void corr81_fwd4_kernel(const float* __restric
   const float* f1b = f1 + (long)b * f1_bs;
   const float* f2b = f2 + (long)b * f2_bs;
 
-  float acc[3][4][9];
+  // 108 accumulators per lane, held as 4 aligned PAIRS + 1 single per (displacement row r, pixel i): with the window value
+  // index i + d even, (d, d + 1) is an aligned register pair of the 12-float window, so two FMAs are one v_pk_fma_f32 with
+  // the f1 value broadcast by op_sel -- even i: pairs d = (0,1) (2,3) (4,5) (6,7) + single d = 8; odd i: single d = 0 +
+  // pairs d = (1,2) (3,4) (5,6) (7,8).  20 VALU instructions per row instead of 36.
+  f32x2c accp[3][4][4];
+  float accs[3][4];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      accs[r][i] = 0.f;
 #pragma unroll
-      for (int d = 0; d < 9; ++d) acc[r][i][d] = 0.f;
-
-  for (int c0 = 0; c0 < C; c0 += QC) {
-    __syncthreads();
-    {
-      constexpr int RU = QTX / 4;                           // 16-B units per halo row
-      constexpr int N2 = QC * QTY * RU, K2 = (N2 + 191) / 192;
-      constexpr int N1 = QC * QY * (QX / 4), K1 = (N1 + 191) / 192;
-      f32x4c v2[K2], v1[K1];
-#pragma unroll
-      for (int k = 0; k < K2; ++k) {
-        const int i = tid + k * 192;
-        const int c = i / (QTY * RU), r = i - c * (QTY * RU);
-        const int sy = r / RU, sx = (r - sy * RU) * 4;
-        const int yy = y0 - HALO + sy, xx = x0 - HALO + sx;
-        v2[k] = f32x4c{0.f, 0.f, 0.f, 0.f};
-        if (i < N2 && c0 + c < C && yy >= 0 && yy < H && xx >= 0 && xx < W) v2[k] = *(const f32x4c*)(f2b + (long)(c0 + c) * plane + (long)yy * W + xx);
-      }
-#pragma unroll
-      for (int k = 0; k < K1; ++k) {
-        const int i = tid + k * 192;
-        const int c = i / (QY * (QX / 4)), r = i - c * (QY * (QX / 4));
-        const int yy = y0 + r / (QX / 4), xx = x0 + (r % (QX / 4)) * 4;
-        v1[k] = f32x4c{0.f, 0.f, 0.f, 0.f};
-        if (i < N1 && c0 + c < C && yy < H && xx < W) v1[k] = *(const f32x4c*)(f1b + (long)(c0 + c) * plane + (long)yy * W + xx);
-      }
-#pragma unroll
-      for (int k = 0; k < K2; ++k) {
-        const int i = tid + k * 192;
-        const int c = i / (QTY * RU), r = i - c * (QTY * RU);
-        const int sy = r / RU, sx = (r - sy * RU) * 4;
-        if (i < N2) *(f32x4c*)(&tile[c][sy][sx]) = v2[k];
-      }
-#pragma unroll
-      for (int k = 0; k < K1; ++k) {
-        const int i = tid + k * 192;
-        if (i < N1) *(f32x4c*)(&t1[0][0][0] + 4 * i) = v1[k];
-      }
+      for (int p_ = 0; p_ < 4; ++p_) accp[r][i][p_] = f32x2c{0.f, 0.f};
     }
+
+  // Staging is software-pipelined: the global loads of stage s+1 are issued (into registers) BEFORE the FMA loop of stage
+  // s and written to LDS after it, so a block's memory latency hides behind its own arithmetic.  (Measured: three waves per
+  // SIMD / four blocks per CU instead of this register prefetch is 40 % SLOWER -- the kernel is bound by the CU's LDS
+  // pipe, which more resident blocks only contend for.)
+  constexpr int RU = QTX / 4;                               // 16-B units per halo row
+  constexpr int N2 = QC * QTY * RU, K2 = (N2 + 191) / 192;
+  constexpr int N1 = QC * QY * (QX / 4), K1 = (N1 + 191) / 192;
+  f32x4c v2[K2], v1[K1];
+  // per-thread staging roles do not depend on the stage: precompute offsets (elements; -1 = outside the image / no unit)
+  int o2[K2], o1[K1];                                      // element offsets inside the sample (< 2^31)
+#pragma unroll
+  for (int k = 0; k < K2; ++k) {
+    const int i = tid + k * 192;
+    const int c = i / (QTY * RU), r = i - c * (QTY * RU);
+    const int sy = r / RU, sx = (r - sy * RU) * 4;
+    const int yy = y0 - HALO + sy, xx = x0 - HALO + sx;
+    o2[k] = (i < N2 && yy >= 0 && yy < H && xx >= 0 && xx < W) ? (int)(c * plane + (long)yy * W + xx) : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < K1; ++k) {
+    const int i = tid + k * 192;
+    const int c = i / (QY * (QX / 4)), r = i - c * (QY * (QX / 4));
+    const int yy = y0 + r / (QX / 4), xx = x0 + (r % (QX / 4)) * 4;
+    o1[k] = (i < N1 && yy < H && xx < W) ? (int)(c * plane + (long)yy * W + xx) : -1;
+  }
+  auto issue = [&](int c0) {
+    const float* p2 = f2b + (long)c0 * plane;
+    const float* p1 = f1b + (long)c0 * plane;
+#pragma unroll
+    for (int k = 0; k < K2; ++k) {
+      v2[k] = f32x4c{0.f, 0.f, 0.f, 0.f};
+      if (CORR_ABL != 3 && o2[k] >= 0 && c0 + (tid + k * 192) / (QTY * RU) < C) v2[k] = *(const f32x4c*)(p2 + o2[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K1; ++k) {
+      v1[k] = f32x4c{0.f, 0.f, 0.f, 0.f};
+      if (CORR_ABL != 3 && o1[k] >= 0 && c0 + (tid + k * 192) / (QY * (QX / 4)) < C) v1[k] = *(const f32x4c*)(p1 + o1[k]);
+    }
+  };
+  auto publish = [&]() {
+#pragma unroll
+    for (int k = 0; k < K2; ++k) {
+      const int i = tid + k * 192;
+      if (i < N2) *(f32x4c*)(&tile[0][0][0] + (i / RU) * FP + (i % RU) * 4) = v2[k];      // unit i = (row i / RU of [c][sy], 16-B column i % RU)
+    }
+#pragma unroll
+    for (int k = 0; k < K1; ++k) {
+      const int i = tid + k * 192;
+      if (i < N1) *(f32x4c*)(&t1[0][0][0] + 4 * i) = v1[k];
+    }
+  };
+  issue(0);
+  for (int c0 = 0; c0 < C; c0 += QC) {
+    __syncthreads();                                        // the previous stage's FMAs have read the tiles
+    publish();
     __syncthreads();
+    if (c0 + QC < C) issue(c0 + QC);                        // in flight during the FMA loop below
+    // FMA loop over (channel, displacement row) steps with the NEXT step's LDS window read ahead of the current step's 36
+    // FMAs (the reads used to be issued right before their use: ~24 exposed LDS round trips per stage, the loop was bound by
+    // LDS latency, not by LDS or VALU throughput)
     const int cn = min(QC, C - c0);
-    for (int c = 0; c < cn; ++c) {
-      const f32x4c a = *(const f32x4c*)(&t1[c][ty][4 * q]);
+    const float* const trow = &tile[0][ty + 3 * grp][4 * q];
+    f32x4c a = *(const f32x4c*)(&t1[0][ty][4 * q]);
+    f32x4c w0 = *(const f32x4c*)(trow), w1 = *(const f32x4c*)(trow + 4), w2 = *(const f32x4c*)(trow + 8);
+#pragma unroll
+    for (int c = 0; c < QC; ++c) {
+      if (c >= cn || (CORR_ABL == 2 && a[0] != 12345.f)) break;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const float* row = &tile[c][ty + 3 * grp + r][4 * q];
-        const f32x4c w0 = *(const f32x4c*)(row), w1 = *(const f32x4c*)(row + 4), w2 = *(const f32x4c*)(row + 8);
+        const int cnx = r == 2 ? c + 1 : c, rnx = r == 2 ? 0 : r + 1;
+        const int cl = cnx < QC ? cnx : QC - 1;            // (the step after the last one re-reads a valid window, unused)
+        const float* row = trow + (cl * QTY + rnx) * FP;
+        const f32x4c n0 = *(const f32x4c*)(row), n1 = *(const f32x4c*)(row + 4), n2 = *(const f32x4c*)(row + 8);
+        const f32x4c an = r == 2 ? *(const f32x4c*)(&t1[cl][ty][4 * q]) : a;
+        const f32x2c wp[6] = {{w0[0], w0[1]}, {w0[2], w0[3]}, {w1[0], w1[1]}, {w1[2], w1[3]}, {w2[0], w2[1]}, {w2[2], w2[3]}};
         const float wv[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+          const f32x2c aa = {a[i], a[i]};
 #pragma unroll
-          for (int d = 0; d < 9; ++d) acc[r][i][d] = fmaf(a[i], wv[i + d], acc[r][i][d]);
+          for (int p_ = 0; p_ < 4; ++p_) accp[r][i][p_] = __builtin_elementwise_fma(aa, wp[(i + (i & 1)) / 2 + p_], accp[r][i][p_]);
+          accs[r][i] = fmaf(a[i], wv[(i & 1) ? i : i + 8], accs[r][i]);
+        }
+        w0 = n0; w1 = n1; w2 = n2; a = an;
       }
     }
   }
   if (!inside) return;
   float* o = out + (long)b * out_bs + (long)y * W + x;
+  // mean over channels (torch.mean = sum / C): for a power-of-two C the multiplication by 1/C is the same rounding as the
+  // division (108 IEEE divisions per lane were a quarter of the kernel's VALU instructions); other C divide
   const float cf = (float)C;
+  const bool pow2 = (C & (C - 1)) == 0;
+  const float rc = 1.f / cf;
+  auto store_all = [&](auto mean) {
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int d = 0; d < 9; ++d) {
-      f32x4c v;
+      for (int d = 0; d < 9; ++d) {
+        f32x4c v;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float t = acc[r][i][d] / cf;             // mean over channels (torch.mean = sum / C)
-        if (fuse_lrelu) t = irr_lrelu(t);
-        v[i] = t;
+        for (int i = 0; i < 4; ++i) {
+          const int e = d - (i & 1);                        // position among the paired displacements of pixel i
+          float t = mean((i & 1) ? (d == 0 ? accs[r][i] : accp[r][i][e / 2][e & 1]) : (d == 8 ? accs[r][i] : accp[r][i][d / 2][d & 1]));
+          if (fuse_lrelu) t = irr_lrelu(t);
+          v[i] = t;
+        }
+        if (CORR_ABL != 1 || v[0] == 12345.f) *(f32x4c*)(o + (long)((3 * grp + r) * 9 + d) * plane) = v;
       }
-      *(f32x4c*)(o + (long)((3 * grp + r) * 9 + d) * plane) = v;
-    }
+  };
+  if (pow2) store_all([&](float v) { return v * rc; });
+  else store_all([&](float v) { return v / cf; });
 }
 
 // SECOND == false: g1[c,p] = (1/C) sum_d g[d][p]     * f2[c][p+d]   (tile = f2, shift +d)
@@ -330,30 +388,39 @@ __global__ __launch_bounds__(192) void corr81_bwd4_kernel(const float* __restric
     }
   }
 
+  // software-pipelined staging as in corr81_fwd4_kernel: stage s+1 is loaded into registers during the FMAs of stage s
+  constexpr int RU = QTX / 4;
+  constexpr int N2 = QC * QTY * RU, K2 = (N2 + 191) / 192;
+  f32x4c v2[K2];
+  long o2[K2];
+  int c2[K2];
+#pragma unroll
+  for (int k = 0; k < K2; ++k) {
+    const int i = tid + k * 192;
+    const int c = i / (QTY * RU), r = i - c * (QTY * RU);
+    const int sy = r / RU, sx = (r - sy * RU) * 4;
+    const int yy = y0 - HALO + sy, xx = x0 - HALO + sx;
+    c2[k] = c;
+    o2[k] = (i < N2 && yy >= 0 && yy < H && xx >= 0 && xx < W) ? (long)c * plane + (long)yy * W + xx : -1;
+  }
+  auto issue = [&](int c0) {
+    const float* p2 = ob + (long)c0 * plane;
+#pragma unroll
+    for (int k = 0; k < K2; ++k) {
+      v2[k] = f32x4c{0.f, 0.f, 0.f, 0.f};
+      if (o2[k] >= 0 && c0 + c2[k] < C) v2[k] = *(const f32x4c*)(p2 + o2[k]);
+    }
+  };
+  issue(0);
   for (int c0 = 0; c0 < C; c0 += QC) {
     __syncthreads();                                        // previous stage's reduction has read `red`, its FMAs `tile`
-    {
-      constexpr int RU = QTX / 4;
-      constexpr int N2 = QC * QTY * RU, K2 = (N2 + 191) / 192;
-      f32x4c v2[K2];
 #pragma unroll
-      for (int k = 0; k < K2; ++k) {
-        const int i = tid + k * 192;
-        const int c = i / (QTY * RU), r = i - c * (QTY * RU);
-        const int sy = r / RU, sx = (r - sy * RU) * 4;
-        const int yy = y0 - HALO + sy, xx = x0 - HALO + sx;
-        v2[k] = f32x4c{0.f, 0.f, 0.f, 0.f};
-        if (i < N2 && c0 + c < C && yy >= 0 && yy < H && xx >= 0 && xx < W) v2[k] = *(const f32x4c*)(ob + (long)(c0 + c) * plane + (long)yy * W + xx);
-      }
-#pragma unroll
-      for (int k = 0; k < K2; ++k) {
-        const int i = tid + k * 192;
-        const int c = i / (QTY * RU), r = i - c * (QTY * RU);
-        const int sy = r / RU, sx = (r - sy * RU) * 4;
-        if (i < N2) *(f32x4c*)(&tile[c][sy][sx]) = v2[k];
-      }
+    for (int k = 0; k < K2; ++k) {
+      const int i = tid + k * 192;
+      if (i < N2) *(f32x4c*)(&tile[0][0][0] + 4 * i) = v2[k];
     }
     __syncthreads();
+    if (c0 + QC < C) issue(c0 + QC);
 #pragma unroll
     for (int c = 0; c < QC; ++c) {
       f32x4c sacc = {0.f, 0.f, 0.f, 0.f};
