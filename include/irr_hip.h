@@ -289,10 +289,12 @@ int irr_f1bal_bwd_f32(const float* logit, const float* tgt, const float* sums, c
  * scripts/IRR-PWC_flyingChairsOcc.sh:29-31) over n contiguous fp32 elements (16-byte aligned pointers):
  *   g = grad*grad_scale + wd*p ; m = lerp(m, g, 1-b1) ; v = b2*v + (1-b2)*g*g ;
  *   p -= (lr/bias_corr1) * m / (sqrt(v)/sqrt(bias_corr2) + eps)          bias_corr_i = 1 - beta_i^t
+ * step_dev (nullable): DEVICE float holding the step count t; when given, the bias corrections are computed from it inside
+ * the kernel and bias_corr1/2 are ignored -- a captured launch (hipGraph) then stays correct on every replay.
  */
 int irr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                       float lr, float beta1, float beta2, float eps, float weight_decay,
-                      float bias_corr1, float bias_corr2, float grad_scale, void* stream);
+                      float bias_corr1, float bias_corr2, float grad_scale, const float* step_dev, void* stream);
 
 /* ---- on-GPU training augmentation: RandomAffineFlowOcc (augmentations.py:368-653) -----------------------------
  * The random parameters (thetas, mirror signs, crop origin) are sampled by the host exactly as the reference does

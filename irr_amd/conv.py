@@ -357,8 +357,9 @@ class WgradSide:
         for t in keep:
             t.record_stream(self.stream)
         self._inflight.append((done, keep))
-        while self._inflight and self._inflight[0][0].query():
-            self._inflight.popleft()
+        if not torch.cuda.is_current_stream_capturing():       # (an event recorded inside a capture cannot be queried)
+            while self._inflight and self._inflight[0][0].query():
+                self._inflight.popleft()
         if self.on_launch is not None:
             self.on_launch(*params)
 

@@ -8,7 +8,12 @@ namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g,
                                                   float4* __restrict__ m, float4* __restrict__ v, long n4, long n,
                                                   float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                  float bc2_sqrt, float gscale) {
+                                                  float bc2_sqrt, float gscale, const float* __restrict__ step_dev) {
+  if (step_dev) {                    // step count kept on the device (hipGraph replays: nothing in the arguments changes per step)
+    const float t = step_dev[0];
+    bc1 = 1.f - powf(b1, t);
+    bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  }
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
@@ -38,7 +43,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const
 
 extern "C" int irr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
                                  float beta1, float beta2, float eps, float weight_decay, float bias_corr1,
-                                 float bias_corr2, float grad_scale, void* stream) {
+                                 float bias_corr2, float grad_scale, const float* step_dev, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0) return IRR_EINVAL;
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return IRR_EINVAL;
   const long n4 = n / 4;
@@ -46,7 +51,7 @@ extern "C" int irr_adam_step_f32(float* param, const float* grad, float* exp_avg
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)param, (const float4*)grad,
                      (float4*)exp_avg, (float4*)exp_avg_sq, n4, n, lr, beta1, beta2, eps, weight_decay, bias_corr1,
-                     sqrtf(bias_corr2), grad_scale);
+                     sqrtf(bias_corr2), grad_scale, step_dev);
   IRR_LAUNCH_CHECK();
   return 0;
 }

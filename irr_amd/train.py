@@ -65,6 +65,61 @@ class TrainStep:
         return loss_dict, output_dict, example_dict["input1"].shape[0]
 
 
+class GraphedTrainStep:
+    """The same optimisation step captured ONCE into a hipGraph and replayed (MI355X-side addition; the reference has no
+    counterpart).  One step of IRR-PWC is ~2 000 kernel launches, many of them on 6x7 ... 24x28 pyramid levels that finish
+    faster than the host can issue them; a replay is a single launch of the whole dependency graph -- both HIP streams of
+    the step (main + asynchronous weight-gradient lane) become branches of it.
+
+    Requirements (checked or arranged here): static shapes; inputs are copied into static buffers; the optimizer keeps
+    its step count on the device (``FusedAdam(capturable=True)``); nothing inside the step reads device data on the host --
+    the reference's per-step NaN assertion (runtime.py:182-183) is evaluated on the captured loss right after the replay.
+    Data-parallel runs (world > 1) use the eager ``TrainStep``: the gradient all-reduce is not captured."""
+
+    def __init__(self, step: TrainStep, warmup: int = 2):
+        if getattr(step.optimizer, "capturable", False) is not True:
+            raise ValueError("GraphedTrainStep needs an optimizer whose step count lives on the device (FusedAdam(capturable=True))")
+        self.step = step
+        self.warmup = warmup
+        self.check_nan = step.check_nan
+        self.graph = None
+        self.static_in: Dict[str, torch.Tensor] = {}
+        self.result = None
+
+    def _capture(self, example_dict):
+        # (detached: a caller's tensor may already require grad -- the static copies must be leaves of their own)
+        self.static_in = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in example_dict.items()}
+        eager = TrainStep(self.step.model_and_loss, self.step.optimizer, self.step.training_key, self.step.grad_sync,
+                          check_nan=False)
+        snap = self.step.optimizer.snapshot()         # the warm-up steps below must not count as training steps
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream(device=cur.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                 # warm-up off the default stream: allocator pools, caches, autograd
+            for _ in range(self.warmup):
+                eager(self.static_in)
+        cur.wait_stream(side)
+        self.step.optimizer.restore(snap)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):            # (records the step; nothing executes until replay())
+            self.result = eager(self.static_in)
+
+    def __call__(self, example_dict: Dict[str, torch.Tensor]):
+        if self.graph is None:
+            self._capture(example_dict)
+        else:
+            with torch.no_grad():
+                for k, v in example_dict.items():
+                    if torch.is_tensor(v) and v.data_ptr() != self.static_in[k].data_ptr():
+                        self.static_in[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        loss_dict, output_dict, bs = self.result
+        if self.check_nan:
+            assert not math.isnan(loss_dict[self.step.training_key].item()), "training_loss is NaN"
+        return loss_dict, output_dict, bs
+
+
 def make_adam(params, lr: float = 1e-4, weight_decay: float = 4e-4) -> torch.optim.Optimizer:
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)
 
