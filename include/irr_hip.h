@@ -158,6 +158,22 @@ int irr_conv_pack_weights_x3(const float* w, void* wq, int Cin, int Cout, int tr
 int irr_conv_pack_weights_x3_sub(const float* w, void* wq, int w_cin, int w_cout, int total_rows, int chan0,
                                  int nchan, int row_offset, void* stream);
 int irr_conv2d_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil);
+
+/* ---- batched weight packing ------------------------------------------------------------------------------------------------
+ * After an optimizer step every packed copy of every conv weight is stale; instead of one launch per copy (~250 per step) the host
+ * keeps a table of pack jobs on the device and refreshes all of them in ONE dispatch.  A job record (irr_conv_pack_job_bytes()
+ * bytes, layout private to the library) is produced in HOST memory by the builder that mirrors the single-job launcher of the
+ * same name; it returns the number of 256-thread blocks the job needs (negative: IRR_EINVAL) and leaves the record's first-block
+ * field (a long at byte offset 24) zero: the caller lays the jobs out back to back (exclusive prefix sum of the block counts),
+ * copies the table to the device and calls irr_conv_pack_batch(table, njobs, total blocks, stream). */
+int irr_conv_pack_job_bytes(void);
+long irr_conv_pack_job_f32(void* job, const float* w, float* wp, int Cin, int Cout, int k, int transpose);
+long irr_conv_pack_job_sub_f32(void* job, const float* w, float* wp, int w_cin, int w_cout, int k, int chan0, int nchan,
+                               int CoP, int row_offset);
+long irr_conv_pack_job_x3(void* job, const float* w, void* wq, int Cin, int Cout, int transpose);
+long irr_conv_pack_job_x3_sub(void* job, const float* w, void* wq, int w_cin, int w_cout, int total_rows, int chan0,
+                              int nchan, int row_offset);
+int irr_conv_pack_batch(const void* jobs, int njobs, long nblocks, void* stream);
 /* tuning knob (tests use 0 to exercise the kernel on small problems): minimum number of blocks a launch must have
  * for irr_conv2d_x3_eligible to accept it; n < 0 only queries.  Returns the previous value (default 384). */
 int irr_conv_x3_set_min_blocks(int n);

@@ -13,7 +13,9 @@ convolution lives in tools/torch_conv_backend.py, outside the product).
 from __future__ import annotations
 
 import collections
+import ctypes
 import os
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -67,31 +69,132 @@ def out_hw(h: int, w: int, k: int, stride: int, dil: int) -> Tuple[int, int]:
 
 
 # ----------------------------------------------------------------------------------------------
-# packed-weight cache: weights are re-packed only when the parameter changed (optimizer step)
+# packed-weight cache: weights are re-packed only when the parameter changed (optimizer step), and then ALL AT ONCE
 # ----------------------------------------------------------------------------------------------
-# bumped by anything that rewrites parameters outside autograd's version counters (FusedAdam.step)
+# bumped by anything that rewrites parameters outside autograd's version counters (FusedAdam.step, TrainStep)
 WEIGHT_EPOCH = [0]
 
 
-def packed_weights(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
-    """Packed copy of ``weight`` for irr_conv2d_fwd_f32, cached ON the tensor object (so it dies with the
-    parameter and can never be confused with another tensor that later reuses the same address) and
-    refreshed whenever the parameter's storage or version counter changes (optimizer step, load_state_dict)."""
-    cache = weight.__dict__.setdefault("_irr_packed", {})
+class _PackRegistry:
+    """Every packed copy of a live conv weight on one device, as a job of the batched pack launch (csrc/pack_batch.hip).
+
+    A copy is registered the first time it is built (single-job launch).  When the weight epoch changes (optimizer step) the
+    first cache miss refreshes EVERY registered copy with one dispatch and re-tags the caches, so a train step issues one pack
+    launch instead of ~250.  Entries hold weak references: they disappear with their model."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = {}               # key -> (weakref(weight), dst tensor, builder(job_addr, w_ptr) -> nblocks, retag())
+        self.version = 0
+        self.epoch = WEIGHT_EPOCH[0]
+        self._table = None              # (signature, device table, njobs, nblocks)
+
+    def register(self, key, weight, dst, builder, retag):
+        if key in self.entries:
+            return
+        reg = self
+
+        def _gone(_ref, key=key):
+            if reg.entries.pop(key, None) is not None:
+                reg.version += 1
+        self.entries[key] = (weakref.ref(weight, _gone), dst, builder, retag)
+        self.version += 1
+
+    def refresh(self) -> bool:
+        """called on a cache miss: if the epoch moved since the last refresh, repack everything registered (True)"""
+        if self.epoch == WEIGHT_EPOCH[0] or not self.entries:
+            self.epoch = WEIGHT_EPOCH[0]
+            return False
+        self.epoch = WEIGHT_EPOCH[0]
+        live = [(k, e, e[0]()) for k, e in list(self.entries.items())]
+        live = [(k, e, w) for k, e, w in live if w is not None and w.is_contiguous()]
+        if not live:
+            return False
+        sig = (self.version, tuple(w.data_ptr() for _, _, w in live))
+        if self._table is None or self._table[0] != sig:
+            jb = hip.lib().irr_conv_pack_job_bytes()
+            buf = ctypes.create_string_buffer(jb * len(live))
+            base = ctypes.addressof(buf)
+            block0 = 0
+            for n_, (_, e, w) in enumerate(live):
+                nb = e[2](base + n_ * jb, w.data_ptr())
+                if nb < 0:
+                    raise hip.HipError(f"pack job rejected ({nb})")
+                ctypes.c_long.from_address(base + n_ * jb + 24).value = block0
+                block0 += nb
+            host = torch.frombuffer(buf, dtype=torch.uint8).clone()
+            self._table = (sig, host.to(self.device), len(live), block0)
+        _, table, njobs, nblocks = self._table
+        with hip.device_of(table):
+            hip.call("irr_conv_pack_batch", hip.ptr(table), njobs, nblocks, hip.stream())
+        LAUNCHES["pack_batch"] += 1
+        for _, e, _ in live:
+            e[3]()
+        return True
+
+
+_REGISTRIES = {}
+
+
+def _registry(device) -> _PackRegistry:
+    r = _REGISTRIES.get(device.index)
+    if r is None:
+        r = _REGISTRIES[device.index] = _PackRegistry(device)
+    return r
+
+
+def _weight_tag(w: torch.Tensor):
+    return (w.data_ptr(), w._version, tuple(w.shape), WEIGHT_EPOCH[0])
+
+
+def _packed(weight: torch.Tensor, transpose: bool, slot: str, nbytes_fn, dtype, single, builder_name):
+    """shared body of packed_weights / packed_weights_x3: cache ON the tensor object (so it dies with the parameter and can
+    never be confused with another tensor that later reuses the same address), refreshed whenever the parameter's storage,
+    version counter or the weight epoch changes -- through the batched launch when the copy is already registered."""
+    cache = weight.__dict__.setdefault(slot, {})
     w = weight.detach()
-    tag = (w.data_ptr(), w._version, tuple(w.shape), WEIGHT_EPOCH[0])
-    hit = cache.get(bool(transpose))
+    key = bool(transpose)
+    tag = _weight_tag(w)
+    hit = cache.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
+    reg = _registry(w.device)
+    if hit is not None and reg.refresh():
+        hit = cache.get(key)
+        if hit[0] == _weight_tag(w):
+            return hit[1]
     cout, cin, k, _ = w.shape
     lcin, lcout = (cout, cin) if transpose else (cin, cout)
-    n = hip.lib().irr_conv_packed_weight_elems(lcin, lcout, k)
+    n = nbytes_fn(lcin, lcout, k)
     wp = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == w.device) else \
-        torch.empty(n, device=w.device, dtype=torch.float32)
+        torch.empty(n, device=w.device, dtype=dtype)
     wc = w.contiguous()
-    hip.call("irr_conv_pack_weights_f32", hip.ptr(wc), hip.ptr(wp), lcin, lcout, k, int(transpose), hip.stream())
-    cache[bool(transpose)] = (tag, wp)
+    single(wc, wp, lcin, lcout, k, int(transpose))
+    LAUNCHES["pack_single"] += 1
+    cache[key] = (tag, wp)
+    if w.is_contiguous():
+        wref = weakref.ref(weight)
+
+        def retag(cache=cache, key=key, wp=wp, wref=wref):
+            t = wref()
+            if t is not None:
+                cache[key] = (_weight_tag(t.detach()), wp)
+        fn = getattr(hip.lib(), builder_name)
+        if builder_name == "irr_conv_pack_job_f32":
+            builder = lambda job, wptr, wp=wp: fn(job, wptr, wp.data_ptr(), lcin, lcout, k, int(transpose))
+        else:
+            builder = lambda job, wptr, wp=wp: fn(job, wptr, wp.data_ptr(), lcin, lcout, int(transpose))
+        reg.register((id(weight), slot, key), weight, wp, builder, retag)
     return wp
+
+
+def packed_weights(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
+    """Packed copy of ``weight`` for irr_conv2d_fwd_f32 (see _packed)."""
+    return _packed(weight, transpose, "_irr_packed", lambda ci, co, k: hip.lib().irr_conv_packed_weight_elems(ci, co, k),
+                   torch.float32,
+                   lambda wc, wp, ci, co, k, tr: hip.call("irr_conv_pack_weights_f32", hip.ptr(wc), hip.ptr(wp), ci, co, k, tr,
+                                                          hip.stream()),
+                   "irr_conv_pack_job_f32")
 
 
 # "x3": 3x3 stride-1 convs run on the bf16 matrix pipe with exact 3-way operand splits (csrc/conv_x3.hip, fp32-faithful)
@@ -120,23 +223,12 @@ def x3_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, di
 
 
 def packed_weights_x3(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
-    """Pre-split (3 x bf16) packed copy of ``weight`` for irr_conv2d_fwd_x3; cached like packed_weights()."""
-    cache = weight.__dict__.setdefault("_irr_packed_x3", {})
-    w = weight.detach()
-    tag = (w.data_ptr(), w._version, tuple(w.shape), WEIGHT_EPOCH[0])
-    hit = cache.get(bool(transpose))
-    if hit is not None and hit[0] == tag:
-        return hit[1]
-    cout, cin, k, _ = w.shape
-    assert k == 3
-    lcin, lcout = (cout, cin) if transpose else (cin, cout)
-    n = hip.lib().irr_conv_x3_packed_bytes(lcin, lcout)
-    wq = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == w.device) else \
-        torch.empty(n, device=w.device, dtype=torch.uint8)
-    wc = w.contiguous()
-    hip.call("irr_conv_pack_weights_x3", hip.ptr(wc), hip.ptr(wq), lcin, lcout, int(transpose), hip.stream())
-    cache[bool(transpose)] = (tag, wq)
-    return wq
+    """Pre-split (3 x bf16) packed copy of ``weight`` for irr_conv2d_fwd_x3 (see _packed)."""
+    assert weight.shape[2] == 3
+    return _packed(weight, transpose, "_irr_packed_x3", lambda ci, co, k: hip.lib().irr_conv_x3_packed_bytes(ci, co), torch.uint8,
+                   lambda wc, wp, ci, co, k, tr: hip.call("irr_conv_pack_weights_x3", hip.ptr(wc), hip.ptr(wp), ci, co, tr,
+                                                          hip.stream()),
+                   "irr_conv_pack_job_x3")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -538,7 +630,7 @@ class _DenseEstimatorFn(hip.Function):
         else:
             lrelu_bwd_bias(G[:, :32], buf[:, :32], True, G[:, :32], None)
         use_x3 = [bool(x3_code(B, t0, H, W, t1 - t0, 3, 1, 1)) for (t0, t1) in ((32, 96), (96, 192), (192, 320), (320, 448), (448, ctot))]
-        packs = _dense_column_packs(ws[:5], cin0, tuple(use_x3))
+        packs = _dense_column_packs(ctx.wobjs[:5], cin0, tuple(use_x3))
         grads_w[4], grads_b[4] = wgrad_param(buf[:, 32:ctot], G[:, :32], ctx.wobjs[4], ctx.bobjs[4], 1, 1)   # conv5
         bounds = [(32, 96), (96, 192), (192, 320), (320, 448), (448, ctot)]
         for k_, (t0, t1) in enumerate(bounds):
@@ -575,35 +667,58 @@ class _DenseEstimatorFn(hip.Function):
 def _dense_column_packs(ws5, cin0: int, use_x3=(False,) * 5):
     """Combined (transposed, flipped) packed weights for the five column targets c4, c3, c2, c1, x of the DenseNet
     buffer; cached on the first weight tensor (per kernel-family choice) and rebuilt when any of the five conv weights
-    changed.  use_x3[k]: column k runs on irr_conv2d_fwd_x3 and needs the pre-split layout."""
-    tags = tuple((w.data_ptr(), w._version) for w in ws5) + (WEIGHT_EPOCH[0], cin0)
-    holder = ws5[0].__dict__.setdefault("_irr_dense_packs", {}).setdefault(tuple(use_x3), {})
+    changed -- as sub-jobs of the batched pack launch once they are registered.  The buffers are allocated (zeroed) once:
+    rows and columns that no layer covers stay zero, the sub-jobs only rewrite what they own.
+    use_x3[k]: column k runs on irr_conv2d_fwd_x3 and needs the pre-split layout."""
+    def cur_tags():
+        return tuple((w.data_ptr(), w._version) for w in ws5) + (WEIGHT_EPOCH[0], cin0)
+    tags = cur_tags()
+    holder = ws5[0].__dict__.setdefault("_irr_dense_packs", {}).setdefault((tuple(use_x3), cin0), {})
     if holder.get("tag") == tags:
         return holder["packs"]
-    grow = _DenseEstimatorFn.GROW                         # out channels of conv1..conv5
+    reg = _registry(ws5[0].device)
+    if "packs" in holder and reg.refresh() and holder.get("tag") == cur_tags():
+        return holder["packs"]
     in0 = [448, 320, 192, 96, 32]                         # first buffer channel read by conv1..conv5
     row0 = {5: 0, 4: 32, 3: 96, 2: 192, 1: 320}           # row (= G channel) where conv i's gradient slice starts
     bounds = [(32, 96), (96, 192), (192, 320), (320, 448), (448, 448 + cin0)]
-    packs = []
     dev = ws5[0].device
+    fresh = "packs" not in holder
+    packs = [] if fresh else holder["packs"]
+    lib = hip.lib()
+    wrefs = [weakref.ref(w) for w in ws5]
+
+    def retag(holder=holder, wrefs=wrefs):
+        live = [r() for r in wrefs]
+        if all(w is not None for w in live):
+            holder["tag"] = tuple((w.data_ptr(), w._version) for w in live) + (WEIGHT_EPOCH[0], cin0)
+
     for k_, (t0, t1) in enumerate(bounds):
         n = t1 - t0
         cop = (n + 31) // 32 * 32
-        if use_x3[k_]:
-            wp = torch.zeros(hip.lib().irr_conv_x3_packed_bytes(t0, n), device=dev, dtype=torch.uint8)
-        else:
-            wp = torch.zeros(hip.lib().irr_conv_packed_weight_elems(t0, n, 3), device=dev, dtype=torch.float32)
+        if fresh:
+            if use_x3[k_]:
+                packs.append(torch.zeros(lib.irr_conv_x3_packed_bytes(t0, n), device=dev, dtype=torch.uint8))
+            else:
+                packs.append(torch.zeros(lib.irr_conv_packed_weight_elems(t0, n, 3), device=dev, dtype=torch.float32))
+        wp = packs[k_]
         for i in (5, 4, 3, 2, 1):
             if in0[i - 1] > t0:
                 continue                                  # conv i does not read this slice
-            w = ws5[i - 1].detach().contiguous()
+            wsrc = ws5[i - 1]
+            w = wsrc.detach().contiguous()
+            wcin, wcout, c0 = w.shape[1], w.shape[0], t0 - in0[i - 1]
             if use_x3[k_]:
-                hip.call("irr_conv_pack_weights_x3_sub", hip.ptr(w), hip.ptr(wp), w.shape[1], w.shape[0], t0,
-                         t0 - in0[i - 1], n, row0[i], hip.stream())
+                hip.call("irr_conv_pack_weights_x3_sub", hip.ptr(w), hip.ptr(wp), wcin, wcout, t0, c0, n, row0[i], hip.stream())
+                builder = (lambda job, wptr, wp=wp, a=(wcin, wcout, t0, c0, n, row0[i]):
+                           lib.irr_conv_pack_job_x3_sub(job, wptr, wp.data_ptr(), *a))
             else:
-                hip.call("irr_conv_pack_weights_sub_f32", hip.ptr(w), hip.ptr(wp), w.shape[1], w.shape[0], 3,
-                         t0 - in0[i - 1], n, cop, row0[i], hip.stream())
-        packs.append(wp)
+                hip.call("irr_conv_pack_weights_sub_f32", hip.ptr(w), hip.ptr(wp), wcin, wcout, 3, c0, n, cop, row0[i], hip.stream())
+                builder = (lambda job, wptr, wp=wp, a=(wcin, wcout, 3, c0, n, cop, row0[i]):
+                           lib.irr_conv_pack_job_sub_f32(job, wptr, wp.data_ptr(), *a))
+            LAUNCHES["pack_single"] += 1
+            if wsrc.is_contiguous():
+                reg.register((id(ws5[0]), "dense", tuple(use_x3), cin0, k_, i), wsrc, wp, builder, retag)
     holder["tag"] = tags
     holder["packs"] = packs
     return packs

@@ -18,6 +18,7 @@
 //     residual/scale and the "+=" used for DenseNet gradient accumulation.
 // The same kernel computes the stride-1 data gradient when fed transposed+flipped packed weights.
 #include "common.h"
+#include "pack.h"
 
 #ifndef CONV_ORDER
 #define CONV_ORDER 3        // 3 (default): one refill load issued behind each MFMA of the step; 0/1/2: block orders kept for A/B runs
@@ -253,46 +254,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int KK,
                                     int CoP, int transpose, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (i >= n - 4 * 32) { wp[i] = 0.f; return; }       // tail slack
-  const int co = (int)(i % CoP);
-  long r = i / CoP;
-  const int half = (int)(r & 1);
-  r >>= 1;
-  const int tap = (int)(r % KK);
-  const int cp = (int)(r / KK);
-  int ci = 2 * cp + half;
-  bool zero_row = false;
-  if ((Cin & 1) && cp == (Cin >> 1)) {        // odd tail: lanes read channels (Cin-2, Cin-1); Cin-2 was already consumed
-    ci = Cin - 2 + half;
-    zero_row = (half == 0);
-  }
-  float v = 0.f;
-  if (!transpose) {
-    if (!zero_row && ci < Cin && co < Cout) v = w[((long)co * Cin + ci) * KK + tap];
-  } else {
-    // logical conv': Cin' = Cout(orig), Cout' = Cin(orig): here (Cin, Cout) are ALREADY the swapped sizes;
-    // w is the original (Cout_orig = Cin, Cin_orig = Cout) tensor: w[ci][co][KK-1-tap]
-    if (!zero_row && ci < Cin && co < Cout) v = w[((long)ci * Cout + co) * KK + (KK - 1 - tap)];
-  }
-  wp[i] = v;
+  if (i < n) pack_f32_elem(w, wp, Cin, Cout, KK, CoP, transpose, n, i);
 }
 
-// Sub-block pack for COMBINED data-gradient weights (DenseNet backward): rows [row_offset, row_offset + w_cout) of the
-// packed matrix take the transposed+flipped weights of one layer restricted to its input channels
-// [chan0, chan0 + nchan):  wp[((r/2*KK + tap)*2 + (r&1))*CoP + c] = w[r - row_offset][chan0 + c][KK-1-tap].
+// (combined data-gradient matrices of the DenseNet backward: see pack_sub_elem in pack.h)
 __global__ void pack_weights_sub_kernel(const float* __restrict__ w, float* __restrict__ wp, int w_cin, int w_cout, int KK,
                                         int chan0, int nchan, int CoP, int row_offset, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int c = (int)(i % CoP);
-  long r1 = i / CoP;
-  const int tap = (int)(r1 % KK);
-  const int rl = (int)(r1 / KK);                 // local row = output channel of the layer
-  const int r = row_offset + rl;
-  float v = 0.f;
-  if (c < nchan) v = w[((long)rl * w_cin + chan0 + c) * KK + (KK - 1 - tap)];
-  wp[(((long)(r >> 1) * KK + tap) * 2 + (r & 1)) * CoP + c] = v;
+  if (i < n) pack_sub_elem(w, wp, w_cin, KK, chan0, nchan, CoP, row_offset, i);
 }
 
 template <int MT, int NT, int KS>

@@ -23,6 +23,7 @@
 //     (chunk, tap, piece, co-tile) is exactly the A fragment; prefetched one tap ahead.
 //   * epilogue identical to conv_fwd.hip (bias, LeakyReLU, residual/scale, "+=", LeakyReLU'-mask).
 #include "x3_split.h"
+#include "pack.h"
 #include <stdlib.h>
 #include <atomic>
 
@@ -569,49 +570,11 @@ static bool x3s_ok(int B, int Cin, int H, int W, int Cout, int dil) {
   return eff >= 0.8 && (tiles >= 2048 || g_min_blocks == 0);
 }
 
-// ---- weight packing: wq[(((chunk*9 + tap)*3 + piece)*CoT + cot)*64 + lane] = 8 bf16 (k-group g = lane>>5, row i = lane&31) ----
-// mode 0: w is (Cout, Cin, 3, 3)                    -> forward
-// mode 1: w is (Cin, Cout, 3, 3) = original layout, used transposed + flipped -> stride-1 data gradient
-// mode 2: sub-block of a COMBINED data-gradient matrix (DenseNet backward): rows [row_offset, row_offset + w_cout)
-//         take layer weights w (w_cout, w_cin, 3, 3) transposed+flipped, restricted to input channels [chan0, chan0+Cout)
+// ---- weight packing: see pack_x3_unit (pack.h) for the layout and the three modes ----
 __global__ void pack_x3_kernel(const float* __restrict__ w, u32x4* __restrict__ wq, int Cin, int Cout, int CoT, int nchunk,
                                int mode, int w_cin, int chan0, int row_offset, int w_cout, long nunits) {
   const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= nunits) return;
-  const int lane = (int)(u & 63);
-  long r = u >> 6;
-  const int cot = (int)(r % CoT);
-  r /= CoT;
-  const int tap = (int)(r % 9);
-  const int chunk = (int)(r / 9);
-  const int g = lane >> 5, i = lane & 31;
-  const int co = cot * 32 + i;
-  const bool tail = (chunk == nchunk - 1) && (Cin & 15);
-  const int ch0 = (tail ? Cin - 16 : chunk * 16) + 8 * g;
-  float v[8];
-  bool any = false;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int ci = ch0 + e;
-    float val = 0.f;
-    const bool dup = tail && ci < (nchunk - 1) * 16;
-    if (!dup && ci >= 0 && ci < Cin && co < Cout) {
-      if (mode == 0) val = w[((long)co * Cin + ci) * 9 + tap];
-      else if (mode == 1) val = w[((long)ci * Cout + co) * 9 + (8 - tap)];
-      else if (ci >= row_offset && ci < row_offset + w_cout) {
-        val = w[((long)(ci - row_offset) * w_cin + chan0 + co) * 9 + (8 - tap)];
-        any = true;
-      }
-    }
-    v[e] = val;
-  }
-  if (mode == 2 && !any) return;                   // rows of other layers: leave untouched
-  u32x4 h, m, l;
-  split8(v, h, m, l);
-  const long base = (((long)chunk * 9 + tap) * 3 * CoT + cot) * 64 + lane;
-  wq[base] = h;
-  wq[base + (long)CoT * 64] = m;
-  wq[base + 2L * CoT * 64] = l;
+  if (u < nunits) pack_x3_unit(w, wq, Cin, Cout, CoT, nchunk, mode, w_cin, chan0, row_offset, w_cout, u);
 }
 
 struct TileCfg { int nt, tr, tc; };

@@ -12,6 +12,8 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
+from . import conv as _conv
+
 
 class ModelAndLoss(nn.Module):
     """configuration.py:20-62: chains model -> loss, owns the ``_model.*`` state_dict namespace."""
@@ -62,6 +64,7 @@ class TrainStep:
         if self.grad_sync is not None:
             self.grad_sync()
         self.optimizer.step()
+        _conv.WEIGHT_EPOCH[0] += 1                # every packed weight copy is stale now: they are refreshed by ONE launch
         return loss_dict, output_dict, example_dict["input1"].shape[0]
 
 
