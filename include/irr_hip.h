@@ -66,13 +66,15 @@ int irr_corr81_bwd_f32(const float* f1, const float* f2, const float* gout, cons
  * WarpingLayer.forward (models/pwc_modules.py:115-133) incl. get_grid (:107-112):
  *   grid = linspace(-1,1) + flow*2/max(size_im-1,1)/div_flow ; bilinear, zeros padding,
  *   align_corners=True ; out = sample(x) * (sample(ones) >= mask_thr).
+ * swap_halves != 0 (B even): sample b warps x[(b + B/2) % B] -- both flow directions run as one batch [x1; x2] whose "other
+ * image" is [x2; x1]; the kernel reads (and, in backward, scatters into) the other batch half instead of a swapped copy.
  * gridx[W], gridy[H] are the two torch.linspace(-1,1,n) vectors (device), so that the base grid is
  * bit-identical to the reference's.  mask_thr = 1.0 is the reference as-is.
  */
 int irr_warp_fwd_f32(const float* x, const float* flow, const float* gridx, const float* gridy,
                      float* out, int B, int C, int H, int W,
                      long x_bs, long flow_bs, long out_bs,
-                     int height_im, int width_im, float div_flow, float mask_thr, void* stream);
+                     int height_im, int width_im, float div_flow, float mask_thr, int swap_halves, void* stream);
 
 /* gx (nullable) receives the scatter-add gradient w.r.t. x (zeroed inside), gflow (nullable) the
  * gradient w.r.t. flow.  No gradient flows through the mask (piecewise constant). */
@@ -80,7 +82,7 @@ int irr_warp_bwd_f32(const float* x, const float* flow, const float* gridx, cons
                      const float* gout, float* gx, float* gflow,
                      int B, int C, int H, int W,
                      long x_bs, long flow_bs, long gout_bs, long gx_bs, long gflow_bs,
-                     int height_im, int width_im, float div_flow, float mask_thr, void* stream);
+                     int height_im, int width_im, float div_flow, float mask_thr, int swap_halves, void* stream);
 
 /* ---- bilinear resize, align_corners=True --------------------------------------------------------
  * upsample2d_as (models/pwc_modules.py:65-67).  out = alpha * resize(x).

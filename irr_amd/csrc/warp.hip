@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
                                                       const float* __restrict__ gridx, const float* __restrict__ gridy,
                                                       float* __restrict__ out, int C, int H, int W, long x_bs,
                                                       long flow_bs, long out_bs, float den_w, float den_h,
-                                                      float div_flow, float mask_thr, int cchunk) {
+                                                      float div_flow, float mask_thr, int cchunk, int xshift) {
   const long plane = (long)H * W;
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= plane) return;
@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
   const float* fl = flow + (long)b * flow_bs;
   const Taps t = make_taps(fl[p], fl[plane + p], gridx[xx], gridy[yy], H, W, den_w, den_h, div_flow, mask_thr);
   const long o_nw = (long)t.y0 * W + t.x0;
-  const float* xb = x + (long)b * x_bs;
+  const int bx = (b + xshift) % (int)gridDim.z;             // swap_halves: sample b reads the OTHER half of x
+  const float* xb = x + (long)bx * x_bs;
   float* ob = out + (long)b * out_bs + p;
   for (int c = c_begin; c < c_end; ++c) {
     const float* xc = xb + (long)c * plane;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
                                                       const float* __restrict__ gout, float* __restrict__ gx,
                                                       float* __restrict__ gflow, int C, int H, int W, long x_bs,
                                                       long flow_bs, long gout_bs, long gx_bs, long gflow_bs,
-                                                      float den_w, float den_h, float div_flow, float mask_thr) {
+                                                      float den_w, float den_h, float div_flow, float mask_thr, int xshift) {
   const long plane = (long)H * W;
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool act = p < plane;
@@ -127,9 +128,10 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
   const bool do_nw = wnw != 0.f || tne != 0.f, do_sw = wsw != 0.f || tse != 0.f;
   const bool do_ne = wne != 0.f && !given, do_se = wse != 0.f && !given;
   float gix = 0.f, giy = 0.f;
-  const float* xb = x + (long)b * x_bs;
+  const int bx = (b + xshift) % (int)gridDim.z;             // swap_halves: x (and its gradient) of the other batch half
+  const float* xb = x + (long)bx * x_bs;
   const float* gb = gout + (long)b * gout_bs + pp;
-  float* gxb = gx ? gx + (long)b * gx_bs : nullptr;
+  float* gxb = gx ? gx + (long)bx * gx_bs : nullptr;
   for (int c = 0; c < C; ++c) {
     const float g = act ? gb[(long)c * plane] : 0.f;
     if (gxb) {
@@ -163,8 +165,9 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
 
 extern "C" int irr_warp_fwd_f32(const float* x, const float* flow, const float* gridx, const float* gridy, float* out,
                                 int B, int C, int H, int W, long x_bs, long flow_bs, long out_bs, int height_im,
-                                int width_im, float div_flow, float mask_thr, void* stream) {
+                                int width_im, float div_flow, float mask_thr, int swap_halves, void* stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !x || !flow || !gridx || !gridy || !out || B > 65535) return IRR_EINVAL;
+  if (swap_halves && (B & 1)) return IRR_EINVAL;
   const long plane = (long)H * W;
   // split channels over blockIdx.y only when the pixel grid alone cannot fill 256 CUs
   int cchunk = C;
@@ -173,7 +176,7 @@ extern "C" int irr_warp_fwd_f32(const float* x, const float* flow, const float* 
   dim3 grid(irr_cdiv(plane, 256), irr_cdiv(C, cchunk), B);
   const float den_w = (float)(width_im - 1 > 1 ? width_im - 1 : 1), den_h = (float)(height_im - 1 > 1 ? height_im - 1 : 1);
   hipLaunchKernelGGL(warp_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, flow, gridx, gridy, out, C, H, W, x_bs,
-                     flow_bs, out_bs, den_w, den_h, div_flow, mask_thr, cchunk);
+                     flow_bs, out_bs, den_w, den_h, div_flow, mask_thr, cchunk, swap_halves ? B / 2 : 0);
   IRR_LAUNCH_CHECK();
   return 0;
 }
@@ -181,8 +184,9 @@ extern "C" int irr_warp_fwd_f32(const float* x, const float* flow, const float* 
 extern "C" int irr_warp_bwd_f32(const float* x, const float* flow, const float* gridx, const float* gridy,
                                 const float* gout, float* gx, float* gflow, int B, int C, int H, int W, long x_bs,
                                 long flow_bs, long gout_bs, long gx_bs, long gflow_bs, int height_im, int width_im,
-                                float div_flow, float mask_thr, void* stream) {
+                                float div_flow, float mask_thr, int swap_halves, void* stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !x || !flow || !gridx || !gridy || !gout || B > 65535) return IRR_EINVAL;
+  if (swap_halves && (B & 1)) return IRR_EINVAL;
   if (!gx && !gflow) return 0;
   const long plane = (long)H * W;
   if (gx) {
@@ -197,7 +201,7 @@ extern "C" int irr_warp_bwd_f32(const float* x, const float* flow, const float* 
   dim3 grid(irr_cdiv(plane, 256), 1, B);
   const float den_w = (float)(width_im - 1 > 1 ? width_im - 1 : 1), den_h = (float)(height_im - 1 > 1 ? height_im - 1 : 1);
   hipLaunchKernelGGL(warp_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, flow, gridx, gridy, gout, gx, gflow, C,
-                     H, W, x_bs, flow_bs, gout_bs, gx_bs, gflow_bs, den_w, den_h, div_flow, mask_thr);
+                     H, W, x_bs, flow_bs, gout_bs, gx_bs, gflow_bs, den_w, den_h, div_flow, mask_thr, swap_halves ? B / 2 : 0);
   IRR_LAUNCH_CHECK();
   return 0;
 }

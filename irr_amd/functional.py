@@ -94,22 +94,22 @@ def compute_cost_volume(feat1, feat2, param_dict):
 # ----------------------------------------------------------------------------------------------
 class _Warp(hip.Function):
     @staticmethod
-    def forward(ctx, x, flow, height_im: int, width_im: int, div_flow: float, mask_thr: float):
+    def forward(ctx, x, flow, height_im: int, width_im: int, div_flow: float, mask_thr: float, swap: bool = False):
         _need_cuda(x, flow)
         x, flow = _pd(x), _pd(flow)
         B, C, H, W = x.shape
         gx, gy = _linspace_dev(W, x.device), _linspace_dev(H, x.device)
         out = torch.empty_like(x)
         hip.call("irr_warp_fwd_f32", hip.ptr(x), hip.ptr(flow), hip.ptr(gx), hip.ptr(gy), hip.ptr(out), B, C, H, W,
-                 hip.bs(x), hip.bs(flow), hip.bs(out), height_im, width_im, div_flow, mask_thr, hip.stream())
-        ctx.cfg = (height_im, width_im, div_flow, mask_thr)
+                 hip.bs(x), hip.bs(flow), hip.bs(out), height_im, width_im, div_flow, mask_thr, int(swap), hip.stream())
+        ctx.cfg = (height_im, width_im, div_flow, mask_thr, swap)
         ctx.save_for_backward(x, flow)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         x, flow = ctx.saved_tensors
-        height_im, width_im, div_flow, mask_thr = ctx.cfg
+        height_im, width_im, div_flow, mask_thr, swap = ctx.cfg
         gout = _pd(gout)
         B, C, H, W = x.shape
         gxg, gyg = _linspace_dev(W, x.device), _linspace_dev(H, x.device)
@@ -118,15 +118,16 @@ class _Warp(hip.Function):
         hip.call("irr_warp_bwd_f32", hip.ptr(x), hip.ptr(flow), hip.ptr(gxg), hip.ptr(gyg), hip.ptr(gout),
                  hip.ptr(gx), hip.ptr(gf), B, C, H, W, hip.bs(x), hip.bs(flow), hip.bs(gout),
                  hip.bs(gx) if gx is not None else 0, hip.bs(gf) if gf is not None else 0,
-                 height_im, width_im, div_flow, mask_thr, hip.stream())
-        return gx, gf, None, None, None, None
+                 height_im, width_im, div_flow, mask_thr, int(swap), hip.stream())
+        return gx, gf, None, None, None, None, None
 
 
-def warp(x, flow, height_im: int, width_im: int, div_flow: float, mask_threshold: float = 1.0):
-    """WarpingLayer.forward (models/pwc_modules.py:119-133)."""
+def warp(x, flow, height_im: int, width_im: int, div_flow: float, mask_threshold: float = 1.0, swap_halves: bool = False):
+    """WarpingLayer.forward (models/pwc_modules.py:119-133).  swap_halves: sample b warps x[(b + B/2) % B] (the other
+    image of a [x1; x2] batch) without a swapped copy of x."""
     if x.shape[0] != flow.shape[0] or x.shape[2:] != flow.shape[2:] or flow.shape[1] != 2:
         raise ValueError(f"bad shapes for warp: x {tuple(x.shape)} flow {tuple(flow.shape)}")
-    return _Warp.apply(x, flow, int(height_im), int(width_im), float(div_flow), float(mask_threshold))
+    return _Warp.apply(x, flow, int(height_im), int(width_im), float(div_flow), float(mask_threshold), bool(swap_halves))
 
 
 # ----------------------------------------------------------------------------------------------

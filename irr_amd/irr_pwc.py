@@ -151,8 +151,9 @@ class PWCNet(nn.Module):
         raw = torch.cat([x1_raw, x2_raw], dim=0)                 # [x1; x2]   (2B)
         pyr = self.feature_pyramid_extractor(raw) + [raw]        # coarsest first; both images in one pass
 
-        def warp(x, fl):
-            return self.warping_layer(x, fl, H, W, div)
+        def warp_other(x, fl):
+            """warp the OTHER image's tensor by this direction's flow: sample b of [x1; x2] reads sample (b + B) % 2B"""
+            return self.warping_layer(x, fl, H, W, div, swap_halves=True)
 
         h0, w0 = pyr[0].shape[2:]
         flow = torch.zeros(2 * B, 2, h0, w0, device=dev)          # [flow_f; flow_b]
@@ -161,14 +162,13 @@ class PWCNet(nn.Module):
 
         for l, x in enumerate(pyr):
             h, w = x.shape[2:]
-            xo = _swap_halves(x)                                  # the other image's features
             if l <= self.output_level:
                 if l == 0:
-                    xo_warp = xo
+                    xo_warp = _swap_halves(x)                     # the other image's features (6x7: the only swapped copy)
                 else:
                     flow = Fn.resize_bilinear_ac(flow, h, w)
                     occ = Fn.resize_bilinear_ac(occ, h, w)
-                    xo_warp = warp(xo, flow)
+                    xo_warp = warp_other(x, flow)
                 corr = Fn.cost_volume(x, xo_warp, lrelu=True)     # cost volume + LeakyReLU fused
 
                 x_1by1 = self.conv_1x1[l](x) if l != self.output_level else x
@@ -202,13 +202,12 @@ class PWCNet(nn.Module):
 
                 # refinement (models/IRR_PWC.py:126-138, alias-free)
                 img = Fn.resize_bilinear_ac(raw, h, w)
-                img_o = _swap_halves(img)
                 G = flow_cont * t_glb
-                img_o_warp = warp(img_o, G)
+                img_o_warp = warp_other(img, G)
                 flow = self.refine_flow(G.detach(), img - img_o_warp, x_1by1, scale=s_glb)   # incl. to_global
                 flow_cont = G * t_glb
 
-                x_1by1_o_warp = warp(_swap_halves(x_1by1), flow)
+                x_1by1_o_warp = warp_other(x_1by1, flow)
                 if pending_join is not None:
                     pending_join[0].wait_stream(pending_join[1])
                     occ_cont.record_stream(pending_join[0])
@@ -219,8 +218,8 @@ class PWCNet(nn.Module):
             else:
                 flow = Fn.resize_bilinear_ac(flow, h, w)
                 flows.append(list(_split_halves(flow)))
-                xo_warp = warp(xo, flow)
-                flow_o_warp = warp(_swap_halves(flow), flow)
+                xo_warp = warp_other(x, flow)
+                flow_o_warp = warp_other(flow, flow)
                 if l != self.num_levels - 1:
                     # conv_1x1_1 on x and on the warped other image: one launch over the 4B batch
                     both = self.conv_1x1_1(torch.cat([x, xo_warp], dim=0))

@@ -99,8 +99,8 @@ class WarpingLayer(nn.Module):
         super().__init__()
         self.mask_threshold = mask_threshold
 
-    def forward(self, x, flow, height_im, width_im, div_flow):
-        return Fn.warp(x, flow, height_im, width_im, div_flow, self.mask_threshold)
+    def forward(self, x, flow, height_im, width_im, div_flow, swap_halves=False):
+        return Fn.warp(x, flow, height_im, width_im, div_flow, self.mask_threshold, swap_halves)
 
 
 class _DenseEstimator(nn.Module):

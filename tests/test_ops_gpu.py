@@ -131,3 +131,25 @@ def test_cost_volume_full_size_properties():
     # displacement (dy,dx)=(+1,-2): channel (1+4)*9+(-2+4)=47
     ref = (f1[:, :, :-1, 2:] * f2[:, :, 1:, :-2]).mean(1)
     assert torch.allclose(cv[:, 47, :-1, 2:], ref, atol=1e-5)
+
+
+def test_warp_swap_halves_equals_swapped_copy():
+    """swap_halves=True warps the OTHER batch half of x (the model's [x1; x2] / [x2; x1] pairing) without the copy: values,
+    the gradient scattered into the other half of gx, and the flow gradient equal those of an explicit torch.cat swap"""
+    from irr_amd import functional as Fn
+    g = torch.Generator().manual_seed(21)
+    B, C, H, W = 4, 5, 24, 36
+    x = torch.randn(B, C, H, W, generator=g)
+    fl = 3.0 * torch.randn(B, 2, H, W, generator=g)
+    go = torch.randn(B, C, H, W, generator=g).cuda()
+    xa, fa = x.cuda().requires_grad_(True), fl.cuda().requires_grad_(True)
+    ya = Fn.warp(torch.cat([xa[B // 2:], xa[:B // 2]], dim=0), fa, 4 * H, 4 * W, 0.05, 0.9999)
+    ya.backward(go)
+    xb, fb = x.cuda().requires_grad_(True), fl.cuda().requires_grad_(True)
+    yb = Fn.warp(xb, fb, 4 * H, 4 * W, 0.05, 0.9999, swap_halves=True)
+    yb.backward(go)
+    assert torch.equal(ya, yb)
+    np.testing.assert_allclose(xb.grad.cpu().numpy(), xa.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(fb.grad.cpu().numpy(), fa.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    with pytest.raises(Exception):
+        Fn.warp(x[:3].cuda(), fl[:3].cuda(), 4 * H, 4 * W, 0.05, 1.0, swap_halves=True)
