@@ -28,3 +28,12 @@ static inline int irr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float irr_lrelu(float v) { return v > 0.f ? v : 0.1f * v; }
 __device__ __forceinline__ float irr_lrelu_grad(float y) { return y > 0.f ? 1.f : 0.1f; }
+
+// XCD-aware block order (speed only, never correctness): the dispatcher is observed to place workgroup b on XCD b % 8, each XCD
+// with its own 4 MiB L2 (MI355X_MICROARCH.md, "Workgroup dispatch").  irr_xcd_order maps the linear workgroup id to its
+// position in "XCD-major" order: ids of one XCD get CONSECUTIVE positions, so a kernel that decodes (position -> tile) with
+// the operand-sharing index fastest keeps the blocks that read the same data on one XCD's L2.  Bijection on [0, total).
+__device__ __forceinline__ unsigned irr_xcd_order(unsigned lin, unsigned total) {
+  const unsigned per = total >> 3, rem = total & 7u, r = lin & 7u, q = lin >> 3;
+  return r * per + (r < rem ? r : rem) + q;
+}

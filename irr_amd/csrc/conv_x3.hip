@@ -78,7 +78,12 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ct = wave % CT, pg = wave / CT;
   const int j = lane & 31, g = lane >> 5;
-  int bt = blockIdx.x;
+  // XCD-major block order (common.h): blocks of one XCD take CONSECUTIVE tiles (their halos overlap in that XCD's L2), and
+  // the co-tile groups of one pixel tile (blockIdx.y, layers with more co-tiles than CT) stay on one XCD: they read the
+  // same input patch.  K-split slices (blockIdx.z) read different channels and are left alone.
+  const unsigned xpos = irr_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int by = (int)(xpos % gridDim.y);
+  int bt = (int)(xpos / gridDim.y);
   const int tx = bt % a.tiles_x;
   bt /= a.tiles_x;
   const int ty = bt % a.tiles_y;
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
   const int LW = a.TC + 2 * d, LH = a.TR + 2 * dy;
   const int npix = LH * LW;
   const long hw = (long)a.H * a.W;
-  const int cot = blockIdx.y * CT + ct;
+  const int cot = by * CT + ct;
   const bool active = cot < a.CoT;
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)0x80000000u, 0x00020000);
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long hw = (long)a.H * a.W;
-  const long t_begin = blockIdx.x, t_step = gridDim.x;
+  const long t_begin = irr_xcd_order(blockIdx.x, gridDim.x), t_step = gridDim.x;     // blocks of one XCD walk neighbouring tiles (shared halos)
 #ifdef X3S_TRACE
   int ntr = 0;
   unsigned long long* dbgp = a.dbg + (size_t)wave * 400;
