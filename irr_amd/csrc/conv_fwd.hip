@@ -74,9 +74,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
   const long ohw = (long)a.OH * a.OW;
   const long hw = (long)a.H * a.W;
   const long total = (long)a.B * ohw;
-  const long pbase = SPLITK ? (long)blockIdx.x * (NT * 32) : ((long)blockIdx.x * 4 + wave) * (NT * 32);
+  // XCD-major block order (common.h): blocks of one XCD take consecutive pixel ranges (shared halo rows in that XCD's L2),
+  // the co-tile groups of one pixel range stay together
+  const unsigned xpos = irr_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const unsigned bxp = xpos / gridDim.y;
+  const long pbase = SPLITK ? (long)bxp * (NT * 32) : ((long)bxp * 4 + wave) * (NT * 32);
   if (pbase >= total) return;
-  const int cog = blockIdx.y;
+  const int cog = (int)(xpos % gridDim.y);
 
   uint32_t voff[NT][KK];
   bool valid[NT][KK];

@@ -132,7 +132,9 @@ __global__ __launch_bounds__(192) void corr81_fwd4_kernel(const float* __restric
   const int grp = tid / 64;                       // vertical displacements 3*grp .. 3*grp + 2
   const int t64 = tid - grp * 64;
   const int q = t64 & 7, ty = t64 >> 3;           // quad column (4 pixels), tile row
-  const int x0 = blockIdx.x * QX, y0 = blockIdx.y * QY, b = blockIdx.z;
+  // XCD-major tile order (common.h): the tiles of one XCD are neighbours, their 2.5x halo overlap is served by that XCD's L2
+  const unsigned tpos = irr_xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+  const int x0 = (int)(tpos % gridDim.x) * QX, y0 = (int)((tpos / gridDim.x) % gridDim.y) * QY, b = (int)(tpos / (gridDim.x * gridDim.y));
   const int x = x0 + 4 * q, y = y0 + ty;
   const bool inside = (x < W) && (y < H);         // W % 4 == 0: a quad is inside or outside as a whole
   const long plane = (long)H * W;
@@ -342,7 +344,9 @@ __global__ __launch_bounds__(192) void corr81_bwd4_kernel(const float* __restric
   const int grp = tid / 64;
   const int t64 = tid - grp * 64;
   const int q = t64 & 7, ty = t64 >> 3;
-  const int x0 = blockIdx.x * QX, y0 = blockIdx.y * QY, b = blockIdx.z;
+  // XCD-major tile order (common.h): the tiles of one XCD are neighbours, their 2.5x halo overlap is served by that XCD's L2
+  const unsigned tpos = irr_xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+  const int x0 = (int)(tpos % gridDim.x) * QX, y0 = (int)((tpos / gridDim.x) % gridDim.y) * QY, b = (int)(tpos / (gridDim.x * gridDim.y));
   const int x = x0 + 4 * q, y = y0 + ty;
   const bool inside = (x < W) && (y < H);
   const long plane = (long)H * W;
