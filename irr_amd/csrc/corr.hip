@@ -122,6 +122,7 @@ constexpr int FP = 96;
 #endif
 typedef float f32x4c __attribute__((ext_vector_type(4)));
 typedef float f32x2c __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // dword-aligned 16-B global access
 
 __global__ __launch_bounds__(192) void corr81_fwd4_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                          float* __restrict__ out, int C, int H, int W, long f1_bs,
@@ -376,18 +377,31 @@ __global__ __launch_bounds__(192) void corr81_bwd4_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) wgt[r][i][dx] = g[i];
       } else {
-        const int yy = y - (dy - 4);
+        // the quad's four sources are consecutive pixels of row y - (dy - 4) starting at x - (dx - 4): one dword-aligned
+        // 16-B load when the whole quad lies inside the row (it used to be four scalar loads with four bounds checks --
+        // 216 load instructions per lane before the first FMA); element-wise only at the image borders
+        const int yy = y - (dy - 4), xx0 = x - (dx - 4);
+        f32x4c g = {0.f, 0.f, 0.f, 0.f};
+        if (inside && yy >= 0 && yy < H) {
+          const long off = (long)d * plane + (long)yy * W + xx0;
+          if (xx0 >= 0 && xx0 + 3 < W) {
+            g = *(const f32x4u*)(gb + off);
+            if (fb) {
+              const f32x4c f = *(const f32x4u*)(fb + off);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int xx = x + i - (dx - 4);
-          float g = 0.f;
-          if (inside && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const long off = (long)d * plane + (long)yy * W + xx;
-            g = gb[off];
-            if (fb) g *= irr_lrelu_grad(fb[off]);
+              for (int i = 0; i < 4; ++i) g[i] *= irr_lrelu_grad(f[i]);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (xx0 + i >= 0 && xx0 + i < W) {
+                g[i] = gb[off + i];
+                if (fb) g[i] *= irr_lrelu_grad(fb[off + i]);
+              }
           }
-          wgt[r][i][dx] = g;
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wgt[r][i][dx] = g[i];
       }
     }
   }
