@@ -302,6 +302,28 @@ int irr_f1bal_value_f32(const float* sums, float* out, int B, int HW, float scal
 int irr_f1bal_bwd_f32(const float* logit, const float* tgt, const float* sums, const float* gscale, float* glogit,
                       int B, int HW, long l_bs, long t_bs, long g_bs, float weight, void* stream);
 
+/* All terms of one kind in ONE launch (the loss has 24 EPE and 24 balanced-F1 terms).  `terms` is a HOST array of nterms
+ * (<= IRR_LOSS_MAX_TERMS) records; it is copied into the kernel arguments, nothing is read from it after the call returns.
+ *   pred / tgt   the term's prediction (flow (B,2,h,w) or occlusion logits (B,1,h,w)) and its pooled target
+ *   grad         (bwd) where the gradient w.r.t. pred goes;  aux: (F1) the term's zeroed sums[B][4] scratch, kept for bwd
+ *   weight       EPE: level weight;  F1: level weight * h*w*0.5  (what irr_f1bal_value_f32 takes as `scale`)
+ *   hw, *_bs     pixels per plane and batch strides in elements;  nbx / block0 are filled in by the library
+ * fwd:  out[0] += sum over terms of the term's weighted loss (out is NOT zeroed);  bwd: grad_t = gscale[0] * d term / d pred. */
+#define IRR_LOSS_MAX_TERMS 32
+typedef struct IrrLossTerm {
+  const float* pred;
+  const float* tgt;
+  float* grad;
+  float* aux;
+  long hw, pred_bs, tgt_bs, grad_bs;
+  float weight;
+  int B, nbx, block0;
+} IrrLossTerm;
+int irr_epe_sum_multi_fwd_f32(const void* terms, int nterms, float* out, void* stream);
+int irr_epe_sum_multi_bwd_f32(const void* terms, int nterms, const float* gscale, void* stream);
+int irr_f1bal_multi_fwd_f32(const void* terms, int nterms, float* out, void* stream);
+int irr_f1bal_multi_bwd_f32(const void* terms, int nterms, const float* gscale, void* stream);
+
 /* ---- fused Adam over one flat arena ------------------------------------------------------------------
  * torch.optim.Adam semantics (runtime.py:189; lr 1e-4, weight_decay 4e-4 as L2-in-gradient,
  * scripts/IRR-PWC_flyingChairsOcc.sh:29-31) over n contiguous fp32 elements (16-byte aligned pointers):

@@ -133,6 +133,145 @@ __global__ __launch_bounds__(256) void f1_bwd_kernel(const float* __restrict__ l
   glogit[(long)b * g_bs + p] = gscale[0] * weight * dls * s * (1.f - s);
 }
 
+
+// ---- all terms of one kind in ONE launch ----------------------------------------------------------------------------------
+// The loss has 24 EPE terms and 24 balanced-F1 terms (7 pyramid levels x 2 or 4 outputs x 2 directions); each used to be
+// 1 + 1 (EPE) or 2 + 1 (F1) launches of a few blocks -- ~150 launches of a step's ~2 000, issued right after the step's only
+// host sync, where the GPU waits for the host.  The term table travels BY VALUE in the kernel arguments (no device copy).
+struct LossTerms {
+  IrrLossTerm t[IRR_LOSS_MAX_TERMS];
+  int n;
+};
+
+__device__ __forceinline__ int find_term(const LossTerms& T, int blk) {
+  int i = 0;
+  while (i + 1 < T.n && T.t[i + 1].block0 <= blk) ++i;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void epe_multi_fwd_kernel(const LossTerms T, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int ti = find_term(T, blockIdx.x);
+  const IrrLossTerm& m = T.t[ti];
+  const int lb = blockIdx.x - m.block0, nbx = m.nbx;
+  const int b = lb / nbx, bx = lb - b * nbx;
+  const long hw = m.hw;
+  const float* f = m.pred + (long)b * m.pred_bs;
+  const float* t = m.tgt + (long)b * m.tgt_bs;
+  float s = 0.f;
+  for (long p = (long)bx * 256 + threadIdx.x; p < hw; p += (long)nbx * 256) {
+    const float du = t[p] - f[p], dv = t[hw + p] - f[hw + p];
+    s += sqrtf(du * du + dv * dv);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, m.weight * s);
+}
+
+__global__ __launch_bounds__(256) void epe_multi_bwd_kernel(const LossTerms T, const float* __restrict__ gscale) {
+  const int ti = find_term(T, blockIdx.x);
+  const IrrLossTerm& m = T.t[ti];
+  const int lb = blockIdx.x - m.block0, nbx = m.nbx;
+  const int b = lb / nbx;
+  const long p = (long)(lb - b * nbx) * 256 + threadIdx.x;
+  const long hw = m.hw;
+  if (p >= hw) return;
+  const float* f = m.pred + (long)b * m.pred_bs;
+  const float* t = m.tgt + (long)b * m.tgt_bs;
+  float* g = m.grad + (long)b * m.grad_bs;
+  const float du = f[p] - t[p], dv = f[hw + p] - t[hw + p];
+  const float n = sqrtf(du * du + dv * dv);
+  const float k = n > 0.f ? gscale[0] * m.weight / n : 0.f;
+  g[p] = k * du;
+  g[hw + p] = k * dv;
+}
+
+__global__ __launch_bounds__(256) void f1_multi_sums_kernel(const LossTerms T) {
+  __shared__ float red[4];
+  const int ti = find_term(T, blockIdx.x);
+  const IrrLossTerm& m = T.t[ti];
+  const int lb = blockIdx.x - m.block0, nbx = m.nbx;
+  const int b = lb / nbx, bx = lb - b * nbx;
+  const long hw = m.hw;
+  const float* l = m.pred + (long)b * m.pred_bs;
+  const float* t = m.tgt + (long)b * m.tgt_bs;
+  const float eps = 1e-8f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (long p = (long)bx * 256 + threadIdx.x; p < hw; p += (long)nbx * 256) {
+    const float s = 1.f / (1.f + expf(-l[p]));
+    const float tt = t[p];
+    a0 -= tt * logf(s + eps);
+    a1 -= (1.f - tt) * logf((1.f - s) + eps);
+    a2 += tt;
+    a3 += s;
+  }
+  a0 = block_sum(a0, red);
+  a1 = block_sum(a1, red);
+  a2 = block_sum(a2, red);
+  a3 = block_sum(a3, red);
+  if (threadIdx.x == 0) {
+    float* sums = m.aux + b * 4;
+    unsafeAtomicAdd(sums + 0, a0);
+    unsafeAtomicAdd(sums + 1, a1);
+    unsafeAtomicAdd(sums + 2, a2);
+    unsafeAtomicAdd(sums + 3, a3);
+  }
+}
+
+// out[0] += sum over the terms of weight * ( sum_b tp/(st+sp+eps) + sum_b fn/((N-st)+(N-sp)+eps) ): one wave per term
+__global__ __launch_bounds__(64) void f1_multi_value_kernel(const LossTerms T, float* __restrict__ out) {
+  const IrrLossTerm& m = T.t[blockIdx.x];
+  const float eps = 1e-8f, n = (float)m.hw;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = threadIdx.x; b < m.B; b += 64) {
+    const float tp = m.aux[b * 4 + 0], fn = m.aux[b * 4 + 1], st = m.aux[b * 4 + 2], sp = m.aux[b * 4 + 3];
+    s1 += tp / (st + sp + eps);
+    s2 += fn / ((n - st) + (n - sp) + eps);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_down(s1, o, 64);
+    s2 += __shfl_down(s2, o, 64);
+  }
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, (s1 + s2) * m.weight);
+}
+
+__global__ __launch_bounds__(256) void f1_multi_bwd_kernel(const LossTerms T, const float* __restrict__ gscale) {
+  const int ti = find_term(T, blockIdx.x);
+  const IrrLossTerm& m = T.t[ti];
+  const int lb = blockIdx.x - m.block0, nbx = m.nbx;
+  const int b = lb / nbx;
+  const long p = (long)(lb - b * nbx) * 256 + threadIdx.x;
+  const long hw = m.hw;
+  if (p >= hw) return;
+  const float eps = 1e-8f;
+  const float* sums = m.aux + b * 4;
+  const float tp = sums[0], fn = sums[1], st = sums[2], sp = sums[3];
+  const float N = (float)hw;
+  const float D1 = st + sp + eps, D2 = (N - st) + (N - sp) + eps;
+  const float s = 1.f / (1.f + expf(-m.pred[(long)b * m.pred_bs + p]));
+  const float tt = m.tgt[(long)b * m.tgt_bs + p];
+  const float dls = -tt / ((s + eps) * D1) - tp / (D1 * D1) + (1.f - tt) / (((1.f - s) + eps) * D2) + fn / (D2 * D2);
+  m.grad[(long)b * m.grad_bs + p] = gscale[0] * m.weight * dls * s * (1.f - s);
+}
+
+// lays the terms out over the blocks of one launch; mode 0: a few grid-stride blocks per sample (reductions), 1: one thread per pixel
+static long layout_terms(const IrrLossTerm* in, int n, int mode, LossTerms* T) {
+  if (!in || n <= 0 || n > IRR_LOSS_MAX_TERMS) return -1;
+  long blk = 0;
+  for (int i = 0; i < n; ++i) {
+    IrrLossTerm t = in[i];
+    if (!t.pred || !t.tgt || t.B <= 0 || t.hw <= 0) return -1;
+    int nbx = mode == 0 ? irr_cdiv(t.hw, 256 * 8) : irr_cdiv(t.hw, 256);
+    if (mode == 0 && nbx > 256) nbx = 256;
+    t.nbx = nbx;
+    t.block0 = (int)blk;
+    blk += (long)nbx * t.B;
+    T->t[i] = t;
+  }
+  T->n = n;
+  return blk < 0x7fffffffL ? blk : -1;
+}
+
 }  // namespace
 
 extern "C" int irr_avgpool_f32(const float* in, float* out, int BC, int h, int w, int s, float scale, void* stream) {
@@ -213,6 +352,52 @@ extern "C" int irr_f1bal_bwd_f32(const float* logit, const float* tgt, const flo
   if (!logit || !tgt || !sums || !gscale || !glogit || B <= 0 || HW <= 0 || B > 65535) return IRR_EINVAL;
   hipLaunchKernelGGL(f1_bwd_kernel, dim3(irr_cdiv(HW, 256), B), dim3(256), 0, (hipStream_t)stream, logit, tgt, sums,
                      gscale, glogit, (long)HW, l_bs, t_bs, g_bs, weight);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- multi-term entry points: `terms` is a HOST array of nterms IrrLossTerm records (include/irr_hip.h) ----
+extern "C" int irr_epe_sum_multi_fwd_f32(const void* terms, int nterms, float* out, void* stream) {
+  LossTerms T;
+  const long nb = layout_terms((const IrrLossTerm*)terms, nterms, 0, &T);
+  if (nb <= 0 || !out) return IRR_EINVAL;
+  hipLaunchKernelGGL(epe_multi_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, T, out);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_epe_sum_multi_bwd_f32(const void* terms, int nterms, const float* gscale, void* stream) {
+  LossTerms T;
+  const long nb = layout_terms((const IrrLossTerm*)terms, nterms, 1, &T);
+  if (nb <= 0 || !gscale) return IRR_EINVAL;
+  for (int i = 0; i < nterms; ++i)
+    if (!T.t[i].grad) return IRR_EINVAL;
+  hipLaunchKernelGGL(epe_multi_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, T, gscale);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+// per-sample sums of every term into its zeroed aux[B][4], then out[0] += sum over terms of weight * per-sample algebra
+extern "C" int irr_f1bal_multi_fwd_f32(const void* terms, int nterms, float* out, void* stream) {
+  LossTerms T;
+  const long nb = layout_terms((const IrrLossTerm*)terms, nterms, 0, &T);
+  if (nb <= 0 || !out) return IRR_EINVAL;
+  for (int i = 0; i < nterms; ++i)
+    if (!T.t[i].aux) return IRR_EINVAL;
+  hipLaunchKernelGGL(f1_multi_sums_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, T);
+  IRR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(f1_multi_value_kernel, dim3((unsigned)nterms), dim3(64), 0, (hipStream_t)stream, T, out);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_f1bal_multi_bwd_f32(const void* terms, int nterms, const float* gscale, void* stream) {
+  LossTerms T;
+  const long nb = layout_terms((const IrrLossTerm*)terms, nterms, 1, &T);
+  if (nb <= 0 || !gscale) return IRR_EINVAL;
+  for (int i = 0; i < nterms; ++i)
+    if (!T.t[i].grad || !T.t[i].aux) return IRR_EINVAL;
+  hipLaunchKernelGGL(f1_multi_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, T, gscale);
   IRR_LAUNCH_CHECK();
   return 0;
 }

@@ -12,11 +12,15 @@ of a single-process run on the global batch.
 """
 from __future__ import annotations
 
+import ctypes
+import os
+
 import torch
 import torch.nn as nn
 
 from . import hip
 
+_SINGLE_TERM_LAUNCHES = os.environ.get("IRR_LOSS_SINGLE") is not None
 LEVEL_WEIGHTS = [0.32, 0.08, 0.02, 0.01, 0.005, 0.00125, 0.0003125]      # losses.py:522
 
 
@@ -103,6 +107,111 @@ class _F1BalLoss(hip.Function):
         return gl, None, None
 
 
+class _Term(ctypes.Structure):
+    """IrrLossTerm of include/irr_hip.h"""
+    _fields_ = [("pred", ctypes.c_void_p), ("tgt", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("aux", ctypes.c_void_p),
+                ("hw", ctypes.c_long), ("pred_bs", ctypes.c_long), ("tgt_bs", ctypes.c_long), ("grad_bs", ctypes.c_long),
+                ("weight", ctypes.c_float), ("B", ctypes.c_int), ("nbx", ctypes.c_int), ("block0", ctypes.c_int)]
+
+
+MAX_TERMS = 32          # IRR_LOSS_MAX_TERMS
+
+
+def _term_table(preds, tgts, weights, grads=None, aux=None):
+    n = len(preds)
+    arr = (_Term * n)()
+    for i in range(n):
+        p, t = preds[i], tgts[i]
+        e = arr[i]
+        e.pred, e.tgt = p.data_ptr(), t.data_ptr()
+        e.grad = grads[i].data_ptr() if grads is not None else None
+        e.aux = aux[i].data_ptr() if aux is not None else None
+        e.hw = p.shape[2] * p.shape[3]
+        e.pred_bs, e.tgt_bs = hip.bs(p), hip.bs(t)
+        e.grad_bs = hip.bs(grads[i]) if grads is not None else 0
+        e.weight = weights[i]
+        e.B = p.shape[0]
+    return arr
+
+
+class _MultiEpe(hip.Function):
+    """sum_i weight_i * sum_p ||tgt_i - flow_i||_2 over ALL flow terms of the loss in one launch (and one for the gradients)."""
+
+    @staticmethod
+    def forward(ctx, weights, *tensors):
+        n = len(weights)
+        preds = [_dense(t) for t in tensors[:n]]
+        tgts = [_dense(t) for t in tensors[n:]]
+        _need_cuda(*preds, *tgts)
+        out = torch.zeros(1, device=preds[0].device, dtype=torch.float32)
+        for i0 in range(0, n, MAX_TERMS):
+            sl = slice(i0, i0 + MAX_TERMS)
+            arr = _term_table(preds[sl], tgts[sl], weights[sl])
+            hip.call("irr_epe_sum_multi_fwd_f32", ctypes.addressof(arr), len(arr), hip.ptr(out), hip.stream())
+        ctx.weights = weights
+        ctx.n = n
+        ctx.save_for_backward(*preds, *tgts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.n
+        preds, tgts = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        g = g.contiguous()
+        grads = [torch.empty(p.shape, device=p.device, dtype=torch.float32) for p in preds]
+        for i0 in range(0, n, MAX_TERMS):
+            sl = slice(i0, i0 + MAX_TERMS)
+            arr = _term_table(preds[sl], tgts[sl], ctx.weights[sl], grads=grads[sl])
+            hip.call("irr_epe_sum_multi_bwd_f32", ctypes.addressof(arr), len(arr), hip.ptr(g), hip.stream())
+        return (None, *grads, *([None] * n))
+
+
+class _MultiF1Bal(hip.Function):
+    """sum_i weight_i * f1_score_bal_loss(sigmoid(logit_i), target_i) over ALL occlusion terms: two launches forward (per-sample
+    sums, per-term algebra), one backward."""
+
+    @staticmethod
+    def forward(ctx, weights, *tensors):
+        n = len(weights)
+        preds = [_dense(t) for t in tensors[:n]]
+        tgts = [_dense(t) for t in tensors[n:]]
+        _need_cuda(*preds, *tgts)
+        B = preds[0].shape[0]
+        sums = torch.zeros(n, B, 4, device=preds[0].device, dtype=torch.float32)
+        out = torch.zeros(1, device=preds[0].device, dtype=torch.float32)
+        scaled = tuple(w * p.shape[2] * p.shape[3] * 0.5 for w, p in zip(weights, preds))       # losses.py:553-556
+        for i0 in range(0, n, MAX_TERMS):
+            sl = slice(i0, i0 + MAX_TERMS)
+            arr = _term_table(preds[sl], tgts[sl], scaled[sl], aux=[sums[i] for i in range(i0, min(n, i0 + MAX_TERMS))])
+            hip.call("irr_f1bal_multi_fwd_f32", ctypes.addressof(arr), len(arr), hip.ptr(out), hip.stream())
+        ctx.scaled = scaled
+        ctx.n = n
+        ctx.save_for_backward(sums, *preds, *tgts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.n
+        sums = ctx.saved_tensors[0]
+        preds, tgts = ctx.saved_tensors[1:1 + n], ctx.saved_tensors[1 + n:]
+        g = g.contiguous()
+        grads = [torch.empty(p.shape, device=p.device, dtype=torch.float32) for p in preds]
+        for i0 in range(0, n, MAX_TERMS):
+            sl = slice(i0, i0 + MAX_TERMS)
+            arr = _term_table(preds[sl], tgts[sl], ctx.scaled[sl], grads=grads[sl],
+                              aux=[sums[i] for i in range(i0, min(n, i0 + MAX_TERMS))])
+            hip.call("irr_f1bal_multi_bwd_f32", ctypes.addressof(arr), len(arr), hip.ptr(g), hip.stream())
+        return (None, *grads, *([None] * n))
+
+
+def multi_epe(preds, tgts, weights):
+    return _MultiEpe.apply(tuple(float(w) for w in weights), *preds, *tgts)
+
+
+def multi_f1_bal(preds, tgts, weights):
+    return _MultiF1Bal.apply(tuple(float(w) for w in weights), *preds, *tgts)
+
+
 def balance_and_total(flow_loss, occ_loss, batch_size, reduce_fn=None):
     """losses.py:560-571 on device scalars: the smaller of the two terms is scaled up to the larger one."""
     f_loss, o_loss = flow_loss.detach(), occ_loss.detach()
@@ -163,21 +272,30 @@ class MultiScaleEPE_PWC_Bi_Occ_upsample(nn.Module):
             def pool(kind, idx, like):
                 return pooled[(kind, idx, like.shape[2], like.shape[3])]
 
-            flow_terms, occ_terms = [], []
+            f_pred, f_tgt, f_w, o_pred, o_tgt, o_w = [], [], [], [], [], []
             for ii, output_ii in enumerate(output_flo):
                 wgt = self._weights[ii] / len(output_ii)
                 for jj in range(len(output_ii) // 2):
                     for d in (0, 1):                                              # forward / backward direction
                         o = output_ii[2 * jj + d]
-                        flow_terms.append(_EpeSum.apply(o, pool("f", d, o), wgt))
+                        f_pred.append(o)
+                        f_tgt.append(pool("f", d, o))
+                        f_w.append(wgt)
             for ii, output_ii in enumerate(output_occ):
                 wgt = self._weights[ii] / len(output_ii)
                 for jj in range(len(output_ii) // 2):
                     for d in (0, 1):
                         o = output_ii[2 * jj + d]
-                        occ_terms.append(_F1BalLoss.apply(o, pool("o", d, o), wgt))
-            flow_loss = torch.cat(flow_terms).sum()
-            occ_loss = torch.cat(occ_terms).sum()
+                        o_pred.append(o)
+                        o_tgt.append(pool("o", d, o))
+                        o_w.append(wgt)
+            # all 24 flow terms in one launch, all 24 occlusion terms in two (csrc/loss.hip, multi-term kernels)
+            if _SINGLE_TERM_LAUNCHES:                                             # A/B switch (IRR_LOSS_SINGLE=1)
+                flow_loss = torch.cat([_EpeSum.apply(p_, t_, w_) for p_, t_, w_ in zip(f_pred, f_tgt, f_w)]).sum()
+                occ_loss = torch.cat([_F1BalLoss.apply(p_, t_, w_) for p_, t_, w_ in zip(o_pred, o_tgt, o_w)]).sum()
+            else:
+                flow_loss = multi_epe(f_pred, f_tgt, f_w).sum()
+                occ_loss = multi_f1_bal(o_pred, o_tgt, o_w).sum()
             loss_dict = balance_and_total(flow_loss, occ_loss, self._batch_size, self._reduce_fn)
         else:
             tgt = target_dict["target1"]
