@@ -202,6 +202,11 @@ def main():
               % (st.get("segment.all.allocated", 0) - seg0, st.get("segment.all.allocated", 0), st.get("num_alloc_retries", 0),
                  torch.cuda.max_memory_allocated(device) / 1e9, torch.cuda.max_memory_reserved(device) / 1e9), file=sys.stderr)
     C.TIMER = None
+    # what one step was ROUTED to (launch counters of irr_amd.conv), taken on one extra step outside the timed region
+    C.LAUNCHES.clear()
+    step(batch)
+    torch.cuda.synchronize()
+    routing = dict(C.LAUNCHES)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -262,6 +267,7 @@ def main():
                           "parallelism": f"dp{world}", "weights": "MSRA init, torch.manual_seed(0)"},
                "loss": {k: float(v.detach()) for k, v in ld.items()},
                "conv_math": C.MATH,
+               "launches_per_step": routing,
                "step_conv_tflops": round(value / world * gf * 1e9 / 1e12, 1) if gf else None,
                "step_mfma_frac": round(value / world * gf * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4) if gf else None,
                "roofline": roof}

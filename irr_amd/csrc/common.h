@@ -26,7 +26,8 @@ static inline int irr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
     return v;                                                \
   }())
 
-__device__ __forceinline__ float irr_lrelu(float v) { return v > 0.f ? v : 0.1f * v; }
+// LeakyReLU(0.1): max(v, 0.1 v) is the same value for every input incl. -0 and NaN (two VALU instead of compare + select + multiply)
+__device__ __forceinline__ float irr_lrelu(float v) { return fmaxf(v, 0.1f * v); }
 __device__ __forceinline__ float irr_lrelu_grad(float y) { return y > 0.f ? 1.f : 0.1f; }
 
 // XCD-aware block order (speed only, never correctness): the dispatcher is observed to place workgroup b on XCD b % 8, each XCD

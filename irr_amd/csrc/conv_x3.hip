@@ -328,6 +328,10 @@ struct X3SArgs {
 #define TR(slot) do {} while (0)
 #endif
 
+// EPI: what the epilogue has to read besides the accumulators -- 0: nothing (bias, LeakyReLU, alpha), 1: + a residual operand,
+// 2: everything (residual, accumulate-into-output, LeakyReLU'-mask).  The kernel is bound by the producer waves' VALU issue
+// slots (operand split + epilogue), so the plain layers do not pay for 24 operand loads and 5 unused VALU per output.
+template <int EPI>
 __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
   constexpr int PLANE_PIX = 352;                           // >= 10 x 34 halo patch
   constexpr int CHUNK = 6 * PLANE_PIX;                     // 16-B units per chunk slot: [piece][g][pixel]
@@ -418,17 +422,21 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
       const int oy = ty * 8 + eq_row, ox = tx * 32 + eq_q * 4;
       const bool pv = oy < a.H && ox < a.W;
       const long pofs = (long)oy * a.W + ox + (long)eq_c8 * 8 * hw;
-      const uint32_t vr = (pv && a.res) ? (uint32_t)(((long)b * a.res_bs + pofs) * 4) : OOB;
+      const uint32_t vr = (EPI >= 1 && pv && a.res) ? (uint32_t)(((long)b * a.res_bs + pofs) * 4) : OOB;
       evd = pv ? (uint32_t)(((long)b * a.y_bs + pofs) * 4) : OOB;
-      const uint32_t vm = (pv && a.mask) ? (uint32_t)(((long)b * a.mask_bs + pofs) * 4) : OOB;
+      const uint32_t vm = (EPI == 2 && pv && a.mask) ? (uint32_t)(((long)b * a.mask_bs + pofs) * 4) : OOB;
+      if (EPI >= 1) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const uint32_t so = (uint32_t)e * hw4;
-        const int co = eq_c8 * 8 + e;
-        const bool cok = co < a.Cout;
-        erv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)(cok ? vr : OOB), (int)so, 0));
-        edv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)((cok && a.accumulate) ? evd : OOB), (int)so, 0));
-        emv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rmask, (int)((cok && co < a.nmask) ? vm : OOB), (int)so, 0));
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t so = (uint32_t)e * hw4;
+          const int co = eq_c8 * 8 + e;
+          const bool cok = co < a.Cout;
+          erv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)(cok ? vr : OOB), (int)so, 0));
+          if (EPI == 2) {
+            edv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)((cok && a.accumulate) ? evd : OOB), (int)so, 0));
+            emv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rmask, (int)((cok && co < a.nmask) ? vm : OOB), (int)so, 0));
+          }
+        }
       }
     };
     f32x4 eacc[8];                                           // the finished tile's accumulators, copied out of the LDS stage
@@ -445,9 +453,12 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
         for (int px = 0; px < 4; ++px) {
           float v = eacc[e][px] + bias_r[e];
           if (a.lrelu) v = irr_lrelu(v);
-          v = erv[e][px] + a.alpha * v;             // erv = 0 without a residual operand
-          v += edv[e][px];                          // edv = 0 unless accumulating
-          if (a.mask && co < a.nmask) v *= irr_lrelu_grad(emv[e][px]);
+          if (EPI == 0) v *= a.alpha;
+          else v = erv[e][px] + a.alpha * v;        // erv = 0 without a residual operand
+          if (EPI == 2) {
+            v += edv[e][px];                        // edv = 0 unless accumulating
+            if (a.mask && co < a.nmask) v *= irr_lrelu_grad(emv[e][px]);
+          }
           o[px] = v;
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, (int)((co < a.Cout && X3_ABL != 7) ? evd : OOB),
@@ -828,7 +839,9 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
     constexpr size_t lds_bytes = (18 * 3 * 64 + 2 * 6 * 352) * 16 + 32 * 256 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       attr_set = true;
     }
     // every operand is addressed through 32-bit byte voffsets below the 2 GiB out-of-range marker
@@ -856,7 +869,10 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
         s.res = res ? res + (long)b0 * res_bs + co0 * hw_ : nullptr;
         s.mask = (mask && nmask > co0) ? mask + (long)b0 * mask_bs + co0 * hw_ : nullptr;
         s.nmask = nmask - (int)co0 < 0 ? 0 : (nmask - (int)co0 > 32 ? 32 : nmask - (int)co0);
-        hipLaunchKernelGGL(conv_x3s_kernel, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
+        const int epi = (s.accumulate || s.mask) ? 2 : s.res ? 1 : 0;
+        if (epi == 0) hipLaunchKernelGGL(conv_x3s_kernel<0>, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
+        else if (epi == 1) hipLaunchKernelGGL(conv_x3s_kernel<1>, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
+        else hipLaunchKernelGGL(conv_x3s_kernel<2>, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
         IRR_LAUNCH_CHECK();
       }
     }

@@ -4,7 +4,7 @@
 # 1. bench.py default (two-lane) with the CPU baseline          -> <tag>_bench.json
 # 2. rocprofv3 --kernel-trace --stats, default and single-stream -> <tag>_kernel_stats{,_serial}.txt (+ the JSON line of the same run)
 # 3. two separate PMC passes (FETCH_SIZE, WRITE_SIZE)            -> <tag>_hbm_traffic.txt, hbm_traffic.json
-TAG=${1:-r1}
+TAG=${1:-r2}
 OUT=gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -12,6 +12,7 @@ python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python bench.py --no-async-wgrad --no-cpu-baseline > $OUT/${TAG}_bench_serial.json 2>> $OUT/${TAG}_bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 bench.py --no-cpu-baseline --steps 5 > $OUT/${TAG}_bench_under_rocprof.json 2>> $OUT/${TAG}_bench.err
 python tools/rocpd_stats.py $(find $OUT/kt -name "*.db" | head -1) 50 > $OUT/${TAG}_kernel_stats.txt
+python tools/rocpd_timeline.py $(find $OUT/kt -name "*.db" | head -1) > $OUT/${TAG}_timeline_two_lane.txt 2>&1
 rm -rf $OUT/kt
 rocprofv3 --kernel-trace --stats -d $OUT/kts -o kts -- python3 bench.py --no-cpu-baseline --no-async-wgrad --steps 5 > $OUT/${TAG}_bench_serial_under_rocprof.json 2>> $OUT/${TAG}_bench.err
 python tools/rocpd_stats.py $(find $OUT/kts -name "*.db" | head -1) 50 > $OUT/${TAG}_kernel_stats_serial.txt
@@ -22,4 +23,7 @@ F=$(find $OUT/pf -name "*.db" | head -1); W=$(find $OUT/pw -name "*.db" | head -
 python tools/rocpd_traffic.py $F $W > $OUT/${TAG}_hbm_traffic.txt
 python tools/rocpd_traffic_json.py $F $W > $OUT/hbm_traffic.json
 rm -rf $OUT/pf $OUT/pw
+IRR_CONV_MATH=f32 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_math_f32.json 2>> $OUT/${TAG}_bench.err
+python bench.py --no-cpu-baseline --batch 8 --height 448 --width 1024 > $OUT/${TAG}_bench_448x1024_bs8.json 2>> $OUT/${TAG}_bench.err
+bash tools/pmc_ops.sh ${TAG} > /dev/null 2>&1
 ls -la $OUT
