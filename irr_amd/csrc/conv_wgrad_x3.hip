@@ -20,6 +20,9 @@
 #include "x3_split.h"
 #include <stdlib.h>
 
+#ifndef WX3_STAGGER
+#define WX3_STAGGER 0  // 1 (A/B): the two waves of a SIMD publish / compute in opposite orders (see the unit loop); 0: all compute first
+#endif
 #ifndef WX3_ABL
 #define WX3_ABL 0      // ablation builds (timing only): 1 = no operand split (VALU) in the staging path
 #endif
@@ -289,15 +292,28 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       publish(r0, true, 0, first);
     }
     __syncthreads();
+    // Units are software-pipelined two deep: while unit u computes, unit u+1 is split and published (its loads were issued
+    // one unit earlier) and the loads of unit u+2 are issued.  publish(u+1) writes the ring slots / gy buffer that unit u-1
+    // read -- free since the barrier that ended unit u-1 -- and nothing that unit u reads, so inside a unit the two steps may
+    // run in EITHER order.  Measured at 96x112x64 (TFLOP/s, one-deep -> two-deep): 565->128 206 -> 214, 467->64 159 -> 171,
+    // 32->32 full resolution 139 -> 148.  Letting the two waves of a SIMD take OPPOSITE orders (WX3_STAGGER=1: one feeds the
+    // matrix pipe while the other splits and writes) is 1-4 % slower than all waves computing first, so it is off.
+    const bool pub_first = WX3_STAGGER && ((wave >> 2) & 1);
+    if (ya + R < yb) issue(b, c0, res, ya + R + 1, true, ya + R, true);
     int gbuf = 0;
     for (int y = ya; y < yb; y += R) {
-      const bool more = y + R < yb;
-      // next unit: x rows y+R+1 .. y+2R (rows up to y+R were staged already), gy rows y+R .. y+2R-1
-      if (more) issue(b, c0, res, y + R + 1, true, y + R, true);
+      const bool more = y + R < yb, more2 = y + 2 * R < yb;
+      if (pub_first) {
+        if (more) publish(y + R + 1, true, gbuf ^ 1, true);
+        if (more2) issue(b, c0, res, y + 2 * R + 1, true, y + 2 * R, true);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      compute(y, gbuf);
+      compute(y, gbuf);                                      // (one copy of the MFMA sequence: 144 accumulators stay in place)
       __builtin_amdgcn_sched_barrier(0);
-      if (more) publish(y + R + 1, true, gbuf ^ 1, true);
+      if (!pub_first) {
+        if (more) publish(y + R + 1, true, gbuf ^ 1, true);
+        if (more2) issue(b, c0, res, y + 2 * R + 1, true, y + 2 * R, true);
+      }
       __syncthreads();
       gbuf ^= 1;
     }
