@@ -27,6 +27,10 @@
 #define WX3_ABL 0      // ablation builds (timing only): 1 = no operand split (VALU) in the staging path
 #endif
 
+#ifdef WX3_TRACE
+static unsigned long long* g_wx3_dbg = nullptr;      // s_memtime trace (IRR_WX3_TRACE=1 builds, tools/wx3_trace.py)
+#endif
+
 namespace {
 
 constexpr uint32_t OOB = 0x80000000u;
@@ -43,6 +47,7 @@ struct WX3Args {
   int nstrips, nchunks_y, rows_per_chunk;      // column = (b, strip, row chunk)
   long ncols;
   int cols_per_block;
+  unsigned long long* dbg;       // WX3_TRACE builds only
   int ngx, ngy, ngz;             // logical grid: block columns x ci tiles x co tiles (launched as a 1-D grid, see the kernel)
 };
 
@@ -78,6 +83,13 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef WX3_TRACE
+  int ntr = 0;
+  unsigned long long* dbgp = a.dbg + (size_t)wave * 400;
+#define WTR(slot) do { if (blockIdx.x == 16 && lane == 0 && ntr < 400) { dbgp[ntr++] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); } } while (0)
+#else
+#define WTR(slot) do {} while (0)
+#endif
   const int wm = wave % MW, wn = (wave / MW) % NW, wk = wave / (MW * NW);
   const int j = lane & 31, g = lane >> 5;
   // Blocks with the same pixel columns (bx) and different channel tiles (by, bz) stage the same x / gy data: decode the
@@ -207,7 +219,8 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       const int slot = (y + row + dy - 1 + RING) % RING;
       const int xi = b_base + slot * XG + grp + MG + q * XPLANE;
       ob[sel] = xs[xi];
-      if (DIL <= 2) {
+      if (WX3_ABL == 2) {
+      } else if (DIL <= 2) {
         lb[sel][3] = xs[xi - 1][3];
         rb[sel][0] = xs[xi + 1][0];
       } else if (DIL == 4) {
@@ -237,7 +250,10 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       __builtin_amdgcn_sched_barrier(0);
       const u32x4 o = ob[cur];
       u32x4 fm, fp;                                        // dx = -DIL / +DIL fragments
-      if (DIL == 1) {
+      if (WX3_ABL == 2) {                                  // ablation (timing only): no shifted fragments
+        fm = o;
+        fp = o;
+      } else if (DIL == 1) {
         fm[0] = alignbit16(o[0], lb[cur][3]);
         fm[1] = alignbit16(o[1], o[0]);
         fm[2] = alignbit16(o[2], o[1]);
@@ -308,13 +324,18 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
         if (more2) issue(b, c0, res, y + 2 * R + 1, true, y + 2 * R, true);
       }
       __builtin_amdgcn_sched_barrier(0);
+      WTR(1);
       compute(y, gbuf);                                      // (one copy of the MFMA sequence: 144 accumulators stay in place)
       __builtin_amdgcn_sched_barrier(0);
+      WTR(2);
       if (!pub_first) {
         if (more) publish(y + R + 1, true, gbuf ^ 1, true);
+        WTR(3);
         if (more2) issue(b, c0, res, y + 2 * R + 1, true, y + 2 * R, true);
       }
+      WTR(4);
       __syncthreads();
+      WTR(5);
       gbuf ^= 1;
     }
   }
@@ -434,6 +455,12 @@ int launch_wx3(WX3Args a, hipStream_t st) {
   a.cols_per_block = (int)((a.ncols + want - 1) / want);
   if (a.cols_per_block < 1) a.cols_per_block = 1;
   a.ngx = irr_cdiv(a.ncols, a.cols_per_block); a.ngy = gy_; a.ngz = gz_;
+  a.dbg = nullptr;
+#ifdef WX3_TRACE
+  if (!g_wx3_dbg) { hipMalloc(&g_wx3_dbg, 16 * 400 * 8); }
+  hipMemsetAsync(g_wx3_dbg, 0, 16 * 400 * 8, st);
+  a.dbg = g_wx3_dbg;
+#endif
   a.n = (long)a.Cout * 9 * a.Cin;
   if ((long)a.ngx * a.n > ws_capacity(a.Cin, a.Cout)) return IRR_EINVAL;      // (cannot happen: gx <= want)
   hipLaunchKernelGGL((conv_wgrad_x3_kernel<MW, NW, KG, R, KW, DIL>), dim3((unsigned)a.ngx * gy_ * gz_), dim3(MW * NW * KW * 64),
@@ -505,6 +532,14 @@ static bool dil_ok(int Cout, int W, int dil) {
   if (dil == 16) return cot == 2 && kg != 1;               // (the (1,4) unit with two margin groups exceeds the LDS)
   return false;
 }
+
+#ifdef WX3_TRACE
+extern "C" int irr_wx3_trace_dump(unsigned long long* host) {
+  if (!g_wx3_dbg) return -1;
+  hipDeviceSynchronize();
+  return (int)hipMemcpy(host, g_wx3_dbg, 16 * 400 * 8, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" long irr_conv2d_wgrad_x3_ws_elems(int Cin, int Cout) { return (Cin > 0 && Cout > 0) ? ws_capacity(Cin, Cout) : 0; }
 
