@@ -80,6 +80,10 @@ class GraphedTrainStep:
     Data-parallel runs (world > 1) use the eager ``TrainStep``: the gradient all-reduce is not captured."""
 
     def __init__(self, step: TrainStep, warmup: int = 2):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise ValueError("GraphedTrainStep is single-process only: the data-parallel gradient all-reduce is not captured "
+                             "(use TrainStep with GradArena.sync)")
         if getattr(step.optimizer, "capturable", False) is not True:
             raise ValueError("GraphedTrainStep needs an optimizer whose step count lives on the device (FusedAdam(capturable=True))")
         self.step = step
