@@ -292,6 +292,9 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return out
 
 
+S2_GATHER_MAX_CIN = 4      # stride-2 data gradients with at most this many result channels use the gather kernel (A/B: 0)
+
+
 def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in_hw: Tuple[int, int],
                gx: Optional[torch.Tensor] = None, accumulate: bool = False,
                mask: Optional[torch.Tensor] = None, nmask: int = 0,
@@ -344,7 +347,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
             if variant is None:
                 variant = hip.lib().irr_conv2d_fwd_variant(B, cin, H, W, k)
             TIMER.wrap(variant, 2.0 * B * H * W * cout * cin * k * k, lambda: _call_conv(args), "dgrad")
-    elif stride == 2 and k == 3 and dil == 1 and H == 2 * oh and W == 2 * ow and cout >= 2:
+    elif stride == 2 and k == 3 and dil == 1 and H == 2 * oh and W == 2 * ow and cout >= 2 and cin > S2_GATHER_MAX_CIN:
         # transposed stride-2 conv == stride-1 conv (flipped weights) of the zero-interleaved gradient
         z = torch.zeros(B, cout, H, W, device=gy.device, dtype=torch.float32)
         z[:, :, ::2, ::2] = gy
@@ -352,6 +355,9 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         hip.call("irr_conv2d_fwd_f32", hip.ptr(z), hip.ptr(wp), None, None, hip.ptr(gx), B, cout, H, W, cin, H, W,
                  k, 1, 1, hip.bs(z), hip.bs(gx), 0, 0, 1.0, int(accumulate), *margs, hip.stream())
     else:
+        # (also the image gradient of the first pyramid conv, 16 -> 3 at stride 2: a 32-row MFMA tile over the zero-interleaved
+        # full-resolution gradient would be 90 % padding on top of 75 % zeros -- 1.9 ms; this gather kernel: see profiles)
+        LAUNCHES["dgrad_strided"] += 1
         tmp = gx if not accumulate else torch.empty(B, cin, H, W, device=gy.device, dtype=torch.float32)
         wc = weight.detach().contiguous()
         hip.call("irr_conv2d_dgrad_strided_f32", hip.ptr(gy), hip.ptr(wc), hip.ptr(tmp), B, cin, H, W, cout, oh, ow,

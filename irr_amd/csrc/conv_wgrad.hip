@@ -597,6 +597,57 @@ __global__ __launch_bounds__(256) void dgrad_strided_kernel(const float* __restr
   gx[(long)b * gx_bs + (long)ci * hw + p] = s;
 }
 
+// Stride-2, 3x3, padding-1 data gradient with a handful of RESULT channels (the image gradient of the first pyramid conv,
+// 16 -> 3: the reference asks for it, runtime.py:158-162 sets requires_grad on the inputs).  A thread owns one 2x2 block of
+// gx = the four parity classes of the transposed conv: it reads the 2x2 neighbourhood of gy once per output channel and uses
+// 1 + 2 + 2 + 4 = 9 taps per (co, ci) -- no zero-interleaved copy of gy, no padded MFMA tile (the gather kernel above: 1.04 ms,
+// zero-interleave + MFMA: 1.36 ms at 384x448x64).  Weights (Cout x CIN x 9) are staged in LDS and read wave-uniformly.
+template <int CIN>
+__global__ __launch_bounds__(256) void dgrad_s2k3_smallci_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                                float* __restrict__ gx, int H, int W, int Cout, int OH, int OW,
+                                                                long gy_bs, long gx_bs) {
+  extern __shared__ float wl[];                                  // [co][ci][9]
+  for (int i = threadIdx.x; i < Cout * CIN * 9; i += blockDim.x) wl[i] = w[i];
+  __syncthreads();
+  const int nbx = (W + 1) / 2, nby = (H + 1) / 2;
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (long)nbx * nby) return;
+  const int i = (int)(q / nbx), j = (int)(q - (long)i * nbx);
+  const int b = blockIdx.y;
+  const long ohw = (long)OH * OW, hw = (long)H * W;
+  const float* g = gy + (long)b * gy_bs;
+  const bool v00 = i < OH && j < OW, v01 = i < OH && j + 1 < OW, v10 = i + 1 < OH && j < OW, v11 = i + 1 < OH && j + 1 < OW;
+  const long o00 = (long)i * OW + j;
+  float a00[CIN], a01[CIN], a10[CIN], a11[CIN];                 // gx at (2i,2j), (2i,2j+1), (2i+1,2j), (2i+1,2j+1)
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) a00[c] = a01[c] = a10[c] = a11[c] = 0.f;
+  for (int co = 0; co < Cout; ++co) {
+    const float* gc = g + (long)co * ohw + o00;
+    const float g00 = v00 ? gc[0] : 0.f, g01 = v01 ? gc[1] : 0.f, g10 = v10 ? gc[OW] : 0.f, g11 = v11 ? gc[OW + 1] : 0.f;
+    const float* wc = wl + co * CIN * 9;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      const float* k = wc + c * 9;                               // k[ty*3 + tx]
+      a00[c] = fmaf(g00, k[4], a00[c]);
+      a01[c] = fmaf(g00, k[5], fmaf(g01, k[3], a01[c]));
+      a10[c] = fmaf(g00, k[7], fmaf(g10, k[1], a10[c]));
+      a11[c] = fmaf(g00, k[8], fmaf(g01, k[6], fmaf(g10, k[2], fmaf(g11, k[0], a11[c]))));
+    }
+  }
+  const int r0 = 2 * i, c0 = 2 * j;
+  float* o = gx + (long)b * gx_bs + (long)r0 * W + c0;
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) {
+    float* oc = o + (long)c * hw;
+    oc[0] = a00[c];
+    if (c0 + 1 < W) oc[1] = a01[c];
+    if (r0 + 1 < H) {
+      oc[W] = a10[c];
+      if (c0 + 1 < W) oc[W + 1] = a11[c];
+    }
+  }
+}
+
 }  // namespace
 
 // one batch slice through the kernel family (or, in plan-only mode, only its grid.x)
@@ -701,6 +752,18 @@ extern "C" int irr_conv2d_dgrad_strided_f32(const float* gy, const float* w, flo
                                             long gx_bs, void* stream) {
   if (!gy || !w || !gx || B <= 0 || Cin <= 0 || Cout <= 0 || B > 65535 || Cin > 65535) return IRR_EINVAL;
   if ((k != 1 && k != 3) || stride < 1 || dil < 1) return IRR_EINVAL;
+  if (k == 3 && stride == 2 && dil == 1 && Cin <= 4 && Cout <= 64 && OH == (H + 1) / 2 && OW == (W + 1) / 2) {
+    dim3 g2(irr_cdiv((long)((H + 1) / 2) * ((W + 1) / 2), 256), B);
+    const size_t lds = sizeof(float) * (size_t)Cout * Cin * 9;
+    switch (Cin) {
+      case 1: hipLaunchKernelGGL(dgrad_s2k3_smallci_kernel<1>, g2, dim3(256), lds, (hipStream_t)stream, gy, w, gx, H, W, Cout, OH, OW, gy_bs, gx_bs); break;
+      case 2: hipLaunchKernelGGL(dgrad_s2k3_smallci_kernel<2>, g2, dim3(256), lds, (hipStream_t)stream, gy, w, gx, H, W, Cout, OH, OW, gy_bs, gx_bs); break;
+      case 3: hipLaunchKernelGGL(dgrad_s2k3_smallci_kernel<3>, g2, dim3(256), lds, (hipStream_t)stream, gy, w, gx, H, W, Cout, OH, OW, gy_bs, gx_bs); break;
+      default: hipLaunchKernelGGL(dgrad_s2k3_smallci_kernel<4>, g2, dim3(256), lds, (hipStream_t)stream, gy, w, gx, H, W, Cout, OH, OW, gy_bs, gx_bs); break;
+    }
+    IRR_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid(irr_cdiv((long)H * W, 256), Cin, B);
   hipLaunchKernelGGL(dgrad_strided_kernel, grid, dim3(256), 0, (hipStream_t)stream, gy, w, gx, Cin, H, W, Cout, OH, OW,
                      k, stride, dil, ((k - 1) * dil) / 2, gy_bs, gx_bs);

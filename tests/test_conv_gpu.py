@@ -33,6 +33,9 @@ CASES = [
     (35, 96, 3, 1, 1, True, 1, 12, 58),
     (3, 16, 3, 2, 1, True, 3, 30, 44),       # first pyramid conv: three-input-channel weight-gradient kernel
     (3, 18, 3, 1, 1, False, 2, 17, 23),
+    (3, 16, 3, 2, 1, True, 2, 33, 47),       # odd sizes: the 2x2-block image-gradient kernel with ragged last row / column
+    (2, 20, 3, 2, 1, False, 1, 21, 20),
+    (4, 8, 3, 2, 1, True, 2, 16, 31),
 ]
 
 
