@@ -292,7 +292,8 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return out
 
 
-S2_GATHER_MAX_CIN = 4      # stride-2 data gradients with at most this many result channels use the gather kernel (A/B: 0)
+S2_GATHER_MAX_CIN = 96   # stride-2 3x3 data gradients with at most this many result channels use the 2x2-block kernel
+                         # (measured at the BASELINE batch: faster up to 128 -> 96 at 24x28, slower for 196 -> 128 at 12x14; A/B: 0)
 
 
 def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in_hw: Tuple[int, int],
@@ -355,8 +356,9 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         hip.call("irr_conv2d_fwd_f32", hip.ptr(z), hip.ptr(wp), None, None, hip.ptr(gx), B, cout, H, W, cin, H, W,
                  k, 1, 1, hip.bs(z), hip.bs(gx), 0, 0, 1.0, int(accumulate), *margs, hip.stream())
     else:
-        # (also the image gradient of the first pyramid conv, 16 -> 3 at stride 2: a 32-row MFMA tile over the zero-interleaved
-        # full-resolution gradient would be 90 % padding on top of 75 % zeros -- 1.9 ms; this gather kernel: see profiles)
+        # stride-2 3x3 layers (the feature pyramid, incl. the image gradient of its first conv): a 2x2-block kernel over the four
+        # parity classes of the transposed conv; the MFMA route above over a zero-interleaved copy of gy spends 75 % of its
+        # work on zeros (tools/s2_dgrad_bench.py)
         LAUNCHES["dgrad_strided"] += 1
         tmp = gx if not accumulate else torch.empty(B, cin, H, W, device=gy.device, dtype=torch.float32)
         wc = weight.detach().contiguous()

@@ -605,10 +605,17 @@ __global__ __launch_bounds__(256) void dgrad_strided_kernel(const float* __restr
 template <int CIN>
 __global__ __launch_bounds__(256) void dgrad_s2k3_smallci_kernel(const float* __restrict__ gy, const float* __restrict__ w,
                                                                 float* __restrict__ gx, int H, int W, int Cout, int OH, int OW,
-                                                                long gy_bs, long gx_bs) {
-  extern __shared__ float wl[];                                  // [co][ci][9]
-  for (int i = threadIdx.x; i < Cout * CIN * 9; i += blockDim.x) wl[i] = w[i];
+                                                                long gy_bs, long gx_bs, int Cin_total) {
+  // blockIdx.z = group of CIN result channels (the other stride-2 layers of the pyramid: 16 ... 128 result channels in groups
+  // of four -- 21 GFLOP of useful work per step, which the zero-interleaved MFMA route spent 1.4 ms on)
+  extern __shared__ float wl[];                                  // [co][ci][9] of this block's channel group
+  const int ci0 = blockIdx.z * CIN;
+  for (int i = threadIdx.x; i < Cout * CIN * 9; i += blockDim.x) {
+    const int co = i / (CIN * 9), r = i - co * (CIN * 9), c = r / 9;
+    wl[i] = ci0 + c < Cin_total ? w[((long)co * Cin_total + ci0) * 9 + r] : 0.f;
+  }
   __syncthreads();
+  gx += (long)ci0 * H * W;
   const int nbx = (W + 1) / 2, nby = (H + 1) / 2;
   const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= (long)nbx * nby) return;
@@ -638,6 +645,7 @@ __global__ __launch_bounds__(256) void dgrad_s2k3_smallci_kernel(const float* __
   float* o = gx + (long)b * gx_bs + (long)r0 * W + c0;
 #pragma unroll
   for (int c = 0; c < CIN; ++c) {
+    if (ci0 + c >= Cin_total) break;
     float* oc = o + (long)c * hw;
     oc[0] = a00[c];
     if (c0 + 1 < W) oc[1] = a01[c];
@@ -752,14 +760,20 @@ extern "C" int irr_conv2d_dgrad_strided_f32(const float* gy, const float* w, flo
                                             long gx_bs, void* stream) {
   if (!gy || !w || !gx || B <= 0 || Cin <= 0 || Cout <= 0 || B > 65535 || Cin > 65535) return IRR_EINVAL;
   if ((k != 1 && k != 3) || stride < 1 || dil < 1) return IRR_EINVAL;
-  if (k == 3 && stride == 2 && dil == 1 && Cin <= 4 && Cout <= 64 && OH == (H + 1) / 2 && OW == (W + 1) / 2) {
-    dim3 g2(irr_cdiv((long)((H + 1) / 2) * ((W + 1) / 2), 256), B);
-    const size_t lds = sizeof(float) * (size_t)Cout * Cin * 9;
-    switch (Cin) {
-      case 1: hipLaunchKernelGGL(dgrad_s2k3_smallci_kernel<1>, g2, dim3(256), lds, (hipStream_t)stream, gy, w, gx, H, W, Cout, OH, OW, gy_bs, gx_bs); break;
-      case 2: hipLaunchKernelGGL(dgrad_s2k3_smallci_kernel<2>, g2, dim3(256), lds, (hipStream_t)stream, gy, w, gx, H, W, Cout, OH, OW, gy_bs, gx_bs); break;
-      case 3: hipLaunchKernelGGL(dgrad_s2k3_smallci_kernel<3>, g2, dim3(256), lds, (hipStream_t)stream, gy, w, gx, H, W, Cout, OH, OW, gy_bs, gx_bs); break;
-      default: hipLaunchKernelGGL(dgrad_s2k3_smallci_kernel<4>, g2, dim3(256), lds, (hipStream_t)stream, gy, w, gx, H, W, Cout, OH, OW, gy_bs, gx_bs); break;
+  if (k == 3 && stride == 2 && dil == 1 && Cout <= 256 && OH == (H + 1) / 2 && OW == (W + 1) / 2 && Cin <= 65535 * 4) {
+    const long nblk = irr_cdiv((long)((H + 1) / 2) * ((W + 1) / 2), 256);
+    if (Cin <= 3) {
+      dim3 g2((unsigned)nblk, B, 1);
+      const size_t lds = sizeof(float) * (size_t)Cout * Cin * 9;
+      switch (Cin) {
+        case 1: hipLaunchKernelGGL(dgrad_s2k3_smallci_kernel<1>, g2, dim3(256), lds, (hipStream_t)stream, gy, w, gx, H, W, Cout, OH, OW, gy_bs, gx_bs, Cin); break;
+        case 2: hipLaunchKernelGGL(dgrad_s2k3_smallci_kernel<2>, g2, dim3(256), lds, (hipStream_t)stream, gy, w, gx, H, W, Cout, OH, OW, gy_bs, gx_bs, Cin); break;
+        default: hipLaunchKernelGGL(dgrad_s2k3_smallci_kernel<3>, g2, dim3(256), lds, (hipStream_t)stream, gy, w, gx, H, W, Cout, OH, OW, gy_bs, gx_bs, Cin); break;
+      }
+    } else {
+      dim3 g2((unsigned)nblk, B, irr_cdiv(Cin, 4));
+      hipLaunchKernelGGL(dgrad_s2k3_smallci_kernel<4>, g2, dim3(256), sizeof(float) * (size_t)Cout * 4 * 9, (hipStream_t)stream, gy, w, gx,
+                         H, W, Cout, OH, OW, gy_bs, gx_bs, Cin);
     }
     IRR_LAUNCH_CHECK();
     return 0;

@@ -36,6 +36,8 @@ CASES = [
     (3, 16, 3, 2, 1, True, 2, 33, 47),       # odd sizes: the 2x2-block image-gradient kernel with ragged last row / column
     (2, 20, 3, 2, 1, False, 1, 21, 20),
     (4, 8, 3, 2, 1, True, 2, 16, 31),
+    (18, 40, 3, 2, 1, True, 2, 20, 26),      # stride-2 data gradient in channel groups of four (ragged last group)
+    (64, 96, 3, 2, 1, True, 1, 12, 14),
 ]
 
 
