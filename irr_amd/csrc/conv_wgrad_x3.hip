@@ -23,6 +23,9 @@
 #ifndef WX3_STAGGER
 #define WX3_STAGGER 0  // 1 (A/B): the two waves of a SIMD publish / compute in opposite orders (see the unit loop); 0: all compute first
 #endif
+#ifndef WX3_STAGE_OLD
+#define WX3_STAGE_OLD 1  // 1: in eight-wave blocks only waves 0..3 stage (see SWAVES); 0 (A/B): all waves stage
+#endif
 #ifndef WX3_ABL
 #define WX3_ABL 0      // ablation builds (timing only): 1 = no operand split (VALU) in the staging path
 #endif
@@ -71,8 +74,14 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   constexpr int GPLANE = 32 * MW * GPITCH;
   constexpr int XUNITS = R * XG * 32 * NW;                 // (channel, row, group) staging units per step
   constexpr int GUNITS = R * KG * 32 * MW;
-  constexpr int XR = (XUNITS + NTHR - 1) / NTHR;
-  constexpr int GR = (GUNITS + NTHR - 1) / NTHR;
+  // Staging waves: with two waves per SIMD the OLDER wave of a SIMD (0..3) runs its MFMAs first and then waits at the barrier
+  // while the younger one (4..7), starved until then, computes (tools/wx3_trace.py) -- so the older waves do ALL the staging
+  // (issue + split + publish) in that wait and the younger ones go straight from their MFMAs to the barrier.
+  // (only where the doubled staging registers fit: at most four 32-B units per staging thread)
+  constexpr int SWAVES = (WX3_STAGE_OLD && MW * NW * KW == 8 && (XUNITS + 255) / 256 + (GUNITS + 255) / 256 <= 4) ? 4 : MW * NW * KW;
+  constexpr int SNTHR = SWAVES * 64;
+  constexpr int XR = (XUNITS + SNTHR - 1) / SNTHR;
+  constexpr int GR = (GUNITS + SNTHR - 1) / SNTHR;
   constexpr int NK = R * KG / 2;                           // MFMA k-steps (16 pixels = two groups) per unit
   static_assert((R * KG) % 2 == 0, "a unit must hold an even number of 8-pixel groups");
   static_assert(NK % KW == 0, "the k-steps of a unit must divide evenly among the wave groups");
@@ -111,18 +120,18 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   int xu_ci[XR], xu_rr[XR], xu_grp[XR];
 #pragma unroll
   for (int r = 0; r < XR; ++r) {
-    const int u = r * NTHR + tid;
+    const int u = r * SNTHR + tid;
     xu_grp[r] = u % XG;
     xu_rr[r] = (u / XG) % R;
-    xu_ci[r] = u < XUNITS ? u / (XG * R) : -1;
+    xu_ci[r] = (u < XUNITS && tid < SNTHR) ? u / (XG * R) : -1;
   }
   int gu_co[GR], gu_rr[GR], gu_grp[GR];
 #pragma unroll
   for (int r = 0; r < GR; ++r) {
-    const int u = r * NTHR + tid;
+    const int u = r * SNTHR + tid;
     gu_grp[r] = u % KG;
     gu_rr[r] = (u / KG) % R;
-    gu_co[r] = u < GUNITS ? u / (KG * R) : -1;
+    gu_co[r] = (u < GUNITS && tid < SNTHR) ? u / (KG * R) : -1;
   }
   float bsum[GR];
 #pragma unroll
@@ -138,7 +147,9 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
 
   // issue the global loads of x rows [row0, row0+R) and (optionally) gy rows [grow0, grow0+R) of column (b, strip c0)
   // (row0 / grow0 count rows of the residue walk: image row = res + DIL * k)
+  const bool stager = wave < SWAVES;
   auto issue = [&](int b, int c0, int res, int row0, bool with_x, int grow0, bool with_g) {
+    if (!stager) return;
 #pragma unroll
     for (int r = 0; r < XR; ++r) {
       const int kk = row0 + xu_rr[r];
@@ -164,6 +175,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   };
   // split the loaded units and publish them: x rows [row0, row0+R) into their ring slots, gy rows into unit buffer gbuf
   auto publish = [&](int row0, bool with_x, int gbuf, bool with_g) {
+    if (!stager) return;
     if (with_x) {
 #pragma unroll
       for (int r = 0; r < XR; ++r) {
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       constexpr int PER = R * KG;
 #pragma unroll
       for (int off = 1; off < PER; off <<= 1) s += __shfl_xor(s, off, 64);
-      const int u = r * NTHR + tid;
+      const int u = r * SNTHR + tid;
       if (gu_co[r] >= 0 && (u % PER) == 0 && co0 + gu_co[r] < a.Cout) unsafeAtomicAdd(a.gbias + co0 + gu_co[r], a.alpha * s);
     }
   }
