@@ -45,6 +45,8 @@ if os.environ.get("IRR_X3_ABL"):
     COMMON = COMMON + ["-DX3_ABL=" + os.environ["IRR_X3_ABL"]]
 if os.environ.get("IRR_WX3_STAGE_OLD"):
     COMMON = COMMON + ["-DWX3_STAGE_OLD=" + os.environ["IRR_WX3_STAGE_OLD"]]
+if os.environ.get("IRR_X3S_PRODUCERS_OLD"):
+    COMMON = COMMON + ["-DX3S_PRODUCERS_OLD=" + os.environ["IRR_X3S_PRODUCERS_OLD"]]
 if os.environ.get("IRR_WX3_TRACE"):
     COMMON = COMMON + ["-DWX3_TRACE=1"]
 if os.environ.get("IRR_WX3_STAGGER"):

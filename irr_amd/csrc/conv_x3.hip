@@ -328,6 +328,9 @@ struct X3SArgs {
 #define TR(slot) do {} while (0)
 #endif
 
+#ifndef X3S_PRODUCERS_OLD
+#define X3S_PRODUCERS_OLD 1   // 1: waves 0..3 produce, 4..7 run the MFMAs; 0 (A/B): the other way round
+#endif
 // EPI: what the epilogue has to read besides the accumulators -- 0: nothing (bias, LeakyReLU, alpha), 1: + a residual operand,
 // 2: everything (residual, accumulate-into-output, LeakyReLU'-mask).  The kernel is bound by the producer waves' VALU issue
 // slots (operand split + epilogue), so the plain layers do not pay for 24 operand loads and 5 unused VALU per output.
@@ -359,9 +362,12 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
   for (int u = tid; u < WUNITS; u += 512) wl[u] = a.wq[((long)(u >> 6) * a.wCoT + a.wcot) * 64 + (u & 63)];
   __syncthreads();
 
-  if (wave >= 4) {
+  // Roles by wave AGE: the instruction arbiter of a SIMD prefers its older wave, and a wave that streams MFMAs leaves the
+  // other one almost no issue slots (tools/wx3_trace.py shows the same in the weight-gradient kernel).  The producers are the
+  // bottleneck of a tile and the MFMA waves have slack at the barriers, so the producers take the OLDER slots (waves 0..3).
+  if (X3S_PRODUCERS_OLD ? wave < 4 : wave >= 4) {
     // ================= producers (+ epilogue) =================
-    const int ptid = tid - 256;
+    const int ptid = X3S_PRODUCERS_OLD ? tid : tid - 256;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)0x80000000u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, (int)0x80000000u, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, (short)0, (int)0x80000000u, 0x00020000);
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
   }
 
   // ================= MFMA waves: wave = pixel group (64 pixels = 2 rows of the tile), one 32-channel co-tile =================
-  const int pg = wave;
+  const int pg = X3S_PRODUCERS_OLD ? wave - 4 : wave;
   const int j = lane & 31, g = lane >> 5;
   const int row0 = pg * 2;                                 // sub-tile s = tile row row0 + s, column j
   const int xidx0 = g * PLANE_PIX + row0 * LW + j;
