@@ -60,6 +60,11 @@ class _SplitHalves(torch.autograd.Function):
     def backward(ctx, g1, g2):
         if g1 is None and g2 is None:
             return None
+        if g1 is not None and g2 is not None and g1._base is not None and g1._base is g2._base:
+            base = g1._base                               # the two halves of one buffer (losses._paired_grads): no copy
+            if base.is_contiguous() and base.shape == (2 * ctx.half[0],) + ctx.half[1:] and g1.data_ptr() == base.data_ptr() \
+                    and g2.data_ptr() == base.data_ptr() + g1.numel() * g1.element_size() and g1.is_contiguous() and g2.is_contiguous():
+                return base
         ref = g1 if g1 is not None else g2
         z = None
         if g1 is None or g2 is None:

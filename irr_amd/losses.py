@@ -117,6 +117,24 @@ class _Term(ctypes.Structure):
 MAX_TERMS = 32          # IRR_LOSS_MAX_TERMS
 
 
+def _paired_grads(preds):
+    """gradient buffers for the terms' predictions.  The loss receives the two flow directions of an output as consecutive
+    terms, both halves of one 2B-sample tensor of the model (irr_pwc._SplitHalves): their gradients are allocated as the two
+    halves of ONE buffer, so the split's backward hands that buffer on instead of concatenating two tensors."""
+    grads = []
+    i = 0
+    while i < len(preds):
+        p = preds[i]
+        if i + 1 < len(preds) and preds[i + 1].shape == p.shape:
+            buf = torch.empty((2 * p.shape[0],) + tuple(p.shape[1:]), device=p.device, dtype=torch.float32)
+            grads += [buf[:p.shape[0]], buf[p.shape[0]:]]
+            i += 2
+        else:
+            grads.append(torch.empty(p.shape, device=p.device, dtype=torch.float32))
+            i += 1
+    return grads
+
+
 def _term_table(preds, tgts, weights, grads=None, aux=None):
     n = len(preds)
     arr = (_Term * n)()
@@ -158,7 +176,7 @@ class _MultiEpe(hip.Function):
         n = ctx.n
         preds, tgts = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
         g = g.contiguous()
-        grads = [torch.empty(p.shape, device=p.device, dtype=torch.float32) for p in preds]
+        grads = _paired_grads(preds)
         for i0 in range(0, n, MAX_TERMS):
             sl = slice(i0, i0 + MAX_TERMS)
             arr = _term_table(preds[sl], tgts[sl], ctx.weights[sl], grads=grads[sl])
@@ -195,7 +213,7 @@ class _MultiF1Bal(hip.Function):
         sums = ctx.saved_tensors[0]
         preds, tgts = ctx.saved_tensors[1:1 + n], ctx.saved_tensors[1 + n:]
         g = g.contiguous()
-        grads = [torch.empty(p.shape, device=p.device, dtype=torch.float32) for p in preds]
+        grads = _paired_grads(preds)
         for i0 in range(0, n, MAX_TERMS):
             sl = slice(i0, i0 + MAX_TERMS)
             arr = _term_table(preds[sl], tgts[sl], ctx.scaled[sl], grads=grads[sl],
