@@ -580,14 +580,23 @@ class _DenseEstimatorFn(hip.Function):
     GROW = (128, 128, 96, 64, 32)
 
     @staticmethod
-    def forward(ctx, x, base, *wb):
+    def forward(ctx, nparts, base, *args):
+        # x arrives as `nparts` tensors (IRR-PWC: cost volume, projected features, flow / occlusion): they are copied straight
+        # into their channel slices of the buffer, and backward returns the slices of the gradient buffer -- no torch.cat of the
+        # decoder input in forward, no split of its gradient in backward
+        parts, wb = args[:nparts], args[nparts:]
         ws, bs = wb[0::2], wb[1::2]
-        B, cin0, H, W = x.shape
+        B, _, H, W = parts[0].shape
+        widths = [int(p_.shape[1]) for p_ in parts]
+        cin0 = sum(widths)
         E = ws[5].shape[0]
         ctot = 448 + cin0
         has_base = base is not None
-        buf = torch.empty(B, ctot + (E if has_base else 0), H, W, device=x.device, dtype=torch.float32)
-        buf[:, 448:ctot].copy_(x)
+        buf = torch.empty(B, ctot + (E if has_base else 0), H, W, device=parts[0].device, dtype=torch.float32)
+        c0 = 448
+        for p_, wd in zip(parts, widths):
+            buf[:, c0:c0 + wd].copy_(p_)
+            c0 += wd
         off = 448
         for i in range(5):
             co = _DenseEstimatorFn.GROW[i]
@@ -600,7 +609,7 @@ class _DenseEstimatorFn(hip.Function):
         else:
             out = conv_forward(buf[:, :ctot], ws[5], bs[5], 1, 1, False)
         ctx.save_for_backward(buf, *ws)
-        ctx.cfg = (cin0, E, has_base)
+        ctx.cfg = (cin0, E, has_base, tuple(widths))
         ctx.wobjs, ctx.bobjs = ws, bs
         return buf, out
 
@@ -608,7 +617,9 @@ class _DenseEstimatorFn(hip.Function):
     def backward(ctx, g_buf, g_out):
         buf = ctx.saved_tensors[0]
         ws = ctx.saved_tensors[1:]
-        cin0, E, has_base = ctx.cfg
+        cin0, E, has_base, widths = ctx.cfg
+        nparts = len(widths)
+        need_x = any(ctx.needs_input_grad[2:2 + nparts])
         B, _, H, W = buf.shape
         ctot = 448 + cin0
         dev = buf.device
@@ -643,7 +654,7 @@ class _DenseEstimatorFn(hip.Function):
         bounds = [(32, 96), (96, 192), (192, 320), (320, 448), (448, ctot)]
         for k_, (t0, t1) in enumerate(bounds):
             last = k_ == 4
-            if last and not ctx.needs_input_grad[0]:
+            if last and not need_x:
                 break
             margs = (None if last else hip.ptr(buf[:, t0:t1]), 0 if last else hip.bs(buf), 0 if last else t1 - t0)
             LAUNCHES["dense_column_x3" if use_x3[k_] else "dense_column_f32"] += 1
@@ -662,11 +673,14 @@ class _DenseEstimatorFn(hip.Function):
             if not last:                                   # G[:, t0:t1] is now the pre-activation gradient of conv(4-k_)
                 i = 3 - k_
                 grads_w[i], grads_b[i] = wgrad_param(buf[:, t1:ctot], G[:, t0:t1], ctx.wobjs[i], ctx.bobjs[i], 1, 1)
-        gx = G[:, 448:ctot] if ctx.needs_input_grad[0] else None
         # g_est is still being read by the asynchronous wgrad lane (conv_last): autograd gets its own copy, because
         # the engine may accumulate the other gradients of `base` into the returned tensor IN PLACE
         gbase = g_est.clone() if (has_base and ctx.needs_input_grad[1]) else None
-        out = [gx, gbase]
+        out = [None, gbase]
+        c0 = 448
+        for i, wd in enumerate(widths):                       # per-part gradients = channel slices of G (plane-dense views)
+            out.append(G[:, c0:c0 + wd] if (need_x and ctx.needs_input_grad[2 + i]) else None)
+            c0 += wd
         for i in range(6):
             out += [grads_w[i], grads_b[i]]
         return tuple(out)
@@ -733,10 +747,12 @@ def _dense_column_packs(ws5, cin0: int, use_x3=(False,) * 5):
 
 
 def dense_estimator(x, base, weights_and_biases):
-    """(buf, out) -- see _DenseEstimatorFn.  weights_and_biases = [w1, b1, ..., w5, b5, w_last, b_last]."""
-    if not x.is_cuda:
+    """(buf, out) -- see _DenseEstimatorFn.  x: the estimator's input, or a sequence of tensors whose channel concatenation
+    it is.  weights_and_biases = [w1, b1, ..., w5, b5, w_last, b_last]."""
+    parts = tuple(x) if isinstance(x, (list, tuple)) else (x,)
+    if not all(p_.is_cuda for p_ in parts):
         raise RuntimeError("irr_amd conv runs on the HIP device only (no CPU fallback)")
-    return _DenseEstimatorFn.apply(x, base, *weights_and_biases)
+    return _DenseEstimatorFn.apply(len(parts), base, *parts, *weights_and_biases)
 
 
 # ----------------------------------------------------------------------------------------------

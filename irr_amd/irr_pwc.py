@@ -184,12 +184,12 @@ class PWCNet(nn.Module):
                 flow = flow * t_loc
 
                 # estimator + "est = flow + res" + cat([x_intm, est]) in one cat-free node (conv.dense_estimator)
-                ctx_in, flow_est = self.flow_estimators.forward_residual(torch.cat([corr, x_1by1, flow], dim=1), flow)
+                ctx_in, flow_est = self.flow_estimators.forward_residual((corr, x_1by1, flow), flow)
                 flow_cont = self.context_networks(ctx_in, res=flow_est)
 
                 # The occlusion decoder + context network are independent of the flow branch until refine_occ: with
                 # IRR_BRANCH_STREAMS=1 they run on a second HIP stream (autograd replays their backward there too).
-                occ_in = torch.cat([corr, x_1by1, occ], dim=1)
+                occ_in = (corr, x_1by1, occ)
                 side = self._branch_stream(dev, l)
                 if side is not None:
                     main = torch.cuda.current_stream()
@@ -197,7 +197,8 @@ class PWCNet(nn.Module):
                     with torch.cuda.stream(side):
                         ctx_in_o, occ_est = self.occ_estimators.forward_residual(occ_in, occ)
                         occ_cont = self.occ_context_networks(ctx_in_o, res=occ_est)
-                    occ_in.record_stream(side)
+                    for t_ in occ_in:
+                        t_.record_stream(side)
                     occ.record_stream(side)
                     pending_join = (main, side, occ_cont)
                 else:
