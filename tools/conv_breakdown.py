@@ -56,7 +56,7 @@ for key, fl, s, e in recs:
 tot = sum(v[2] for v in agg.values())
 print(f"total conv time {tot:.1f} ms, {sum(v[1] for v in agg.values())/1e12:.2f} TFLOP")
 print(f"{'kind':10s} {'cin':>4s} {'cout':>4s} {'oh':>4s} {'ow':>4s} k dil {'n':>3s} {'ms':>8s} {'TF':>7s} {'%':>5s}")
-for key, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:45]:
+for key, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:70]:
     print(f"{key[0]:10s} {key[1]:4d} {key[2]:4d} {key[3]:4d} {key[4]:4d} {key[5]} {key[6]:3d} {v[0]:3d} {v[2]:8.2f} {v[1]/v[2]/1e9:7.1f} {100*v[2]/tot:5.1f}")
 # by level
 lev = collections.OrderedDict()
@@ -65,3 +65,10 @@ for key, v in agg.items():
 print("by level:")
 for k, v in sorted(lev.items(), key=lambda kv: -kv[1][1]):
     print(f"  {k[0]:10s} {k[1]:4d}x{k[2]:<4d} {v[1]:8.2f} ms {v[0]/v[1]/1e9:7.1f} TF")
+
+lev = collections.OrderedDict()
+for key, v in agg.items():
+    a = lev.setdefault((key[3], key[0]), [0, 0.0, 0.0]); a[0] += v[0]; a[1] += v[1]; a[2] += v[2]
+print("per level (output height) and kind:")
+for (oh, kind), v in sorted(lev.items(), key=lambda kv: (-kv[0][0], kv[0][1])):
+    print(f"  oh {oh:4d} {kind:10s} {v[0]:4d} launches {v[2]:8.2f} ms {v[1]/v[2]/1e9:7.1f} TF")

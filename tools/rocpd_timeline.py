@@ -1,6 +1,6 @@
 """Occupancy timeline of the LAST train step in a rocprofv3 --kernel-trace rocpd database: how much of the step has
 no kernel running, exactly one running with a grid that cannot fill 256 CUs, or two lanes running.
-usage: python tools/rocpd_timeline.py <results.db> [n_steps_in_run]"""
+usage: python tools/rocpd_timeline.py <results.db> [--dump FROM_MS TO_MS]"""
 import sqlite3
 import sys
 
@@ -90,6 +90,19 @@ def main():
           f"one kernel >= 256 blocks {single_big / 1e6:.2f} ms, >= 2 kernels {multi / 1e6:.2f} ms  ({len(rows)} dispatches)")
     for k, v in sorted(small_by.items(), key=lambda kv: -kv[1])[:45]:
         print(f"   {v / 1e6:7.2f} ms  {k}")
+    if "--dump" in sys.argv:         # --dump FROM_MS TO_MS (relative to the step's end when negative): every dispatch in the window
+        i = sys.argv.index("--dump")
+        lo, hi = float(sys.argv[i + 1]) * 1e6, float(sys.argv[i + 2]) * 1e6
+        lo = t1 + lo if lo < 0 else t0 + lo
+        hi = t1 + hi if hi <= 0 else t0 + hi
+        print("dispatches in the window (start offset us, duration us, gap to the previous end on the same stream us, stream, blocks, kernel):")
+        prev_end = {}
+        for name, s_, e_, a_, b_, c_, x_, y_, z_, st in rows:
+            blocks = (a_ // max(x_, 1)) * (b_ // max(y_, 1)) * (c_ // max(z_, 1)) if a_ >= x_ else a_ * b_ * c_
+            gap = (s_ - prev_end[st]) / 1e3 if st in prev_end else 0.0
+            prev_end[st] = e_
+            if s_ >= lo and s_ <= hi:
+                print(f"  {(s_ - t0) / 1e3:10.1f} {(e_ - s_) / 1e3:8.1f} {gap:8.1f}  s{st} {blocks:6d}  {short(name)[:80]}")
 
 
 if __name__ == "__main__":
