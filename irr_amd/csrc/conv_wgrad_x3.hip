@@ -300,14 +300,29 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   // ---- walk this block's columns ----
   const long col_begin = (long)bx * a.cols_per_block;
   const long col_end = min(a.ncols, col_begin + a.cols_per_block);
-  for (long col = col_begin; col < col_end; ++col) {
-    long t = col;
-    const int chunk = (int)(t % a.nchunks_y);
+  // column = (b, strip, res, chunk) in mixed radix, chunk fastest: decoded once, then stepped (the 64-bit divisions of a
+  // per-column decode are ~2k cycles of scalar work on every wave)
+  int chunk, res, strip, b;
+  {
+    long t = col_begin;
+    chunk = (int)(t % a.nchunks_y);
     t /= a.nchunks_y;
-    const int res = (int)(t % DIL);
+    res = (int)(t % DIL);
     t /= DIL;
-    const int strip = (int)(t % a.nstrips);
-    const int b = (int)(t / a.nstrips);
+    strip = (int)(t % a.nstrips);
+    b = (int)(t / a.nstrips);
+  }
+  for (long col = col_begin; col < col_end; ++col) {
+    if (col != col_begin && ++chunk == a.nchunks_y) {
+      chunk = 0;
+      if (++res == DIL) {
+        res = 0;
+        if (++strip == a.nstrips) {
+          strip = 0;
+          ++b;
+        }
+      }
+    }
     const int c0 = strip * KG * 8;
     const int hk = (a.H - res + DIL - 1) / DIL;              // rows of this residue walk
     const int ya = chunk * a.rows_per_chunk;

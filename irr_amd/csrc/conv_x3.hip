@@ -382,13 +382,28 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
     const uint32_t hw4 = (uint32_t)(hw * 4);
     const uint32_t c1off = (uint32_t)(a.Cin - 16) * hw4;   // second chunk = channels [Cin-16, Cin) (duplicates: zero weights)
     f32x4 raw[2][8];
-    auto issue_chunk = [&](long t, int c) {
-      const int tx = (int)(t % a.tiles_x);
-      const long t2 = t / a.tiles_x;
-      const int ty = (int)(t2 % a.tiles_y);
-      const int b = (int)(t2 / a.tiles_y);
+    // Tile coordinates are stepped, not decoded: three 64-bit divisions per call (twice per tile here, once more in the
+    // epilogue) were 12 % of the producers' critical path.  t advances by gridDim.x = (sb, sy, sx) in mixed radix.
+    struct TileAt { int b, ty, tx; };
+    const int step_x = (int)(t_step % a.tiles_x), step_y = (int)((t_step / a.tiles_x) % a.tiles_y),
+              step_b = (int)(t_step / ((long)a.tiles_x * a.tiles_y));
+    auto advance = [&](TileAt& c) {
+      c.tx += step_x;
+      const int cx = c.tx >= a.tiles_x;
+      c.tx -= cx ? a.tiles_x : 0;
+      c.ty += step_y + cx;
+      const int cy = c.ty >= a.tiles_y;
+      c.ty -= cy ? a.tiles_y : 0;
+      c.b += step_b + cy;
+    };
+    // (`valid` = false: the same eight loads with the out-of-range marker.  The loop body below has NO conditional memory
+    // instruction: the compiler then counts the operations between a load and its use exactly and waits with vmcnt(16+)
+    // instead of vmcnt(0) -- with branches around them it drained the whole queue, the stores just issued and the next tile's
+    // prefetch included, before every split.)
+    auto issue_chunk = [&](const TileAt& at, int c, bool valid) {
+      const int tx = X3_ABL == 11 ? 1 : at.tx, ty = X3_ABL == 11 ? 1 : at.ty, b = X3_ABL == 11 ? 0 : at.b;   // ablation 11: every block re-reads one tile (cache hits), no stores
       const int iy = ty * 8 - 1 + su_ly, ix = tx * 32 - 4 + su_q * 4;
-      const bool ok = su_act && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const bool ok = valid && su_act && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && X3_ABL != 10;     // ablation 10: no global loads, no stores
       const uint32_t vo = ok ? (uint32_t)(((long)b * a.x_bs + (long)su_gg * 8 * hw + (long)iy * a.W + ix) * 4) : OOB;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -420,13 +435,10 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
     for (int e = 0; e < 8; ++e) bias_r[e] = (a.bias && eq_c8 * 8 + e < a.Cout) ? a.bias[eq_c8 * 8 + e] : 0.f;
     f32x4 erv[8], edv[8], emv[8];
     uint32_t evd = OOB;
-    auto epilogue_loads = [&](long t) {
-      const int tx = (int)(t % a.tiles_x);
-      const long t2 = t / a.tiles_x;
-      const int ty = (int)(t2 % a.tiles_y);
-      const int b = (int)(t2 / a.tiles_y);
+    auto epilogue_loads = [&](const TileAt& at, bool valid) {
+      const int tx = at.tx, ty = at.ty, b = at.b;
       const int oy = ty * 8 + eq_row, ox = tx * 32 + eq_q * 4;
-      const bool pv = oy < a.H && ox < a.W;
+      const bool pv = valid && oy < a.H && ox < a.W;
       const long pofs = (long)oy * a.W + ox + (long)eq_c8 * 8 * hw;
       const uint32_t vr = (EPI >= 1 && pv && a.res) ? (uint32_t)(((long)b * a.res_bs + pofs) * 4) : OOB;
       evd = pv ? (uint32_t)(((long)b * a.y_bs + pofs) * 4) : OOB;
@@ -467,52 +479,59 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
           }
           o[px] = v;
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, (int)((co < a.Cout && X3_ABL != 7) ? evd : OOB),
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, (int)((co < a.Cout && X3_ABL != 7 && X3_ABL != 10 && X3_ABL != 11) ? evd : OOB),
                                                (int)((uint32_t)e * hw4), 0);
       }
     };
-    if (t_begin < a.ntiles) {
-      issue_chunk(t_begin, 0);
-      issue_chunk(t_begin, 1);
+    TileAt at_prev = {0, 0, 0}, at_cur, at_next;            // tiles t - t_step (epilogue), t, t + t_step (loads in flight)
+    at_cur.tx = (int)(t_begin % a.tiles_x);
+    at_cur.ty = (int)((t_begin / a.tiles_x) % a.tiles_y);
+    at_cur.b = (int)(t_begin / ((long)a.tiles_x * a.tiles_y));
+    at_next = at_cur;
+    advance(at_next);
+    issue_chunk(at_cur, 0, t_begin < a.ntiles);
+    issue_chunk(at_cur, 1, t_begin < a.ntiles);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      eacc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      erv[e] = edv[e] = emv[e] = eacc[e];
     }
     // The two phases of a tile are balanced against the MFMA waves' two chunk phases: the epilogue of tile n-1 is
     // split into operand loads + accumulator copy (phase of chunk 0) and arithmetic + stores (phase of chunk 1).
+    // Nothing in the body is conditional: without a finished tile the epilogue stores go to the out-of-range marker (evd).
     long tprev = -1;
-    bool pending = false;
     for (long t = t_begin; t < a.ntiles; t += t_step) {
+      const bool more = t + t_step < a.ntiles;
       // phase after barrier #(2n-1): the MFMA waves are on (n-1, chunk 1); slot 0 is free
       TR(1);
-      if (pending) epilogue_finish();                       // tile n-2: operands and accumulators are in registers
-      pending = false;
+      epilogue_finish();                                    // tile n-2: operands and accumulators are in registers
       TR(2);
       write_chunk(0);
       TR(3);
-      if (t + t_step < a.ntiles) issue_chunk(t + t_step, 0);
+      issue_chunk(at_next, 0, more);
       TR(4);
       __syncthreads();
       TR(5);                                      // barrier #2n: (n, chunk 0) published; accumulators of tile n-1 published
       // phase: MFMA waves on (n, chunk 0); slot 1 is free; the accumulator stage holds tile n-1 until barrier #2n+1
-      if (tprev >= 0) {
-        epilogue_loads(tprev);
-        epilogue_grab();
-        pending = true;
-      }
+      epilogue_loads(at_prev, tprev >= 0);
+      epilogue_grab();
       TR(6);
       write_chunk(1);
       TR(7);
-      if (t + t_step < a.ntiles) issue_chunk(t + t_step, 1);
+      issue_chunk(at_next, 1, more);
       TR(8);
       __syncthreads();
       TR(9);                                      // barrier #2n+1: (n, chunk 1) published; accumulator stage free again
       tprev = t;
+      at_prev = at_cur;
+      at_cur = at_next;
+      advance(at_next);
     }
-    if (pending) epilogue_finish();
+    epilogue_finish();
     __syncthreads();                                        // final barrier: accumulators of the last tile published
-    if (tprev >= 0) {
-      epilogue_loads(tprev);
-      epilogue_grab();
-      epilogue_finish();
-    }
+    epilogue_loads(at_prev, tprev >= 0);
+    epilogue_grab();
+    epilogue_finish();
     return;
   }
 
@@ -540,9 +559,17 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) xb[sel][s][p] = buf[base + s * LW + 2 * p * PLANE_PIX];
+          for (int p = 0; p < 3; ++p) xb[sel][s][p] = (X3_ABL == 9 && tap > 0) ? xb[sel ^ 1][s][p] : buf[base + s * LW + 2 * p * PLANE_PIX];
+        if (X3_ABL == 8 && tap > 0) {                       // ablation: the weight fragments of tap 0 for every tap (no LDS reads)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wa[sel][p] = wl[((c * 9 + tap) * 3 + p) * 64 + lane];
+          for (int p = 0; p < 3; ++p) wa[sel][p] = wa[sel ^ 1][p];
+        } else if (X3_ABL == 9 && tap > 0) {                // ablation: the B fragments of tap 0 for every tap
+#pragma unroll
+          for (int p = 0; p < 3; ++p) wa[sel][p] = wl[((c * 9 + tap) * 3 + p) * 64 + lane];
+        } else {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) wa[sel][p] = wl[((c * 9 + tap) * 3 + p) * 64 + lane];
+        }
       };
       read_step(0, 0);
 #pragma unroll
