@@ -39,6 +39,8 @@ if os.environ.get("IRR_CONV_ORDER"):
     COMMON = COMMON + ["-DCONV_ORDER=" + os.environ["IRR_CONV_ORDER"]]
 if os.environ.get("IRR_WX3_ABL"):
     COMMON = COMMON + ["-DWX3_ABL=" + os.environ["IRR_WX3_ABL"]]
+if os.environ.get("IRR_X3_SPLIT_SCALAR"):
+    COMMON = COMMON + ["-DX3_SPLIT_SCALAR=" + os.environ["IRR_X3_SPLIT_SCALAR"]]
 if os.environ.get("IRR_X3S_TRACE"):
     COMMON = COMMON + ["-DX3S_TRACE=1"]
 if os.environ.get("IRR_X3_ABL"):
