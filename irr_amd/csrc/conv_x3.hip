@@ -141,7 +141,7 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
 
   float raw[NR][8];
   auto issue_x = [&](int c) {
-    const int ch0 = (c == a.nchunk - 1) ? tail_base : c * 16;
+    const int ch0 = X3_ABL == 12 ? 0 : (c == a.nchunk - 1) ? tail_base : c * 16;       // ablation 12: every chunk re-reads chunk 0 (cache hits, real data)
     const uint32_t s0 = (uint32_t)ch0 * hw4;
 #pragma unroll
     for (int r = 0; r < NR; ++r)
