@@ -428,7 +428,11 @@ class WgradSide:
         self.views = views                      # id(parameter) -> flat-arena view with the parameter's shape
         dev = next(iter(views.values())).device
         self.stream = torch.cuda.Stream(device=dev)
-        self._inflight = collections.deque()    # (event on the lane, tensors its launch reads)
+        # The references in _inflight are dropped only after the lane has passed the launch (marker) or after the current stream
+        # has joined the lane, so the caching allocator can never hand the memory out early; Tensor.record_stream on top of that
+        # makes the allocator record one (system-scope) event on the lane per freed tensor -- 500 per step (A/B switch: 1 = on)
+        self.record_streams = os.environ.get("IRR_LANE_RECORD_STREAM", "0") != "0"
+        self._inflight = collections.deque()    # (done marker on the lane, tensors its launch reads)
         self.on_launch = None                   # optional hook(weight, bias) after each routed launch (ddp: early buckets)
 
     def route(self, weight, bias):
@@ -440,11 +444,11 @@ class WgradSide:
 
     def launch(self, fn, tensors, params=(None, None)):
         """Run ``fn`` on the lane after everything enqueued so far on the current stream.  The tensors it reads are kept
-        ALIVE (strong references) until the lane has passed the launch: (a) the caching allocator cannot recycle them
-        (``record_stream`` as well, for the time after the reference is dropped), and (b) a tensor with a second owner is
-        never accumulated into IN PLACE by the autograd engine (InputBuffer::accumulate only steals a gradient whose
-        use_count is 1), nor handed to a consumer as its exclusive property -- whatever the model code around the node
-        does with the same gradient tensor (``a = a + b`` feeding two nodes, models/pwcnet_irr*.py)."""
+        ALIVE (strong references) until the lane has passed the launch: (a) the caching allocator cannot recycle them, and
+        (b) a tensor with a second owner is never accumulated into IN PLACE by the autograd engine (InputBuffer::accumulate
+        only steals a gradient whose use_count is 1), nor handed to a consumer as its exclusive property -- whatever the
+        model code around the node does with the same gradient tensor (``a = a + b`` feeding two nodes,
+        models/pwcnet_irr*.py)."""
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(main)
@@ -453,11 +457,13 @@ class WgradSide:
             fn()
             done = torch.cuda.Event()
             done.record(self.stream)
+        capturing = torch.cuda.is_current_stream_capturing()
         keep = [t for t in tensors if t is not None]
-        for t in keep:
-            t.record_stream(self.stream)
+        if self.record_streams:
+            for t in keep:
+                t.record_stream(self.stream)
         self._inflight.append((done, keep))
-        if not torch.cuda.is_current_stream_capturing():       # (an event recorded inside a capture cannot be queried)
+        if not capturing:                                      # (an event recorded inside a capture cannot be queried)
             while self._inflight and self._inflight[0][0].query():
                 self._inflight.popleft()
         if self.on_launch is not None:
