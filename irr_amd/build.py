@@ -61,8 +61,11 @@ _BASE_FLAGS = 7            # len(COMMON) without macro switches
 if len(COMMON) != _BASE_FLAGS and not TAG:
     raise RuntimeError("ablation / trace macros change the kernels: set IRR_BUILD_TAG=<name> so the build goes to "
                        "irr_amd/lib_<name>/ instead of replacing the product library")
+# The x3 kernels are compiled without the SLP vectoriser: it turns adjacent scalar fp32 adds into v_pk_add_f32, and a packed
+# fp32 instruction beside a stream of MFMAs costs far more than its issue slot (x3_split.h; +0.3-0.6 % per train step).
 EXTRA = {"warp.hip": ["-ffp-contract=off"], "resize.hip": ["-ffp-contract=off"],
-         "augment.hip": ["-ffp-contract=off"]}
+         "augment.hip": ["-ffp-contract=off"],
+         "conv_wgrad_x3.hip": ["-fno-slp-vectorize"], "conv_x3.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
