@@ -11,7 +11,12 @@ A "step" is one pass of the hot path over one synthetic batch: zero_grad -> PWCN
 MultiScaleEPE_PWC_Bi_Occ_upsample -> NaN check -> backward -> [RCCL gradient all-reduce] -> Adam step,
 i.e. the reference's TrainingEpoch._step (runtime.py:131-194) with inputs already resident in HBM.
 Workload = BASELINE configs[2] (384x448, 32 pairs per GPU, FlyingChairsOcc-shaped synthetic tensors,
-weak scaling: every rank gets its own 32 pairs).  Prints ONE JSON line on rank 0.
+weak scaling: every rank gets its own 32 pairs).  Prints ONE JSON line on rank 0.  After the headline timing the same process
+runs 5 steps of the per-GPU workload of BASELINE configs[4] (448x1024, 8 pairs per GPU: north_star's second crop) and reports it
+under ``"secondary"`` (own roofline object); ``metric`` / ``value`` are the headline's.
+
+``IRR_DDP_BACKEND=gloo`` (single-GPU boxes, tests): the ranks share the visible GPUs (rank r -> cuda:r % device_count) and
+exchange through gloo -- RCCL refuses two ranks on one device; everything but the transport is the same code.
 """
 import argparse
 import json
@@ -40,6 +45,9 @@ def kernel_name(var):
         return (f"conv_x3_kernel<{c // 1000},{(c // 100) % 10},{(c // 10) % 10},{X3_PLANES.get(c % 10, 0)}>", X3_PEAK_TFLOPS)
     return (f"conv_fwd_kernel<{var // 100},{(var // 10) % 10},{var % 10}>", FP32_MFMA_PEAK_TFLOPS)
 CONV_GFLOP_PER_PAIR = {(384, 448): 1088.4, (448, 1024): 2902.5}   # 3x forward conv FLOPs
+SECONDARY = (8, 448, 1024)             # per-GPU share of BASELINE configs[4] (Sintel-shaped 448x1024, bs64 on 8 GPUs)
+SECONDARY_STEPS = 5
+TRAFFIC_FILES = {(384, 448, 32): "hbm_traffic.json", (448, 1024, 8): "hbm_traffic_448x1024.json"}
 
 
 def synthetic_batch(batch, height, width, seed, device):
@@ -123,6 +131,7 @@ def main():
     ap.add_argument("--quick-cpu-baseline", action="store_true", help="one CPU leg (batch 2) instead of three")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-async-wgrad", action="store_true", help="keep weight gradients on the main stream")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 448x1024 leg after the headline timing")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -132,12 +141,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE={world} of the launcher")
+    backend = os.environ.get("IRR_DDP_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import irr_amd
     from irr_amd import conv as C
@@ -146,131 +161,163 @@ def main():
     from irr_amd.optim import FusedAdam
 
     pre_gb = a.prealloc_gb if a.prealloc_gb >= 0 else 0.30 * torch.cuda.get_device_properties(device).total_memory / 1e9
+    if backend != "nccl" and world > 1:
+        pre_gb /= world                                      # the ranks share a device
     if pre_gb > 0:
         # a step peaks at 39 GB allocated / 69 GB reserved (bs32, 384x448): the pool would otherwise still grow by a few
         # segments during the first timed steps
         blk = torch.empty(int(pre_gb * 1e9), dtype=torch.uint8, device=device)
         del blk
-    args = types.SimpleNamespace(batch_size=a.batch, model_div_flow=0.05)
     torch.manual_seed(0)                                     # same MSRA init on every rank
-    model = irr_amd.PWCNet(args).to(device).train()
+    model = irr_amd.PWCNet(types.SimpleNamespace(batch_size=a.batch, model_div_flow=0.05)).to(device).train()
     ddp.broadcast_params(model)
-    loss = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(args, reduce_fn=ddp.reduce_losses() if world > 1 else None).train()
-    mal = ModelAndLoss(args, model, loss).train()
     arena = ddp.GradArena(model.named_parameters())
     if not a.no_async_wgrad:
         arena.enable_async_wgrad()
     opt = FusedAdam(model, arena, lr=1e-4, weight_decay=4e-4)
-    step = TrainStep(mal, opt, grad_sync=arena.sync, check_nan=os.environ.get("IRR_BENCH_NO_NANCHECK") is None)   # (diagnostic switch)
-    batch = synthetic_batch(a.batch, a.height, a.width, 1234 + rank, device)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    marks = [] if os.environ.get("IRR_BENCH_STEPTIMES") else None      # diagnostic: per-step GPU time (events, no extra syncs)
+    def run(batch_pairs, height, width, steps, warmup, timed_kernels):
+        """W untimed + exactly K timed train steps of one workload -> dict(dt, value, loss, routing, roofline)"""
+        args = types.SimpleNamespace(batch_size=batch_pairs, model_div_flow=0.05)
+        loss = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(args, reduce_fn=ddp.reduce_losses() if world > 1 else None).train()
+        mal = ModelAndLoss(args, model, loss).train()
+        step = TrainStep(mal, opt, grad_sync=arena.sync, check_nan=os.environ.get("IRR_BENCH_NO_NANCHECK") is None)   # (diagnostic switch)
+        batch = synthetic_batch(batch_pairs, height, width, 1234 + rank, device)
+        marks = [] if os.environ.get("IRR_BENCH_STEPTIMES") else None      # diagnostic: per-step GPU time (events, no extra syncs)
 
-    def mark():
-        if marks is not None:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            marks.append((time.perf_counter(), ev))
+        def mark():
+            if marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append((time.perf_counter(), ev))
 
-    for _ in range(a.warmup):
+        for _ in range(warmup):
+            mark()
+            step(batch)
+        seg0 = torch.cuda.memory_stats(device).get("segment.all.allocated", 0) if marks is not None else 0
+        timer = None
+        if timed_kernels:
+            timer = C.KernelTimer()
+            C.TIMER = timer
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            mark()
+            ld, _, _ = step(batch)
         mark()
+        barrier()
+        dt = time.perf_counter() - t0
+        C.TIMER = None
+        if marks is not None and rank == 0:
+            print("per-step ms (gpu / cpu issue), first %d are warm-up: " % warmup +
+                  " ".join("%.1f/%.1f" % (m0[1].elapsed_time(m1[1]), 1e3 * (m1[0] - m0[0])) for m0, m1 in zip(marks[:-1], marks[1:])),
+                  file=sys.stderr)
+            st = torch.cuda.memory_stats(device)
+            print("allocator: segments created in the timed steps %d (total %d), retries %d, peak allocated %.1f GB, reserved %.1f GB"
+                  % (st.get("segment.all.allocated", 0) - seg0, st.get("segment.all.allocated", 0), st.get("num_alloc_retries", 0),
+                     torch.cuda.max_memory_allocated(device) / 1e9, torch.cuda.max_memory_reserved(device) / 1e9), file=sys.stderr)
+        # what one step was ROUTED to (launch counters of irr_amd.conv), taken on one extra step outside the timed region
+        C.LAUNCHES.clear()
         step(batch)
-    seg0 = torch.cuda.memory_stats(device).get("segment.all.allocated", 0) if marks is not None else 0
-    timer = None
-    if not a.no_kernel_timer:
-        timer = C.KernelTimer()
-        C.TIMER = timer
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        mark()
-        ld, _, _ = step(batch)
-    mark()
-    barrier()
-    dt = time.perf_counter() - t0
-    if marks is not None and rank == 0:
-        print("per-step ms (gpu / cpu issue), first %d are warm-up: " % a.warmup +
-              " ".join("%.1f/%.1f" % (m0[1].elapsed_time(m1[1]), 1e3 * (m1[0] - m0[0])) for m0, m1 in zip(marks[:-1], marks[1:])),
-              file=sys.stderr)
-        st = torch.cuda.memory_stats(device)
-        print("allocator: segments created in the timed steps %d (total %d), retries %d, peak allocated %.1f GB, reserved %.1f GB"
-              % (st.get("segment.all.allocated", 0) - seg0, st.get("segment.all.allocated", 0), st.get("num_alloc_retries", 0),
-                 torch.cuda.max_memory_allocated(device) / 1e9, torch.cuda.max_memory_reserved(device) / 1e9), file=sys.stderr)
-    C.TIMER = None
-    # what one step was ROUTED to (launch counters of irr_amd.conv), taken on one extra step outside the timed region
-    C.LAUNCHES.clear()
-    step(batch)
-    torch.cuda.synchronize()
-    routing = dict(C.LAUNCHES)
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    pairs = a.batch * world * a.steps
-    value = pairs / dt
+        torch.cuda.synchronize()
+        routing = dict(C.LAUNCHES)
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        res = {"dt": dt, "value": batch_pairs * world * steps / dt, "routing": routing,
+               "loss": {k: float(v.detach()) for k, v in ld.items()},
+               "roofline": roofline(timer, steps, height, width, batch_pairs) if (timer is not None and rank == 0) else None}
+        del batch, step, mal, loss
+        return res
 
-    roof = None
-    if timer is not None:
+    def roofline(timer, steps, height, width, batch_pairs):
         summ = timer.summary()
-        if summ:
-            var, st = max(summ.items(), key=lambda kv: kv[1]["seconds"])
-            ach = st["flops"] / st["seconds"] / 1e12
-            tot_f = sum(s["flops"] for s in summ.values())
-            tot_s = sum(s["seconds"] for s in summ.values())
-            kname, peak = kernel_name(var)
-            roof = {"bound": "mfma", "kernel": kname,
-                    "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
-                    "peak_note": ("algorithmic fp32 FLOPs (2*MACs); conv_x3 issues 6 bf16 MFMA products per fp32 product, "
-                                  "so its roof is the dense bf16 MFMA peak 2500 / 6 = 416.7 TFLOP/s" if peak != FP32_MFMA_PEAK_TFLOPS
-                                  else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
-                    "launches": st["calls"], "avg_launch_us": round(st["seconds"] / st["calls"] * 1e6, 2),
-                    "flop_per_launch": st["flops"] / st["calls"],
-                    "concurrent_lanes": 1 if a.no_async_wgrad else 2,
-                    "note": ("durations include time-sharing the chip with the asynchronous weight-gradient lane "
-                             "(second HIP stream) during backward; 'exclusive' = the forward-pass launches of the same "
-                             "kernel, which run alone") if not a.no_async_wgrad else "single stream",
-                    "exclusive": ({"achieved": round(st["fwd_flops"] / st["fwd_seconds"] / 1e12, 2),
-                                   "frac": round(st["fwd_flops"] / st["fwd_seconds"] / 1e12 / peak, 4),
-                                   "launches": st["fwd_calls"],
-                                   "avg_launch_us": round(st["fwd_seconds"] / st["fwd_calls"] * 1e6, 2)}
-                                  if st["fwd_calls"] else None),
-                    "all_conv_fwd_dgrad": {"achieved": round(tot_f / tot_s / 1e12, 2), "seconds_per_step": round(tot_s / a.steps, 5),
-                                           "flops_per_step": tot_f / a.steps},
-                    "by_kernel": {kernel_name(v)[0]: {"launches": s_["calls"], "ms_per_step": round(s_["seconds"] / a.steps * 1e3, 2),
-                                                      "achieved": round(s_["flops"] / s_["seconds"] / 1e12, 1)}
-                                  for v, s_ in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:6]}}
-    if rank == 0 and roof is not None:
-        # HBM bytes per launch of that kernel from the committed PMC passes (profiles/r1_hbm_traffic.txt:
-        # separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH x2 gfx950 correction); not re-measured here.
+        if not summ:
+            return None
+        var, st = max(summ.items(), key=lambda kv: kv[1]["seconds"])
+        ach = st["flops"] / st["seconds"] / 1e12
+        tot_f = sum(s["flops"] for s in summ.values())
+        tot_s = sum(s["seconds"] for s in summ.values())
+        kname, peak = kernel_name(var)
+        roof = {"bound": "mfma", "kernel": kname,
+                "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None,
+                "peak_note": ("algorithmic fp32 FLOPs (2*MACs); conv_x3 issues 6 bf16 MFMA products per fp32 product, "
+                              "so its roof is the dense bf16 MFMA peak 2500 / 6 = 416.7 TFLOP/s" if peak != FP32_MFMA_PEAK_TFLOPS
+                              else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                "launches": st["calls"], "avg_launch_us": round(st["seconds"] / st["calls"] * 1e6, 2),
+                "flop_per_launch": st["flops"] / st["calls"],
+                "concurrent_lanes": 1 if a.no_async_wgrad else 2,
+                "note": ("durations include time-sharing the chip with the asynchronous weight-gradient lane "
+                         "(second HIP stream) during backward; 'exclusive' = the forward-pass launches of the same "
+                         "kernel, which run alone") if not a.no_async_wgrad else "single stream",
+                "exclusive": ({"achieved": round(st["fwd_flops"] / st["fwd_seconds"] / 1e12, 2),
+                               "frac": round(st["fwd_flops"] / st["fwd_seconds"] / 1e12 / peak, 4),
+                               "launches": st["fwd_calls"],
+                               "avg_launch_us": round(st["fwd_seconds"] / st["fwd_calls"] * 1e6, 2)}
+                              if st["fwd_calls"] else None),
+                "all_conv_fwd_dgrad": {"achieved": round(tot_f / tot_s / 1e12, 2), "seconds_per_step": round(tot_s / steps, 5),
+                                       "flops_per_step": tot_f / steps},
+                "by_kernel": {kernel_name(v)[0]: {"launches": s_["calls"], "ms_per_step": round(s_["seconds"] / steps * 1e3, 2),
+                                                  "achieved": round(s_["flops"] / s_["seconds"] / 1e12, 1)}
+                              for v, s_ in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:6]}}
+        # HBM bytes per launch of that kernel from the committed PMC passes (profiles/hbm_traffic*.json: separate --pmc FETCH_SIZE /
+        # WRITE_SIZE runs of THIS command, FETCH x2 gfx950 correction).  PMC counters cannot be collected from inside the process,
+        # so the bytes are only reported when the json was measured on a library built from the very sources that are loaded now.
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            from irr_amd import build as B_
+            tr = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILES[(height, width, batch_pairs)])))
             k = roof["kernel"].replace(",", ", ")
-            if k in tr and (a.height, a.width, a.batch) == (384, 448, 32):
+            if tr.get("_source_hash") != B_.source_hash():
+                roof["traffic_source"] = (f"stale: {TRAFFIC_FILES[(height, width, batch_pairs)]} was measured on sources "
+                                          f"{tr.get('_source_hash')}, the library is built from {B_.source_hash()}")
+            elif k in tr:
                 roof["traffic"] = round((tr[k]["fetch_MB_per_launch_corrected"] + tr[k]["write_MB_per_launch"]) * 1e6)
-                roof["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 PMC passes, bytes per launch)"
+                roof["traffic_source"] = (f"profiles/{TRAFFIC_FILES[(height, width, batch_pairs)]} (rocprofv3 PMC passes over this "
+                                          f"command, bytes per launch, sources {tr['_source_hash']})")
         except Exception:
             pass
+        return roof
+
+    def workload_name(cfg, batch_pairs, height, width):
+        return (f"BASELINE {cfg}: IRR_PWC train step (fwd + MultiScaleEPE_PWC_Bi_Occ_upsample + bwd + Adam), "
+                f"synthetic {height}x{width}, {batch_pairs} pairs per GPU")
+
+    head = run(a.batch, a.height, a.width, a.steps, a.warmup, not a.no_kernel_timer)
+    second = None
+    if not a.no_secondary and (a.height, a.width) == (384, 448):
+        second = run(SECONDARY[0], SECONDARY[1], SECONDARY[2], SECONDARY_STEPS, 2, not a.no_kernel_timer)
     if rank == 0:
         gf = CONV_GFLOP_PER_PAIR.get((a.height, a.width))
+        value = head["value"]
         out = {"metric": "image-pairs/sec fwd+bwd IRR-PWC 384x448 bs32", "value": round(value, 3), "unit": "image-pairs/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(head["dt"] / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"BASELINE configs[2]: IRR_PWC train step (fwd + MultiScaleEPE_PWC_Bi_Occ_upsample + "
-                                      f"bwd + Adam), FlyingChairsOcc-shaped synthetic {a.height}x{a.width}, {a.batch} pairs per GPU",
+               "config": {"workload": workload_name("configs[2]" if (a.height, a.width) == (384, 448) else "(other crop)",
+                                                    a.batch, a.height, a.width).replace("synthetic", "FlyingChairsOcc-shaped synthetic"),
                           "pairs_per_gpu": a.batch, "global_batch": a.batch * world, "height": a.height, "width": a.width,
-                          "parallelism": f"dp{world}", "weights": "MSRA init, torch.manual_seed(0)"},
-               "loss": {k: float(v.detach()) for k, v in ld.items()},
+                          "parallelism": f"dp{world}", "weights": "MSRA init, torch.manual_seed(0)",
+                          "transport": "rccl" if backend == "nccl" else backend},
+               "loss": head["loss"],
                "conv_math": C.MATH,
-               "launches_per_step": routing,
+               "launches_per_step": head["routing"],
                "step_conv_tflops": round(value / world * gf * 1e9 / 1e12, 1) if gf else None,
                "step_mfma_frac": round(value / world * gf * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4) if gf else None,
-               "roofline": roof}
+               "roofline": head["roofline"]}
+        if second is not None:
+            gf2 = CONV_GFLOP_PER_PAIR[(SECONDARY[1], SECONDARY[2])]
+            out["secondary"] = {"workload": workload_name("configs[4] per-GPU share", *SECONDARY).replace("synthetic", "Sintel-shaped synthetic"),
+                                "metric": "image-pairs/sec fwd+bwd IRR-PWC 448x1024 bs8", "value": round(second["value"], 3),
+                                "unit": "image-pairs/s", "steps": SECONDARY_STEPS, "warmup": 2,
+                                "ms_per_step": round(second["dt"] / SECONDARY_STEPS * 1e3, 3), "loss": second["loss"],
+                                "step_conv_tflops": round(second["value"] / world * gf2 * 1e9 / 1e12, 1),
+                                "launches_per_step": second["routing"], "roofline": second["roofline"]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.height, a.width, quick=a.quick_cpu_baseline)
         print(json.dumps(out), flush=True)

@@ -26,7 +26,7 @@
  *     family a problem is routed to -- both families compute the same function, so a concurrent change can never
  *     produce a wrong result, only a different choice; production code never touches it);
  *   - kernels are launched on ``stream`` from the CALLING thread's current HIP device: make the device that owns the
- *     stream and the buffers current first (the host binding does -- irr_amd/hip.py:device_guard -- as the reference does
+ *     stream and the buffers current first (the host binding does -- irr_amd/hip.py:device_of -- as the reference does
  *     with torch.cuda.device_of, models/correlation_package/correlation.py:21,34).
  */
 #ifndef IRR_HIP_H
@@ -166,9 +166,10 @@ int irr_conv2d_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int st
  * keeps a table of pack jobs on the device and refreshes all of them in ONE dispatch.  A job record (irr_conv_pack_job_bytes()
  * bytes, layout private to the library) is produced in HOST memory by the builder that mirrors the single-job launcher of the
  * same name; it returns the number of 256-thread blocks the job needs (negative: IRR_EINVAL) and leaves the record's first-block
- * field (a long at byte offset 24) zero: the caller lays the jobs out back to back (exclusive prefix sum of the block counts),
+ * field (a long at byte offset irr_conv_pack_job_block0_offset()) zero: the caller lays the jobs out back to back (exclusive prefix sum of the block counts),
  * copies the table to the device and calls irr_conv_pack_batch(table, njobs, total blocks, stream). */
 int irr_conv_pack_job_bytes(void);
+int irr_conv_pack_job_block0_offset(void);
 long irr_conv_pack_job_f32(void* job, const float* w, float* wp, int Cin, int Cout, int k, int transpose);
 long irr_conv_pack_job_sub_f32(void* job, const float* w, float* wp, int w_cin, int w_cout, int k, int chan0, int nchan,
                                int CoP, int row_offset);
@@ -331,10 +332,12 @@ int irr_f1bal_multi_bwd_f32(const void* terms, int nterms, const float* gscale, 
  *   p -= (lr/bias_corr1) * m / (sqrt(v)/sqrt(bias_corr2) + eps)          bias_corr_i = 1 - beta_i^t
  * step_dev (nullable): DEVICE float holding the step count t; when given, the bias corrections are computed from it inside
  * the kernel and bias_corr1/2 are ignored -- a captured launch (hipGraph) then stays correct on every replay.
+ * The scalar hyper-parameters are DOUBLES, as in torch.optim.Adam: 1 - beta_i, lr / bias_corr1 and sqrt(bias_corr2) are formed
+ * in double and rounded to fp32 once (1.f - 0.999f is 1.3e-5 away from 0.001).
  */
 int irr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
-                      float lr, float beta1, float beta2, float eps, float weight_decay,
-                      float bias_corr1, float bias_corr2, float grad_scale, const float* step_dev, void* stream);
+                      double lr, double beta1, double beta2, double eps, double weight_decay,
+                      double bias_corr1, double bias_corr2, double grad_scale, const float* step_dev, void* stream);
 
 /* ---- on-GPU training augmentation: RandomAffineFlowOcc (augmentations.py:368-653) -----------------------------
  * The random parameters (thetas, mirror signs, crop origin) are sampled by the host exactly as the reference does

@@ -26,6 +26,7 @@ ARCH = "gfx950"
 
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
           "-Wno-unused-function"]
+_BASE_FLAGS = len(COMMON)  # everything appended below is an ablation / trace macro switch
 # per-file extras.  warp.hip reproduces ATen's fp32 rounding sequence: no contraction there.
 if os.environ.get("IRR_WG_ABL"):
     COMMON = COMMON + ["-DWG_ABL=" + os.environ["IRR_WG_ABL"]]
@@ -57,7 +58,6 @@ if os.environ.get("IRR_CORR_ABL"):
     COMMON = COMMON + ["-DCORR_ABL=" + os.environ["IRR_CORR_ABL"]]
 if os.environ.get("IRR_WG_TR4"):
     COMMON = COMMON + ["-DWG_TR4=1"]
-_BASE_FLAGS = 7            # len(COMMON) without macro switches
 if len(COMMON) != _BASE_FLAGS and not TAG:
     raise RuntimeError("ablation / trace macros change the kernels: set IRR_BUILD_TAG=<name> so the build goes to "
                        "irr_amd/lib_<name>/ instead of replacing the product library")
@@ -77,6 +77,32 @@ def _hipcc() -> str:
 
 def _newer(a: str, b: str) -> bool:
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def sources():
+    """everything the library is built from: csrc/*.hip, csrc/*.h, the public header and this recipe"""
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + \
+        [os.path.join(ROOT, "include", "irr_hip.h"), os.path.abspath(__file__)]
+
+
+def source_hash() -> str:
+    """sha256 over the library's sources (16 hex digits): profiles/hbm_traffic.json stores the hash of the sources its PMC
+    passes were measured on, bench.py refuses to report those bytes for a library built from other sources"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sources():
+        if f.endswith("build.py"):
+            continue
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def stale(lib: str = LIB) -> bool:
+    """library missing, or built from other sources than the ones in the tree (content hash written next to it by build():
+    modification times do not survive the copy to the GPU box)"""
+    stamp = os.path.join(os.path.dirname(lib), "source.hash")
+    return (not os.path.exists(lib)) or (not os.path.exists(stamp)) or open(stamp).read().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -111,6 +137,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
     with open(stamp, "w") as f:
         f.write(flags)
+    with open(os.path.join(LIBDIR, "source.hash"), "w") as f:
+        f.write(source_hash())
     return LIB
 
 

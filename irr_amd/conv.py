@@ -113,6 +113,7 @@ class _PackRegistry:
         sig = (self.version, tuple(w.data_ptr() for _, _, w in live))
         if self._table is None or self._table[0] != sig:
             jb = hip.lib().irr_conv_pack_job_bytes()
+            b0 = hip.lib().irr_conv_pack_job_block0_offset()
             buf = ctypes.create_string_buffer(jb * len(live))
             base = ctypes.addressof(buf)
             block0 = 0
@@ -120,7 +121,7 @@ class _PackRegistry:
                 nb = e[2](base + n_ * jb, w.data_ptr())
                 if nb < 0:
                     raise hip.HipError(f"pack job rejected ({nb})")
-                ctypes.c_long.from_address(base + n_ * jb + 24).value = block0
+                ctypes.c_long.from_address(base + n_ * jb + b0).value = block0
                 block0 += nb
             host = torch.frombuffer(buf, dtype=torch.uint8).clone()
             self._table = (sig, host.to(self.device), len(live), block0)

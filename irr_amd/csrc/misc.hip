@@ -1,2 +1,2 @@
 #include "common.h"
-extern "C" int irr_abi_version(void) { return 2; }
+extern "C" int irr_abi_version(void) { return 3; }   // 3: Adam scalars are doubles, irr_conv_pack_job_block0_offset

@@ -4,7 +4,7 @@
 #pragma once
 #include "x3_split.h"
 
-struct IrrPackJob {            // 72 bytes; mirrored by irr_amd/conv.py (numpy dtype) -- filled by the irr_conv_pack_job_* entry points
+struct IrrPackJob {            // opaque to the host: size and the block0 offset are exported (irr_conv_pack_job_bytes / _block0_offset); filled by irr_conv_pack_job_*
   const float* w;             // source weights (device)
   void* dst;                  // packed destination (device)
   long n;                     // elements (kind 0/1) or 16-B units x lanes (kind 2) of the job

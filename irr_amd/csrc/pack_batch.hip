@@ -2,6 +2,7 @@
 // transposed), the combined DenseNet data-gradient matrices and the pre-split bf16x3 packs.  The host keeps a table of
 // IrrPackJob records on the device (built once; sources and destinations are persistent buffers); block b finds its job
 // by binary search over the jobs' first-block prefix and runs the job's per-element function (pack.h).
+#include <cstddef>
 #include "pack.h"
 
 namespace {
@@ -27,6 +28,7 @@ static int x3_nchunk_(int Cin, int Cout) { return (Cin == 16 && Cout <= 32) ? 2 
 }  // namespace
 
 extern "C" int irr_conv_pack_job_bytes(void) { return (int)sizeof(IrrPackJob); }
+extern "C" int irr_conv_pack_job_block0_offset(void) { return (int)offsetof(IrrPackJob, block0); }
 
 // The four job builders take the arguments of the single-job launchers (irr_conv_pack_weights_f32 / _sub_f32 / _x3 / _x3_sub)
 // and write the record into HOST memory `job`; they return the number of 256-thread blocks the job needs (< 0: IRR_EINVAL).

@@ -100,6 +100,7 @@ class GradArena:
         self._side_lane = None
         self._hooks = []
         self._expected: Optional[dict] = None          # id(param) -> contributions per step (None: not calibrated yet)
+        self.calibration_mismatch = False
         self._seen = {}
         self.launch_log: List[Tuple[int, str]] = []    # (bucket, "backward" | "sync") of the last step -- tests / diagnostics
         self._reset()
@@ -115,6 +116,7 @@ class GradArena:
         self._seen = {pid: 0 for pid in self._bucket_of}
         self._launched = [False] * len(self.buckets)
         self._in_sync = False
+        self._late = False
         if self._expected is not None:
             self._remaining = [sum(1 for pid in ids if self._expected.get(pid, 0) > 0) for ids in self._members]
         else:
@@ -171,8 +173,11 @@ class GradArena:
         if self._expected is None:
             return
         if self._launched[bi]:
-            raise RuntimeError("a gradient contribution arrived after its bucket's all-reduce was started: the model graph "
-                               "differs from the calibrated one -- call GradArena.recalibrate() before this step")
+            # Not raised here: this runs inside an autograd hook / lane callback on THIS rank only, and the other ranks have
+            # already enqueued the matching all-reduce -- they would hang in sync().  The step's collectives are completed
+            # as usual and sync() raises once they are matched (the bucket's sum lacks this contribution).
+            self._late = True
+            return
         if self._seen[pid] == self._expected.get(pid, 0):
             self._remaining[bi] -= 1
             if self._remaining[bi] == 0:
@@ -216,8 +221,25 @@ class GradArena:
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self._side)
         self.flat.mul_(1.0 / self.world)
+        if self._late:
+            self._expected = None                       # (a caller that catches this continues in reduce-at-sync mode)
+            raise RuntimeError("a gradient contribution arrived after its bucket's all-reduce was started: the model graph "
+                               "differs from the calibrated one (the reduced gradients of this step are incomplete) -- call "
+                               "GradArena.recalibrate() before changing the graph")
         if self._expected is None:
-            self._expected = dict(self._seen)           # calibration step: every bucket was reduced here
+            # calibration step: every bucket was reduced here.  The learned counts decide WHEN each rank starts a bucket's
+            # collective, so they must agree on every rank (ranks whose graphs differ would start the buckets in different
+            # orders and deadlock RCCL): compare them once; on a mismatch stay in reduce-at-sync mode.
+            counts = torch.tensor([self._seen[id(p)] for _, p in self.order], dtype=torch.int64, device=self.flat.device)
+            lo, hi = counts.clone(), counts.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            if bool((lo == hi).all()):
+                self._expected = dict(self._seen)
+            else:
+                self.calibration_mismatch = True
+                import warnings
+                warnings.warn("GradArena: gradient-contribution counts differ between ranks -- buckets stay reduced at sync()")
 
 
 def broadcast_params(module: torch.nn.Module, src: int = 0, group=None) -> None:

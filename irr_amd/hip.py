@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("IRR_HIP_LIB") or os.path.join(_PKG, "lib", "libirr_hi
 _CTYPES = {
     "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
     "const int*": ctypes.c_void_p, "int*": ctypes.c_void_p,
-    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
+    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
 }
 
 
@@ -116,12 +116,13 @@ class device_of:
 
     def __enter__(self):
         if self.idx >= 0 and self.idx != torch.cuda.current_device():
-            self.prev = torch.cuda._exchange_device(self.idx)
+            self.prev = torch.cuda.current_device()
+            torch.cuda.set_device(self.idx)
         return self
 
     def __exit__(self, *exc):
         if self.prev >= 0:
-            torch.cuda._maybe_exchange_device(self.prev)
+            torch.cuda.set_device(self.prev)
         return False
 
 

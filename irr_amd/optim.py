@@ -34,6 +34,10 @@ class FusedAdam:
         self.capturable = capturable
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.float32) if capturable else None
 
+    def hyper(self):
+        """what a captured step baked into its kernel arguments (GraphedTrainStep re-captures when it changes)"""
+        return (float(self.lr), tuple(float(b) for b in self.betas), float(self.eps), float(self.weight_decay))
+
     def zero_grad(self, set_to_none: bool = False):
         self.arena.zero_grad()
 

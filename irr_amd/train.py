@@ -77,7 +77,11 @@ class GraphedTrainStep:
     Requirements (checked or arranged here): static shapes; inputs are copied into static buffers; the optimizer keeps
     its step count on the device (``FusedAdam(capturable=True)``); nothing inside the step reads device data on the host --
     the reference's per-step NaN assertion (runtime.py:182-183) is evaluated on the captured loss right after the replay.
-    Data-parallel runs (world > 1) use the eager ``TrainStep``: the gradient all-reduce is not captured."""
+    Data-parallel runs (world > 1) use the eager ``TrainStep``: the gradient all-reduce is not captured.
+
+    The optimizer's hyper-parameters (lr, betas, eps, weight decay) are kernel ARGUMENTS of the captured launch: after changing
+    one of them (the reference trains with MultiStepLR, scripts/IRR-PWC_flyingChairsOcc.sh) the next call re-captures
+    (``FusedAdam.hyper()`` is compared with the captured values)."""
 
     def __init__(self, step: TrainStep, warmup: int = 2):
         import torch.distributed as dist
@@ -86,10 +90,15 @@ class GraphedTrainStep:
                              "(use TrainStep with GradArena.sync)")
         if getattr(step.optimizer, "capturable", False) is not True:
             raise ValueError("GraphedTrainStep needs an optimizer whose step count lives on the device (FusedAdam(capturable=True))")
+        if warmup < 2:
+            # step 1 builds the packed weights one by one, step 2 builds the job table of the batched pack launch (a pageable
+            # host-to-device copy): neither may happen inside the capture
+            raise ValueError("GraphedTrainStep needs warmup >= 2")
         self.step = step
         self.warmup = warmup
         self.check_nan = step.check_nan
         self.graph = None
+        self.hyper = None
         self.static_in: Dict[str, torch.Tensor] = {}
         self.result = None
 
@@ -113,14 +122,20 @@ class GraphedTrainStep:
             self.result = eager(self.static_in)
 
     def __call__(self, example_dict: Dict[str, torch.Tensor]):
+        if self.graph is not None and self.hyper != self.step.optimizer.hyper():
+            self.graph = None                                   # lr schedule moved: the captured kernel arguments are stale
         if self.graph is None:
             self._capture(example_dict)
+            self.hyper = self.step.optimizer.hyper()
         else:
             with torch.no_grad():
                 for k, v in example_dict.items():
                     if torch.is_tensor(v) and v.data_ptr() != self.static_in[k].data_ptr():
                         self.static_in[k].copy_(v, non_blocking=True)
         self.graph.replay()
+        # the captured FusedAdam kernel rewrote the weights behind autograd's back (no version counter moves during a replay):
+        # every packed weight copy the NEXT eager forward (validation, inference) would reuse is stale now
+        _conv.WEIGHT_EPOCH[0] += 1
         loss_dict, output_dict, bs = self.result
         if self.check_nan:
             assert not math.isnan(loss_dict[self.step.training_key].item()), "training_loss is NaN"

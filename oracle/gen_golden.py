@@ -301,6 +301,83 @@ def gen_e2e_train_x3(out_dir, B=4, H=384, W=448):
     np.savez_compressed(os.path.join(out_dir, f"e2e_train_B{B}_{H}x{W}.npz"), **d)
 
 
+TRAIN3_SEEDS = (1234, 99, 7)
+TRAIN3_FULL = ("conv_1x1_1.0.bias", "conv_1x1_1.0.weight", "flow_estimators.conv_last.0.bias", "flow_estimators.conv_last.0.weight",
+               "occ_shuffle_upsample.out_convs.0.weight", "feature_pyramid_extractor.convs.0.0.0.bias",
+               "refine_flow.convs.6.0.bias", "context_networks.convs.6.0.weight")
+
+
+def gen_train3(out_dir, B=2, H=128, W=192):
+    """THREE consecutive optimisation steps of the reference (runtime.py:158-189 with torch.optim.Adam(lr 1e-4, weight_decay 4e-4),
+    scripts/IRR-PWC_flyingChairsOcc.sh:29-31) on three DIFFERENT batches (seeds 1234 / 99 / 7), robust-mask mode.  After the
+    first step Adam is lr*sign(g) whatever its hyper-parameters are; steps 2-3 on fresh batches make beta1, beta2, both bias
+    corrections and the weight-decay term observable.  Stored: the three loss triples, for every parameter the L2 norm of
+    (parameter after step 3 - initial parameter) and of (after step 3 - after step 1), and a few small tensors in full."""
+    P = O.synthetic_params(0)
+    names = sorted(P.keys())
+    set_mode(True, True)
+    m, args = ref_model(P)
+    args.batch_size = B
+    m.train()
+    lossm = losses.MultiScaleEPE_PWC_Bi_Occ_upsample(args)
+    lossm.train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=4e-4)
+    sd = dict(m.named_parameters())
+    init = {n: sd[n].detach().double().clone() for n in names}
+    d = {"param_names": np.array(names), "seeds": np.array(TRAIN3_SEEDS), "full_names": np.array(TRAIN3_FULL)}
+    ls = []
+    after1 = None
+    for it, seed in enumerate(TRAIN3_SEEDS):
+        batch = O.synthetic_batch(B, H, W, seed)
+        for k, t in batch.items():                              # runtime.py:158-162
+            t.requires_grad_("input" in k)
+        opt.zero_grad()
+        ld = lossm(m(batch), batch)
+        ld["total_loss"].backward()
+        opt.step()
+        ls.append([float(ld["flow_loss"]), float(ld["occ_loss"]), float(ld["total_loss"])])
+        if it == 0:
+            after1 = {n: sd[n].detach().double().clone() for n in names}
+    d["losses"] = np.array(ls)
+    d["delta_norm_3_vs_init"] = np.array([float((sd[n].detach().double() - init[n]).norm()) for n in names])
+    d["delta_norm_3_vs_1"] = np.array([float((sd[n].detach().double() - after1[n]).norm()) for n in names])
+    d["delta_sum_3_vs_init"] = np.array([float((sd[n].detach().double() - init[n]).sum()) for n in names])
+    for n in TRAIN3_FULL:
+        d["full_" + n] = (sd[n].detach().double() - init[n]).numpy()          # the DELTA, float64
+    set_mode(False, False)
+    print("train3 losses", d["losses"].tolist(), "total delta", float(np.sqrt((d["delta_norm_3_vs_init"] ** 2).sum())))
+    np.savez_compressed(os.path.join(out_dir, f"train3_B{B}_{H}x{W}.npz"), **d)
+
+
+def gen_train_448x1024(out_dir, B=1, H=448, W=1024):
+    """One train step at the second crop of north_star (Sintel-shaped 448x1024, BASELINE configs[4]), B = 1, robust-mask mode:
+    losses, the 124 gradient norms / sums and subsampled level-4 / full-resolution outputs."""
+    P = O.synthetic_params(0)
+    batch = O.synthetic_batch(B, H, W, 1234)
+    names = sorted(P.keys())
+    d = {"param_names": np.array(names)}
+    set_mode(True, True)
+    m, args = ref_model(P)
+    args.batch_size = B
+    m.train()
+    lossm = losses.MultiScaleEPE_PWC_Bi_Occ_upsample(args)
+    lossm.train()
+    out = m({"input1": batch["input1"].clone().requires_grad_(True), "input2": batch["input2"].clone().requires_grad_(True)})
+    ld = lossm(out, batch)
+    ld["total_loss"].backward()
+    sd = dict(m.named_parameters())
+    d["robust_train_losses"] = np.array([float(ld["flow_loss"]), float(ld["occ_loss"]), float(ld["total_loss"])])
+    d["robust_train_gradnorm"] = np.array([float(sd[n].grad.double().norm()) for n in names])
+    d["robust_train_gradsum"] = np.array([float(sd[n].grad.double().sum()) for n in names])
+    d["robust_train_l4_flow_f"] = npf(out["flow"][4][2][:1, :, ::2, ::2])
+    d["robust_train_l4_occ_b"] = npf(out["occ"][4][3][:1, :, ::2, ::2])
+    d["robust_train_l6_flow_b"] = npf(out["flow"][6][1][:1, :, ::8, ::8])
+    d["robust_train_l6_occ_f"] = npf(out["occ"][6][0][:1, :, ::8, ::8])
+    set_mode(False, False)
+    print("448x1024 train losses", d["robust_train_losses"], "grad-L2", float(np.sqrt((d["robust_train_gradnorm"] ** 2).sum())))
+    np.savez_compressed(os.path.join(out_dir, f"e2e_train_B{B}_{H}x{W}.npz"), **d)
+
+
 def gen_oddsize(out_dir):
     """Inputs whose height / width are NOT multiples of 64 (the reference evaluates Sintel 436x1024 and KITTI ~375x1242 as
     they come, scripts/validation/IRR-PWC_sintel.sh:17-29): odd pyramid sizes (436 -> 218, 109, 55, 28, 14, 7), the
@@ -550,7 +627,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
-    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "trainx3": gen_e2e_train_x3, "oddsize": gen_oddsize, "pwcnet": gen_pwcnet_plumbing, "noise": gen_noise_floor, "augment": gen_augment, "variants": gen_variants, "flowvis": gen_flowvis}
+    steps = {"ops": gen_ops, "init": gen_init, "e2e": gen_e2e, "big": gen_e2e_big, "trainx3": gen_e2e_train_x3, "train3": gen_train3, "train448": gen_train_448x1024, "oddsize": gen_oddsize, "pwcnet": gen_pwcnet_plumbing, "noise": gen_noise_floor, "augment": gen_augment, "variants": gen_variants, "flowvis": gen_flowvis}
     for k, fn in steps.items():
         if a.only and k not in a.only.split(","):
             continue

@@ -353,7 +353,10 @@ def _f1_bal(y_pred: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
 
 
 def multiscale_loss(out: dict, target1, target2, target_occ1, target_occ2, batch_size: int,
-                    div_flow: float = 0.05) -> Dict[str, torch.Tensor]:
+                    div_flow: float = 0.05, global_sums=None) -> Dict[str, torch.Tensor]:
+    """``global_sums`` = (flow_loss, occ_loss) un-normalised sums over the WHOLE batch when ``out`` holds only a chunk of it
+    (every term is a sum over samples, only the balancing weights of losses.py:560-567 couple them): the chunk's
+    ``total_loss`` is then its share of the whole batch's, with ``batch_size`` the whole batch's size."""
     tf_f, tf_b = div_flow * target1, div_flow * target2                   # losses.py:535-536
     flow_loss = 0
     occ_loss = 0
@@ -370,7 +373,7 @@ def multiscale_loss(out: dict, target1, target2, target_occ1, target_occ2, batch
             acc = acc + _f1_bal(of, F.adaptive_avg_pool2d(target_occ1, list(of.shape[2:])))
             acc = acc + _f1_bal(ob, F.adaptive_avg_pool2d(target_occ2, list(ob.shape[2:])))
         occ_loss = occ_loss + LEVEL_WEIGHTS[ii] * acc / len(lvl)
-    fl, ol = flow_loss.detach(), occ_loss.detach()                        # losses.py:560-567
+    fl, ol = (flow_loss.detach(), occ_loss.detach()) if global_sums is None else global_sums   # losses.py:560-567
     if fl > ol:
         w_f, w_o = 1, fl / ol
     else:
@@ -419,6 +422,28 @@ def train_step(p: Params, opt: torch.optim.Optimizer, batch: dict, mask_threshol
     total.backward()
     opt.step()
     return {k: float(v.detach()) for k, v in loss.items()}
+
+
+def train_grads_chunked(p: Params, batch: dict, chunk: int, mask_threshold: float = 1.0) -> Dict[str, float]:
+    """Losses and parameter gradients (accumulated into ``p[...].grad``) of ONE batch evaluated ``chunk`` samples at a time --
+    identical to the whole-batch step up to summation order, with the memory of a chunk (a 32-pair 384x448 batch holds 53 GB
+    of autograd state in one piece).  Pass 1 (no grad): the un-normalised loss sums of the whole batch, which fix the
+    balancing weights; pass 2: forward + backward per chunk with those weights."""
+    B = batch["input1"].shape[0]
+    parts = [{k: v[i:i + chunk] for k, v in batch.items()} for i in range(0, B, chunk)]
+    fl = ol = 0.0
+    with torch.no_grad():
+        for c in parts:
+            out = irr_pwc_forward(p, c["input1"], c["input2"], True, mask_threshold=mask_threshold)
+            ld = multiscale_loss(out, c["target1"], c["target2"], c["target_occ1"], c["target_occ2"], batch_size=1)
+            fl, ol = fl + ld["flow_loss"], ol + ld["occ_loss"]
+    total = 0.0
+    for c in parts:
+        out = irr_pwc_forward(p, c["input1"], c["input2"], True, mask_threshold=mask_threshold)
+        ld = multiscale_loss(out, c["target1"], c["target2"], c["target_occ1"], c["target_occ2"], batch_size=B, global_sums=(fl, ol))
+        ld["total_loss"].backward()
+        total += float(ld["total_loss"].detach())
+    return {"flow_loss": float(fl) / B, "occ_loss": float(ol) / B, "total_loss": total}
 
 
 def make_trainable(p: Params) -> Params:

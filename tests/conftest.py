@@ -22,7 +22,9 @@ def golden_dir():
 def _built_library():
     """The C-ABI library is git-ignored: build it on demand (hipcc cross-compiles gfx950 without a GPU)."""
     from irr_amd import build, hip
-    if not os.path.exists(hip.LIB_PATH):
+    if build.stale(hip.LIB_PATH):          # missing, or any csrc/ file, header or the build recipe is newer than the library
+        if os.environ.get("IRR_HIP_LIB"):
+            raise RuntimeError("IRR_HIP_LIB points to a library that is older than its sources: " + hip.LIB_PATH)
         build.build(verbose=False)
     yield
 

@@ -56,3 +56,22 @@ def test_bench_self_launches_two_ranks():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["value"] > 0
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """`python bench.py --gpus 2` from a cold shell on a ONE-GPU box: the script starts its own ranks (launch_ranks), both share
+    cuda:0 and exchange through gloo (IRR_DDP_BACKEND) -- broadcast_params, reduce_losses, the bucketed gradient all-reduce, the
+    MAX-over-ranks timing and the rank-0 relay of bench.py run exactly as in the driver's multi-GPU leg, incl. the secondary
+    448x1024 workload; ONE JSON line comes back."""
+    import json
+    env = _env()
+    env["IRR_DDP_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--batch", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0 and out["config"]["transport"] == "gloo"
+    assert out["secondary"]["value"] > 0 and out["secondary"]["roofline"]["achieved"] > 0
+    assert out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out

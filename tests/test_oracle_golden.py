@@ -158,3 +158,68 @@ def test_oddsize_vs_reference(golden_dir):
     np.testing.assert_allclose(gn, g["small_train_gradnorm"], rtol=2e-3, atol=1e-4 * np.sqrt((g["small_train_gradnorm"] ** 2).sum()))
     post = np.array([float(Pt[n].detach().double().sum()) for n in names])
     np.testing.assert_allclose(post, g["small_poststep_sum"], rtol=1e-5, atol=1e-3)
+
+
+def _oracle_three_steps(g, **adam_kw):
+    names = [str(n) for n in g["param_names"]]
+    P = O.make_trainable(O.synthetic_params(0))
+    init = {n: P[n].detach().double().clone() for n in names}
+    opt = O.make_adam(P) if not adam_kw else torch.optim.Adam(list(P.values()), **{**dict(lr=1e-4, weight_decay=4e-4), **adam_kw})
+    losses, after1 = [], None
+    for i, seed in enumerate(g["seeds"]):
+        ld = O.train_step(P, opt, O.synthetic_batch(2, 128, 192, int(seed)), mask_threshold=0.9999)
+        losses.append([ld["flow_loss"], ld["occ_loss"], ld["total_loss"]])
+        if i == 0:
+            after1 = {n: P[n].detach().double().clone() for n in names}
+    d3 = {n: float((P[n].detach().double() - init[n]).norm()) for n in names}
+    d31 = {n: float((P[n].detach().double() - after1[n]).norm()) for n in names}
+    full = {str(n): (P[str(n)].detach().double() - init[str(n)]).numpy() for n in g["full_names"]}
+    return losses, d3, d31, full
+
+
+def test_three_optimizer_steps_vs_reference_and_checker_has_teeth(golden_dir):
+    """Three Adam steps on three different batches: the oracle reproduces the imported reference (losses of all three steps,
+    per-parameter update norms, small tensors element by element) -- and the SAME checker, at the SAME tolerances the GPU
+    tests use, rejects an optimiser with a wrong beta2, beta1, weight decay, eps or learning rate."""
+    from train3_check import problems
+    g = _load(golden_dir, "train3_B2_128x192.npz")
+    assert problems(g, *_oracle_three_steps(g)) == []
+    for kw in (dict(betas=(0.9, 0.99)), dict(betas=(0.8, 0.999)), dict(weight_decay=0.0), dict(eps=1e-6), dict(lr=1.01e-4)):
+        assert problems(g, *_oracle_three_steps(g, **kw)), f"checker accepted Adam with {kw}"
+
+
+def test_e2e_train_448x1024_robust(golden_dir):
+    """the oracle against the reference's train step at north_star's second crop (448x1024, BASELINE configs[4]), B = 1"""
+    g = _load(golden_dir, "e2e_train_B1_448x1024.npz")
+    names = [str(n) for n in g["param_names"]]
+    P = O.make_trainable(O.synthetic_params(0))
+    batch = O.synthetic_batch(1, 448, 1024, 1234)
+    out = O.irr_pwc_forward(P, batch["input1"], batch["input2"], True, mask_threshold=0.9999)
+    ld = O.multiscale_loss(out, batch["target1"], batch["target2"], batch["target_occ1"], batch["target_occ2"], batch_size=1)
+    ld["total_loss"].backward()
+    np.testing.assert_allclose([float(ld[k].detach()) for k in ("flow_loss", "occ_loss", "total_loss")], g["robust_train_losses"], rtol=1e-5)
+    gn = np.array([float(P[n].grad.double().norm()) for n in names])
+    ref = g["robust_train_gradnorm"]
+    tot_ref = np.sqrt((ref ** 2).sum())
+    assert abs(np.sqrt((gn ** 2).sum()) - tot_ref) / tot_ref < 1e-4
+    np.testing.assert_allclose(gn, ref, rtol=2e-3, atol=1e-4 * tot_ref)
+    np.testing.assert_allclose(out["flow"][4][2][:1, :, ::2, ::2].detach().numpy(), g["robust_train_l4_flow_f"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["occ"][6][0][:1, :, ::8, ::8].detach().numpy(), g["robust_train_l6_occ_f"], rtol=1e-4, atol=1e-5)
+
+
+def test_chunked_oracle_step_equals_whole_batch():
+    """train_grads_chunked (what the GPU test of the full bs32 bench shape compares with, to bound host memory) == the
+    whole-batch step: losses and every gradient."""
+    batch = O.synthetic_batch(4, 128, 192, 5)
+    P0 = O.make_trainable(O.synthetic_params(0))
+    out = O.irr_pwc_forward(P0, batch["input1"], batch["input2"], True, mask_threshold=0.9999)
+    ld = O.multiscale_loss(out, batch["target1"], batch["target2"], batch["target_occ1"], batch["target_occ2"], batch_size=4)
+    ld["total_loss"].backward()
+    P1 = O.make_trainable(O.synthetic_params(0))
+    lc = O.train_grads_chunked(P1, batch, 2, mask_threshold=0.9999)
+    for k in ("flow_loss", "occ_loss", "total_loss"):
+        np.testing.assert_allclose(lc[k], float(ld[k].detach()), rtol=1e-6)
+    tot = np.sqrt(sum(float((v.grad.double() ** 2).sum()) for v in P0.values()))
+    for n in P0:
+        d = float((P1[n].grad.double() - P0[n].grad.double()).norm())
+        assert d <= 2e-4 * float(P0[n].grad.double().norm()) + 1e-6 * tot, (n, d)     # (fp32 summation order of the conv backward)

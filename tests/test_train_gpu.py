@@ -1,0 +1,283 @@
+"""GPU parity of the OPTIMISATION path at the shapes and step counts round 2 left unpinned: the Adam kernel against torch.optim.Adam
+element by element over several steps, three consecutive train steps against the imported reference (eager and hipGraph replay),
+the train step at north_star's second crop (448x1024) against the reference, the full bench shape (32 x 384x448, default routing,
+asynchronous lane) against the oracle run on the host, and the weight-pack cache across hipGraph replays."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(bs):
+    return types.SimpleNamespace(batch_size=bs, model_div_flow=0.05)
+
+
+def _setup(bs, lane=True, capturable=False):
+    import irr_amd
+    from irr_amd import ddp
+    from irr_amd.optim import FusedAdam
+    from irr_amd.train import ModelAndLoss, TrainStep
+    from oracle import irr_pwc_oracle as O
+    m = irr_amd.PWCNet(_args(bs), mask_threshold=0.9999)
+    m.load_state_dict(O.synthetic_params(0), strict=True)
+    m = m.cuda().train()
+    loss = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(_args(bs)).train()
+    mal = ModelAndLoss(_args(bs), m, loss).train()
+    arena = ddp.GradArena(m.named_parameters())
+    if lane:
+        arena.enable_async_wgrad()
+    opt = FusedAdam(m, arena, capturable=capturable)
+    return m, mal, arena, opt, TrainStep(mal, opt, grad_sync=arena.sync)
+
+
+def _batch(B, H, W, seed=1234):
+    from oracle import irr_pwc_oracle as O
+    return {k: v.cuda() for k, v in O.synthetic_batch(B, H, W, seed).items()}
+
+
+@pytest.mark.parametrize("capturable", [False, True])
+def test_adam_kernel_vs_torch_adam_elementwise(capturable):
+    """irr_adam_step_f32 against torch.optim.Adam (what the reference steps with, runtime.py:189 / optim/__init__.py:8-12) on the
+    same flat vectors: FIVE steps with a fresh gradient each, parameters and both moments element by element -- beta1, beta2,
+    both bias corrections, eps and the L2 weight-decay term (lr 1e-4, wd 4e-4 as in scripts/IRR-PWC_flyingChairsOcc.sh:29-31,
+    and a second setting with other values so that no default hides a transposed argument).  n is not a multiple of 4
+    (scalar tail of the float4 kernel)."""
+    from irr_amd import hip
+    n = 100003
+    for lr, b1, b2, eps, wd in ((1e-4, 0.9, 0.999, 1e-8, 4e-4), (3e-3, 0.8, 0.95, 1e-6, 1e-2)):
+        g = torch.Generator().manual_seed(5)
+        p0 = torch.randn(n, generator=g) * 0.05
+        p0[::7] = 0.0                                                  # zero-initialised biases
+        ref = p0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([ref], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+        p, m, v = p0.cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+        step_dev = torch.zeros(1).cuda() if capturable else None
+        for t in range(1, 6):
+            grad = torch.randn(n, generator=g) * (10.0 ** float(torch.randint(-4, 2, (1,), generator=g)))
+            grad[::11] = 0.0
+            ref.grad = grad.clone()
+            opt.step()
+            if capturable:
+                step_dev += 1.0
+            gd = grad.cuda()
+            with hip.device_of(p):
+                hip.call("irr_adam_step_f32", hip.ptr(p), hip.ptr(gd), hip.ptr(m), hip.ptr(v), n, lr, b1, b2, eps, wd,
+                         1.0 - b1 ** t, 1.0 - b2 ** t, 1.0, hip.ptr(step_dev), hip.stream())
+            st = opt.state[ref]
+            np.testing.assert_allclose(m.cpu().numpy(), st["exp_avg"].numpy(), rtol=2e-6, atol=2e-7 * float(st["exp_avg"].abs().max()))
+            np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=2e-6, atol=1e-30)
+            upd, upd_ref = (p.cpu() - p0).numpy(), (ref.detach() - p0).numpy()
+            np.testing.assert_allclose(upd, upd_ref, rtol=2e-4, atol=2e-7 * lr / 1e-4)      # (the update is a difference of fp32 values)
+            np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-9)
+
+
+def _three_steps(step, m, g):
+    names = [str(n) for n in g["param_names"]]
+    sd = dict(m.named_parameters())
+    init = {n: sd[n].detach().double().clone() for n in names}
+    losses, after1 = [], None
+    for i, seed in enumerate(g["seeds"]):
+        ld, _, _ = step(_batch(2, 128, 192, int(seed)))
+        losses.append([float(ld["flow_loss"].detach()), float(ld["occ_loss"].detach()), float(ld["total_loss"].detach())])
+        if i == 0:
+            torch.cuda.synchronize()
+            after1 = {n: sd[n].detach().double().clone() for n in names}
+    torch.cuda.synchronize()
+    d3 = {n: float((sd[n].detach().double() - init[n]).norm()) for n in names}
+    d31 = {n: float((sd[n].detach().double() - after1[n]).norm()) for n in names}
+    full = {str(n): (sd[str(n)].detach().double() - init[str(n)]).cpu().numpy() for n in g["full_names"]}
+    return losses, d3, d31, full
+
+
+@pytest.mark.parametrize("mode", ["eager", "graphed", "torch_adam"])
+def test_three_optimizer_steps_vs_reference(golden_dir, mode, routing):
+    """Three consecutive optimisation steps on three different batches against the imported reference
+    (tests/golden/train3_B2_128x192.npz; checker and tolerances shared with the CPU test that proves they reject a wrong
+    beta1 / beta2 / eps / lr / weight decay): lane + GradArena + FusedAdam, eagerly and as hipGraph replays, and the plain
+    torch.optim.Adam route of train.make_adam."""
+    from train3_check import problems
+    from irr_amd.train import GraphedTrainStep, TrainStep, make_adam
+    g = np.load(os.path.join(golden_dir, "train3_B2_128x192.npz"))
+    m, mal, arena, opt, step = _setup(2, lane=(mode != "torch_adam"), capturable=(mode == "graphed"))
+    try:
+        if mode == "graphed":
+            step = GraphedTrainStep(step)
+        elif mode == "torch_adam":
+            step = TrainStep(mal, make_adam(m.parameters()))
+        res = _three_steps(step, m, g)
+    finally:
+        arena.disable_async_wgrad()
+    print("losses", res[0])
+    bad = problems(g, *res)
+    assert bad == [], bad
+
+
+def test_graphed_step_then_eager_eval_uses_fresh_weights():
+    """A hipGraph replay rewrites the weights through raw pointers (no autograd version counter moves): an EAGER forward between
+    replays (validation) must still see the weights of the LAST step, not packed copies made before it.  Compared with the
+    same sequence run by eager TrainSteps."""
+    from irr_amd.train import GraphedTrainStep
+    evals = {}
+    ev_in = _batch(2, 128, 192, 77)
+    for graphed in (False, True):
+        m, mal, arena, opt, step = _setup(2, lane=True, capturable=graphed)
+        try:
+            if graphed:
+                step = GraphedTrainStep(step)
+            outs = []
+            for seed in (1234, 99, 7, 1234):
+                step({k: v.clone() for k, v in _batch(2, 128, 192, seed).items()})
+                m.eval()
+                with torch.no_grad():
+                    outs.append(m({"input1": ev_in["input1"], "input2": ev_in["input2"]})["flow"].clone())
+                m.train()
+            evals[graphed] = outs
+        finally:
+            arena.disable_async_wgrad()
+    for i, (a, b) in enumerate(zip(evals[False], evals[True])):
+        epe = torch.norm(a - b, dim=1).mean().item()
+        moved = torch.norm(evals[False][i] - evals[False][i - 1], dim=1).mean().item() if i else 1.0
+        print(f"eval after step {i + 1}: EPE graphed vs eager {epe:.2e} px (one step moves the output by {moved:.2e})")
+        assert epe <= 2e-3 and epe < 0.05 * moved, (i, epe, moved)
+
+
+def test_graphed_step_recaptures_when_lr_changes():
+    """the optimiser's hyper-parameters are kernel arguments of the captured launch: a changed lr must take effect"""
+    from irr_amd.train import GraphedTrainStep
+    m, mal, arena, opt, step = _setup(2, lane=True, capturable=True)
+    try:
+        gs = GraphedTrainStep(step)
+        b = _batch(2, 128, 192)
+        gs({k: v.clone() for k, v in b.items()})
+        p0 = opt.param_flat.clone()
+        gs({k: v.clone() for k, v in b.items()})
+        d1 = (opt.param_flat - p0).norm().item()
+        opt.lr = 1e-6
+        p0 = opt.param_flat.clone()
+        gs({k: v.clone() for k, v in b.items()})
+        d2 = (opt.param_flat - p0).norm().item()
+        assert d2 < 0.05 * d1, (d1, d2)
+        with pytest.raises(ValueError):
+            GraphedTrainStep(step, warmup=1)
+    finally:
+        arena.disable_async_wgrad()
+
+
+def test_train_step_B1_448x1024_vs_reference(golden_dir):
+    """north_star's second crop (BASELINE configs[4], Sintel-shaped 448x1024): one train step at B = 1 against the imported
+    reference (tests/golden/e2e_train_B1_448x1024.npz) -- default routing, asynchronous lane: losses, subsampled level-4 and
+    full-resolution outputs of both directions, the 124 gradient norms and sums."""
+    g = np.load(os.path.join(golden_dir, "e2e_train_B1_448x1024.npz"))
+    names = [str(n) for n in g["param_names"]]
+    m, mal, arena, opt, step = _setup(1)
+    try:
+        b = _batch(1, 448, 1024)
+        arena.zero_grad()
+        ld, out = mal(b)
+        ld["total_loss"].backward()
+        arena.sync()
+        torch.cuda.synchronize()
+        got = np.array([float(ld["flow_loss"]), float(ld["occ_loss"]), float(ld["total_loss"])])
+        print("losses", got, "ref", g["robust_train_losses"])
+        np.testing.assert_allclose(got, g["robust_train_losses"], rtol=2e-5)
+        for key, t in (("robust_train_l4_flow_f", out["flow"][4][2][:1, :, ::2, ::2]), ("robust_train_l4_occ_b", out["occ"][4][3][:1, :, ::2, ::2]),
+                       ("robust_train_l6_flow_b", out["flow"][6][1][:1, :, ::8, ::8]), ("robust_train_l6_occ_f", out["occ"][6][0][:1, :, ::8, ::8])):
+            ref = torch.from_numpy(g[key]).cuda()
+            d = (t.detach() - ref).abs().mean().item()
+            assert d <= 1e-4 * max(1.0, ref.abs().mean().item()), (key, d)
+        sd = dict(m.named_parameters())
+        gn = np.array([float(sd[n].grad.double().norm()) for n in names])
+        ref = g["robust_train_gradnorm"]
+        tot, tot_ref = np.sqrt((gn ** 2).sum()), np.sqrt((ref ** 2).sum())
+        print(f"grad-L2 {tot:.3f} ref {tot_ref:.3f}")
+        assert abs(tot - tot_ref) / tot_ref < 1e-4
+        np.testing.assert_allclose(gn, ref, rtol=5e-3, atol=1e-4 * tot_ref)
+        gs = np.array([float(sd[n].grad.double().sum()) for n in names])
+        np.testing.assert_allclose(gs, g["robust_train_gradsum"], rtol=5e-3, atol=2e-4 * tot_ref)
+    finally:
+        arena.disable_async_wgrad()
+
+
+def _vs_chunked_oracle(B, H, W, chunk):
+    from oracle import irr_pwc_oracle as O
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
+    batch = O.synthetic_batch(B, H, W, 1234)
+    P = O.make_trainable(O.synthetic_params(0))
+    ref = O.train_grads_chunked(P, batch, chunk, mask_threshold=0.9999)
+    m, mal, arena, opt, step = _setup(B)
+    try:
+        from irr_amd import conv as C
+        dev = {k: v.cuda() for k, v in batch.items()}
+        C.LAUNCHES.clear()
+        arena.zero_grad()
+        ld, _ = mal(dev)
+        ld["total_loss"].backward()
+        arena.sync()
+        torch.cuda.synchronize()
+        routing = dict(C.LAUNCHES)
+        got = {k: float(ld[k].detach()) for k in ("flow_loss", "occ_loss", "total_loss")}
+        print("losses", got, "oracle", ref, "routing", routing)
+        for k in got:
+            np.testing.assert_allclose(got[k], ref[k], rtol=2e-5)
+        sd = dict(m.named_parameters())
+        tot_ref = np.sqrt(sum(float((P[n].grad.double() ** 2).sum()) for n in P))
+        tot = np.sqrt(sum(float((p.grad.double() ** 2).sum()) for p in sd.values()))
+        print(f"grad-L2 {tot:.4f} oracle {tot_ref:.4f}")
+        assert abs(tot - tot_ref) / tot_ref < 1e-4
+        worst = 0.0
+        for n, p in sd.items():
+            r = P[n].grad.double()
+            d = float((p.grad.double().cpu() - r).norm())
+            worst = max(worst, d / (float(r.norm()) + 1e-4 * tot_ref))
+            assert d <= 2e-3 * float(r.norm()) + 1e-5 * tot_ref, (n, d, float(r.norm()))
+        print(f"worst per-parameter gradient difference vs oracle {worst:.2e} (relative, floor 1e-4 of the total norm)")
+        return routing
+    finally:
+        arena.disable_async_wgrad()
+
+
+def test_bench_shape_bs32_384x448_backward_vs_oracle():
+    """The EXACT bench shape (BASELINE configs[2]: 32 pairs of 384x448 -> 2B = 64 samples, the >= 2 GiB batch-slicing and
+    buffer-range-clamp branches of the weight-gradient kernels), default routing, asynchronous lane: losses (2e-5) and EVERY
+    parameter gradient against the oracle run on the host in chunks of 8 pairs (oracle.train_grads_chunked == the whole-batch
+    step, tests/test_oracle_golden.py)."""
+    routing = _vs_chunked_oracle(32, 384, 448, 8)
+    for fam in ("fwd_x3", "fwd_x3s", "dgrad_x3", "dense_column_x3", "wgrad_x3", "wgrad_x3_dil"):
+        assert routing.get(fam, 0) > 0, (fam, routing)
+
+
+def test_config4_share_bs8_448x1024_backward_vs_oracle():
+    """The per-GPU workload of BASELINE configs[4] (448x1024, 8 pairs): losses and every parameter gradient vs the oracle."""
+    _vs_chunked_oracle(8, 448, 1024, 2)
+
+
+def test_async_wgrad_lane_is_race_free_at_4x384x448():
+    """test_async_wgrad_lane_is_race_free (tests/test_e2e_gpu.py) at a shape whose kernels run for milliseconds: every gradient
+    of four two-stream backward passes equals the single-stream gradient of the same inputs."""
+    m, mal, arena, opt, step = _setup(4, lane=False)
+    b = _batch(4, 384, 448)
+
+    def grads(lane):
+        if lane:
+            arena.enable_async_wgrad()
+        try:
+            arena.zero_grad()
+            ld, _ = mal(b)
+            ld["total_loss"].backward()
+            arena.sync()
+            torch.cuda.synchronize()
+            return arena.flat.clone()
+        finally:
+            if lane:
+                arena.disable_async_wgrad()
+
+    ref = grads(False)
+    for it in range(4):
+        g = grads(True)
+        d = (g - ref).double().norm().item() / ref.double().norm().item()
+        bad = ((g - ref).abs() > 1e-3 * ref.abs() + 1e-4).sum().item()
+        assert d <= 1e-4 and bad == 0, (it, d, bad)

@@ -1,9 +1,14 @@
 """hbm_traffic.json from the two PMC passes (same aggregation as rocpd_traffic.py): {kernel: {launches, avg_us,
-fetch_MB_per_launch_corrected, write_MB_per_launch}}.  usage: rocpd_traffic_json.py fetch.db write.db > profiles/hbm_traffic.json"""
+fetch_MB_per_launch_corrected, write_MB_per_launch}}.  usage: rocpd_traffic_json.py fetch.db write.db > profiles/hbm_traffic.json
+(the json also records the hash of the library sources the passes ran on: irr_amd.build.source_hash())"""
 import json
+import os
 import re
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from irr_amd import build as _build  # noqa: E402
 
 
 def agg(path, counter):
@@ -24,7 +29,7 @@ def agg(path, counter):
 
 f = agg(sys.argv[1], "FETCH_SIZE")
 w = agg(sys.argv[2], "WRITE_SIZE")
-res = {}
+res = {"_source_hash": _build.source_hash()}      # bench.py reports these bytes only for a library built from the same sources
 for k in sorted(f, key=lambda k: -f[k][2])[:40]:
     n = f[k][0]
     wn = max(w.get(k, [1])[0], 1)
