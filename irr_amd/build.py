@@ -56,6 +56,8 @@ if os.environ.get("IRR_WX3_STAGGER"):
     COMMON = COMMON + ["-DWX3_STAGGER=" + os.environ["IRR_WX3_STAGGER"]]
 if os.environ.get("IRR_CORR_ABL"):
     COMMON = COMMON + ["-DCORR_ABL=" + os.environ["IRR_CORR_ABL"]]
+if os.environ.get("IRR_DEFS"):              # generic form: IRR_DEFS="-DWX3_MINI=0 -DWX3_TSTAGE=0"
+    COMMON = COMMON + os.environ["IRR_DEFS"].split()
 if os.environ.get("IRR_WG_TR4"):
     COMMON = COMMON + ["-DWG_TR4=1"]
 if len(COMMON) != _BASE_FLAGS and not TAG:

@@ -26,6 +26,12 @@
 #ifndef WX3_STAGE_OLD
 #define WX3_STAGE_OLD 1  // 1: in eight-wave blocks only waves 0..3 stage (see SWAVES); 0 (A/B): all waves stage
 #endif
+#ifndef WX3_MINI
+#define WX3_MINI 1     // 1: DIL == 1 stages ONE pixel per side of a strip row instead of a whole margin group (see MINI); 0 (A/B): groups
+#endif
+#ifndef WX3_TALL
+#define WX3_TALL 1     // 1: DIL == 1 walks all samples of a strip as one tall image (see TALL); 0 (A/B): one column per sample
+#endif
 #ifndef WX3_ABL
 #define WX3_ABL 0      // ablation builds (timing only): 1 = no operand split (VALU) in the staging path
 #endif
@@ -48,6 +54,7 @@ struct WX3Args {
   int B, Cin, H, W, Cout;
   long x_bs, gy_bs;
   int nstrips, nchunks_y, rows_per_chunk;      // column = (b, strip, row chunk)
+  int tall;                                    // 1: columns = (strip, chunk of the B * (H + 1)-row tall image), see TALL
   long ncols;
   int cols_per_block;
   unsigned long long* dbg;       // WX3_TRACE builds only
@@ -72,7 +79,21 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   constexpr int GPITCH = 2 * R * KG + 1;                   // 16-B units per output channel (two unit buffers)
   constexpr int XPLANE = 32 * NW * XPITCH;                 // 16-B units per piece
   constexpr int GPLANE = 32 * MW * GPITCH;
-  constexpr int XUNITS = R * XG * 32 * NW;                 // (channel, row, group) staging units per step
+  // MINI (DIL == 1): the +-1 column taps need ONE pixel from each neighbour of a strip row (the high half of dword 3 of the left
+  // margin group, the low half of dword 0 of the right one).  Staging whole 32-B margin groups for them doubled the x traffic and
+  // the x split work at KG = 2 (the 96x112 level); a margin is now one dword load, a one-value split and three 4-B LDS stores
+  // into the same slots -- the MFMA waves read exactly what they read before.
+  constexpr bool MINI = WX3_MINI && DIL == 1;
+  // TALL (DIL == 1): a column does not stop at the end of a sample.  The B samples of a strip are walked as ONE image of
+  // B * (H + 1) rows -- sample b's row y is tall row b * (H + 1) + y, the row between two samples reads as zeros (it is the lower
+  // padding row of one sample and the upper one of the next; its gy row is zero too) -- so the ring never has to be refilled:
+  // one prologue per block instead of one per (sample, strip) (at 48x56 a column was 12 units + a 2-unit prologue with its loads
+  // exposed), and the vertical split into chunks can balance the blocks' shares to a unit.
+  const bool TALL = WX3_TALL && DIL == 1 && a.tall;       // (chosen per launch by the host's cost model, see launch_wx3)
+  constexpr int XGS = MINI ? KG : XG;                      // groups of a row staged as full 32-B units
+  constexpr int GOFS = MINI ? MG : 0;                      // ... stored from this group slot on
+  constexpr int XUNITS = R * XGS * 32 * NW;                // (channel, row, group) staging units per step
+  constexpr int MUNITS = MINI ? R * 2 * 32 * NW : 0;       // (channel, row, side) one-pixel margin units per step
   constexpr int GUNITS = R * KG * 32 * MW;
   // Staging waves: with two waves per SIMD the OLDER wave of a SIMD (0..3) runs its MFMAs first and then waits at the barrier
   // while the younger one (4..7), starved until then, computes (tools/wx3_trace.py) -- so the older waves do ALL the staging
@@ -81,6 +102,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   constexpr int SWAVES = (WX3_STAGE_OLD && MW * NW * KW == 8 && (XUNITS + 255) / 256 + (GUNITS + 255) / 256 <= 4) ? 4 : MW * NW * KW;
   constexpr int SNTHR = SWAVES * 64;
   constexpr int XR = (XUNITS + SNTHR - 1) / SNTHR;
+  constexpr int MR = (MUNITS + SNTHR - 1) / SNTHR;
   constexpr int GR = (GUNITS + SNTHR - 1) / SNTHR;
   constexpr int NK = R * KG / 2;                           // MFMA k-steps (16 pixels = two groups) per unit
   static_assert((R * KG) % 2 == 0, "a unit must hold an even number of 8-pixel groups");
@@ -117,22 +139,26 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)a.gy, (short)0, (int)g_bytes, 0x00020000);
 
   // ---- staging roles (fixed per thread) ----
-  int xu_ci[XR], xu_rr[XR], xu_grp[XR];
+  // one register per role: channel | row << 8 | group << 12 (negative: no unit) -- the unit loop runs at 246-256 registers
+  int xu[XR], gu[GR], mu[MR > 0 ? MR : 1];
 #pragma unroll
   for (int r = 0; r < XR; ++r) {
     const int u = r * SNTHR + tid;
-    xu_grp[r] = u % XG;
-    xu_rr[r] = (u / XG) % R;
-    xu_ci[r] = (u < XUNITS && tid < SNTHR) ? u / (XG * R) : -1;
+    xu[r] = (u < XUNITS && tid < SNTHR) ? (u / (XGS * R)) | (((u / XGS) % R) << 8) | ((u % XGS) << 12) : -1;
   }
-  int gu_co[GR], gu_rr[GR], gu_grp[GR];
 #pragma unroll
   for (int r = 0; r < GR; ++r) {
     const int u = r * SNTHR + tid;
-    gu_grp[r] = u % KG;
-    gu_rr[r] = (u / KG) % R;
-    gu_co[r] = (u < GUNITS && tid < SNTHR) ? u / (KG * R) : -1;
+    gu[r] = (u < GUNITS && tid < SNTHR) ? (u / (KG * R)) | (((u / KG) % R) << 8) | ((u % KG) << 12) : -1;
   }
+#pragma unroll
+  for (int r = 0; r < MR; ++r) {                            // "group" = side: 0 left, 1 right
+    const int u = r * SNTHR + tid;
+    mu[r] = (u < MUNITS && tid < SNTHR) ? (u / (2 * R)) | (((u >> 1) % R) << 8) | ((u & 1) << 12) : -1;
+  }
+#define RU_CH(v) ((v) & 255)
+#define RU_RR(v) (((v) >> 8) & 15)
+#define RU_GRP(v) ((v) >> 12)
   float bsum[GR];
 #pragma unroll
   for (int r = 0; r < GR; ++r) bsum[r] = 0.f;
@@ -144,31 +170,58 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   f32x4 xraw[XR][2], graw[GR][2];
+  float mraw[MR > 0 ? MR : 1];
 
   // issue the global loads of x rows [row0, row0+R) and (optionally) gy rows [grow0, grow0+R) of column (b, strip c0)
   // (row0 / grow0 count rows of the residue walk: image row = res + DIL * k)
   const bool stager = wave < SWAVES;
+  const int Hp = a.H + 1;
+  int trow = 0, tb = 0, ty = 0;                            // TALL: tall row trow is row ty of sample tb
   auto issue = [&](int b, int c0, int res, int row0, bool with_x, int grow0, bool with_g) {
     if (!stager) return;
+    // TALL: (sample, row) of the first staged x / gy row (uniform); a thread's row is at most R - 1 further down: one wrap
+    // (tracked from (tb, ty) = sample and row of tall row trow, which the unit loop steps: no division per unit)
+    int xb = b, xy0 = row0, gb0 = b, gy0 = grow0;
+    if (TALL) {
+      xb = tb; xy0 = ty + (row0 - trow);
+      if (xy0 >= Hp) { xy0 -= Hp; ++xb; }
+      if (xy0 < 0) xy0 = -1;                               // the row above the tracked one: a separator / the top padding row
+      gb0 = tb; gy0 = ty + (grow0 - trow);
+      if (gy0 >= Hp) { gy0 -= Hp; ++gb0; }
+    }
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+      int kk = xy0 + RU_RR(mu[r]), bb = xb;
+      if (TALL && kk >= Hp) { kk -= Hp; ++bb; }
+      const int yy = TALL ? kk : (kk < 0 ? -1 : res + DIL * kk);
+      const int xx = RU_GRP(mu[r]) ? c0 + KG * 8 : c0 - 1;
+      const int ci = ci0 + RU_CH(mu[r]);
+      const bool ok = with_x && mu[r] >= 0 && ci < a.Cin && yy >= 0 && yy < a.H && bb < a.B && xx >= 0 && xx < a.W;
+      const uint32_t vo = ok ? (uint32_t)(((long)bb * a.x_bs + (long)ci * hw + (long)yy * a.W + xx) * 4) : OOB;
+      mraw[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)vo, 0, 0));
+    }
 #pragma unroll
     for (int r = 0; r < XR; ++r) {
-      const int kk = row0 + xu_rr[r];
-      const int yy = kk < 0 ? -1 : res + DIL * kk;
-      const int xx = c0 + (xu_grp[r] - MG) * 8;
-      const int ci = ci0 + xu_ci[r];
-      const bool ok = with_x && xu_ci[r] >= 0 && ci < a.Cin && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-      const uint32_t vo = ok ? (uint32_t)(((long)b * a.x_bs + (long)ci * hw + (long)yy * a.W + xx) * 4) : OOB;
+      int kk = xy0 + RU_RR(xu[r]), bb = xb;
+      if (TALL && kk >= Hp) { kk -= Hp; ++bb; }
+      const int yy = TALL ? kk : (kk < 0 ? -1 : res + DIL * kk);
+      const int xx = c0 + (RU_GRP(xu[r]) + GOFS - MG) * 8;
+      const int ci = ci0 + RU_CH(xu[r]);
+      const bool ok = with_x && xu[r] >= 0 && ci < a.Cin && yy >= 0 && yy < a.H && bb < a.B && xx >= 0 && xx < a.W;
+      const uint32_t vo = ok ? (uint32_t)(((long)bb * a.x_bs + (long)ci * hw + (long)yy * a.W + xx) * 4) : OOB;
       // (W % 4 == 0: a group may straddle the end of the row -- its second half then reads zeros)
       xraw[r][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)vo, 0, 0));
       xraw[r][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)((ok && xx + 4 < a.W) ? vo + 16 : OOB), 0, 0));
     }
 #pragma unroll
     for (int r = 0; r < GR; ++r) {
-      const int yy = res + DIL * (grow0 + gu_rr[r]);
-      const int xx = c0 + gu_grp[r] * 8;
-      const int co = co0 + gu_co[r];
-      const bool ok = with_g && gu_co[r] >= 0 && co < a.Cout && yy >= 0 && yy < a.H && xx < a.W;
-      const uint32_t vo = ok ? (uint32_t)(((long)b * a.gy_bs + (long)co * hw + (long)yy * a.W + xx) * 4) : OOB;
+      int kk = gy0 + RU_RR(gu[r]), bb = gb0;
+      if (TALL && kk >= Hp) { kk -= Hp; ++bb; }
+      const int yy = TALL ? kk : res + DIL * kk;
+      const int xx = c0 + RU_GRP(gu[r]) * 8;
+      const int co = co0 + RU_CH(gu[r]);
+      const bool ok = with_g && gu[r] >= 0 && co < a.Cout && yy >= 0 && yy < a.H && bb < a.B && xx < a.W;
+      const uint32_t vo = ok ? (uint32_t)(((long)bb * a.gy_bs + (long)co * hw + (long)yy * a.W + xx) * 4) : OOB;
       graw[r][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)vo, 0, 0));
       graw[r][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)((ok && xx + 4 < a.W) ? vo + 16 : OOB), 0, 0));
     }
@@ -178,8 +231,29 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     if (!stager) return;
     if (with_x) {
 #pragma unroll
+      for (int r = 0; r < MR; ++r) {
+        if (mu[r] < 0) continue;
+        // one value -> three bf16 pieces (same rounding sequence as split8), each into its half-dword of the margin slot
+        const float v0 = mraw[r];
+        const uint32_t hp = pk_bf16(v0, 0.f);
+        float r0 = v0 - lo_f(hp);
+        asm volatile("" : "+v"(r0));
+        const uint32_t mp = pk_bf16(r0, 0.f);
+        float s0 = r0 - lo_f(mp);
+        asm volatile("" : "+v"(s0));
+        const uint32_t lp = pk_bf16(s0, 0.f);
+        const int side = RU_GRP(mu[r]);
+        const int slot = (row0 + RU_RR(mu[r]) + RING) % RING;
+        const int idx = RU_CH(mu[r]) * XPITCH + slot * XG + (side ? KG + MG : MG - 1);
+        uint32_t* const w = (uint32_t*)xs + idx * 4 + (side ? 0 : 3);
+        const int sh = side ? 0 : 16;                        // left margin: pixel c0-1 is the HIGH half of dword 3
+        w[0] = (hp & 0xffffu) << sh;
+        w[XPLANE * 4] = (mp & 0xffffu) << sh;
+        w[2 * XPLANE * 4] = (lp & 0xffffu) << sh;
+      }
+#pragma unroll
       for (int r = 0; r < XR; ++r) {
-        if (xu_ci[r] < 0) continue;
+        if (xu[r] < 0) continue;
         float v[8] = {xraw[r][0][0], xraw[r][0][1], xraw[r][0][2], xraw[r][0][3], xraw[r][1][0], xraw[r][1][1], xraw[r][1][2], xraw[r][1][3]};
         u32x4 h, m, l;
 #if WX3_ABL == 1
@@ -187,8 +261,8 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
 #else
         split8(v, h, m, l);
 #endif
-        const int slot = (row0 + xu_rr[r] + RING) % RING;          // rows >= -1
-        const int idx = xu_ci[r] * XPITCH + slot * XG + xu_grp[r];
+        const int slot = (row0 + RU_RR(xu[r]) + RING) % RING;      // rows >= -1
+        const int idx = RU_CH(xu[r]) * XPITCH + slot * XG + RU_GRP(xu[r]) + GOFS;
         xs[idx] = h;
         xs[idx + XPLANE] = m;
         xs[idx + 2 * XPLANE] = l;
@@ -197,7 +271,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     if (with_g) {
 #pragma unroll
       for (int r = 0; r < GR; ++r) {
-        if (gu_co[r] < 0) continue;
+        if (gu[r] < 0) continue;
         float v[8] = {graw[r][0][0], graw[r][0][1], graw[r][0][2], graw[r][0][3], graw[r][1][0], graw[r][1][1], graw[r][1][2], graw[r][1][3]};
         bsum[r] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         u32x4 h, m, l;
@@ -206,7 +280,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
 #else
         split8(v, h, m, l);
 #endif
-        const int idx = gu_co[r] * GPITCH + (gbuf * R + gu_rr[r]) * KG + gu_grp[r];
+        const int idx = RU_CH(gu[r]) * GPITCH + (gbuf * R + RU_RR(gu[r])) * KG + RU_GRP(gu[r]);
         gs[idx] = h;
         gs[idx + GPLANE] = m;
         gs[idx + 2 * GPLANE] = l;
@@ -220,16 +294,28 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   // the 54 MFMAs x NK of one unit: gy rows of unit buffer gbuf against x rows y-1 .. y+R.
   // Flat software pipeline over stages (ks, dy, B piece q): the LDS reads of stage s+1 are issued ahead of the MFMAs of
   // stage s; sched_barriers keep the compiler from hoisting more than that (144 of the 256 registers are accumulators).
+  // (Round 3 measured nine-MFMA stages with three B-piece buffers -- every read issued >= 288 cycles ahead of its use instead of
+  // 96 .. 288: 2-4 % SLOWER on every shape.  LDS latency is not what holds a lone wave at 70 % MFMA density)
   auto compute = [&](int y, int gbuf) {
-    constexpr int NS = (NK / KW) * 9;                      // this wave's k-steps: wk, wk + KW, ...
-    u32x4 ob[2], lb[2], rb[2];                             // the group and its left / right neighbours (DIL <= 2: one dword each)
+    constexpr int NKW = NK / KW;                           // this wave's k-steps: wk, wk + KW, ...
     u32x4 af[3];
-    auto read_b = [&](int sel, int st) {
-      const int ks = wk + KW * (st / 9), dy = (st % 9) / 3, q = st % 3;
+    auto b_index = [&](int ki, int dy, int q) {
+      const int ks = wk + KW * ki;
       const int gi = 2 * ks + g;
       const int row = gi / KG, grp = gi - row * KG;
       const int slot = (y + row + dy - 1 + RING) % RING;
-      const int xi = b_base + slot * XG + grp + MG + q * XPLANE;
+      return b_base + slot * XG + grp + MG + q * XPLANE;
+    };
+    auto read_a1 = [&](int ki, int p) {
+      const int ks = wk + KW * ki;
+      const int gi = 2 * ks + g;
+      const int row = gi / KG, grp = gi - row * KG;
+      af[p] = gs[a_base + (gbuf * R + row) * KG + grp + p * GPLANE];
+    };
+    constexpr int NS = NKW * 9;
+    u32x4 ob[2], lb[2], rb[2];                             // the group and its left / right neighbours (DIL <= 2: one dword each)
+    auto read_b = [&](int sel, int st) {
+      const int xi = b_index(st / 9, (st % 9) / 3, st % 3);
       ob[sel] = xs[xi];
       if (WX3_ABL == 2) {
       } else if (DIL <= 2) {
@@ -246,11 +332,8 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       }
     };
     auto read_a = [&](int ki) {
-      const int ks = wk + KW * ki;
-      const int gi = 2 * ks + g;
-      const int row = gi / KG, grp = gi - row * KG;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[p] = gs[a_base + (gbuf * R + row) * KG + grp + p * GPLANE];
+      for (int p = 0; p < 3; ++p) read_a1(ki, p);
     };
     read_a(0);
     read_b(0, 0);
@@ -324,9 +407,10 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       }
     }
     const int c0 = strip * KG * 8;
-    const int hk = (a.H - res + DIL - 1) / DIL;              // rows of this residue walk
+    const int hk = TALL ? a.B * Hp : (a.H - res + DIL - 1) / DIL;   // rows of this walk (TALL: all samples, b stays 0)
     const int ya = chunk * a.rows_per_chunk;
     const int yb = min(hk, ya + a.rows_per_chunk);
+    if (TALL) { trow = ya; tb = ya / Hp; ty = ya - tb * Hp; }
     // prologue: x rows ya-1 .. ya+R and the first gy unit
     __syncthreads();
     for (int r0 = ya - 1; r0 <= ya + R; r0 += R) {
@@ -364,6 +448,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       __syncthreads();
       WTR(5);
       gbuf ^= 1;
+      if (TALL) { trow += R; ty += R; if (ty >= Hp) { ty -= Hp; ++tb; } }
     }
   }
 
@@ -414,7 +499,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
 #pragma unroll
       for (int off = 1; off < PER; off <<= 1) s += __shfl_xor(s, off, 64);
       const int u = r * SNTHR + tid;
-      if (gu_co[r] >= 0 && (u % PER) == 0 && co0 + gu_co[r] < a.Cout) unsafeAtomicAdd(a.gbias + co0 + gu_co[r], a.alpha * s);
+      if (gu[r] >= 0 && (u % PER) == 0 && co0 + RU_CH(gu[r]) < a.Cout) unsafeAtomicAdd(a.gbias + co0 + RU_CH(gu[r]), a.alpha * s);
     }
   }
 }
@@ -462,9 +547,10 @@ int launch_wx3(WX3Args a, hipStream_t st) {
   // a flush of 9 * 32 MW * 32 NW partial sums, a fixed cost per block that a second round doubles (measured with the
   // earlier atomic flush: one round is 2-7 % faster at 96x112, 10-25 % at 48x56, 15-45 % at 24x28)
   const long want = cu_count() / ((long)gy_ * gz_) > 0 ? cu_count() / ((long)gy_ * gz_) : 1;
+  // Cost model (units of R rows): a block walks cols_per_block columns of ceil(rows / R) units + a ring-fill prologue worth ~2.
+  constexpr double PROLOGUE = 2.0;
+  // (a) one column per (sample, strip, residue), split vertically into 1, 2, 4 or 8 row chunks
   const int hk = (a.H + DIL - 1) / DIL;                     // rows of the longest residue walk
-  // columns (b, strip, residue) are split vertically into 1, 2, 4 or 8 row chunks: the split that makes the blocks' equal
-  // shares of columns the cheapest (a block walks cols_per_block columns of rows + ring-fill rows each)
   int rows = hk;
   a.nchunks_y = 1;
   double best = 1e30;
@@ -474,11 +560,27 @@ int launch_wx3(WX3Args a, hipStream_t st) {
     const int nch = (hk + rc - 1) / rc;
     const long ncols = (long)a.B * a.nstrips * DIL * nch;
     const long cpb = (ncols + want - 1) / want;
-    const double t = (double)cpb * (rc + 2);
+    const double t = (double)cpb * ((rc + R - 1) / R + PROLOGUE);
     if (t < best * 0.97) { best = t; rows = rc; a.nchunks_y = nch; }
   }
   a.rows_per_chunk = rows;
   a.ncols = (long)a.B * a.nstrips * DIL * a.nchunks_y;
+  a.tall = 0;
+  if (WX3_TALL && DIL == 1 && !IRR_ENV_FLAG("IRR_WX3_NO_TALL")) {
+    // (b) columns = (strip, chunk of the tall image of B * (H + 1) rows), any number of chunks: one extra row per sample, but a
+    // block's share is ONE column (one prologue) and the shares are equal to a unit
+    const long tk = (long)a.B * (a.H + 1);
+    const long cmax = 4 * want > 64 ? 4 * want : 64;
+    for (long c = 1; c <= cmax; ++c) {
+      const long rc = ((tk + c - 1) / c + R - 1) / R * R;
+      if (c > 1 && rc < 8 * R) break;
+      const long nch = (tk + rc - 1) / rc;
+      const long ncols = (long)a.nstrips * nch;
+      const long cpb = (ncols + want - 1) / want;
+      const double t = (double)cpb * ((double)(rc / R) + PROLOGUE);
+      if (t < best * 0.99) { best = t; a.tall = 1; a.rows_per_chunk = (int)rc; a.nchunks_y = (int)nch; a.ncols = ncols; }
+    }
+  }
   a.cols_per_block = (int)((a.ncols + want - 1) / want);
   if (a.cols_per_block < 1) a.cols_per_block = 1;
   a.ngx = irr_cdiv(a.ncols, a.cols_per_block); a.ngy = gy_; a.ngz = gz_;
