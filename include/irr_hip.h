@@ -220,6 +220,19 @@ int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, 
 long irr_conv2d_wgrad_x3_ws_elems(int Cin, int Cout);
 int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                         int B, int Cin, int H, int W, int Cout, long x_bs, long gy_bs, void* stream);
+/* ---- deferred fold of the partial images ---------------------------------------------------------------------------------------
+ * Every irr_conv2d_wgrad_{f32,x3,x3_dil} launch ends with a small kernel that folds the partial images of its scratch into gw.
+ * Between irr_wgrad_defer_begin(jobs, capacity) and irr_wgrad_defer_end() ON THE CALLING THREAD those launchers append a job
+ * record (irr_wgrad_job_bytes() bytes, layout private to the library) to the HOST array `jobs` instead (a launch whose scratch is
+ * reused by a second batch slice, or one that finds the array full, still folds immediately); irr_wgrad_defer_end returns the
+ * number of records appended.  The caller keeps ws and gw alive and runs irr_wgrad_reduce_batch(jobs, njobs <=
+ * irr_wgrad_reduce_batch_max(), stream) on the same stream before gw is read; two jobs of one batch must not share a gw
+ * (IRR_EINVAL).  Same arithmetic and summation order as the immediate fold: results are bit-identical. */
+int irr_wgrad_job_bytes(void);
+int irr_wgrad_reduce_batch_max(void);
+int irr_wgrad_defer_begin(void* jobs, int capacity);
+int irr_wgrad_defer_end(void);
+int irr_wgrad_reduce_batch(const void* jobs, int njobs, void* stream);
 /* the dilated layers of the context networks (dil in {2,4,8,16}, accepted when irr_conv2d_wgrad_x3_eligible says so) */
 int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                             int B, int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs, void* stream);

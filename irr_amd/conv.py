@@ -372,10 +372,50 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
     return gx
 
 
+class ReduceBatch:
+    """Fold jobs of weight-gradient launches whose partial images have not been added to their gradients yet
+    (include/irr_hip.h, "deferred fold"): the MFMA weight-gradient launchers append a job here instead of running their own
+    10-20 us fold kernel, and ``run()`` folds all of them with ONE launch.  Holds the scratch tensors alive until then."""
+
+    def __init__(self):
+        lib = hip.lib()
+        self.jb = lib.irr_wgrad_job_bytes()
+        self.cap = lib.irr_wgrad_reduce_batch_max()
+        self.buf = ctypes.create_string_buffer(self.jb * self.cap)
+        self.n = 0
+        self.keep = []                   # scratch (and gradient) tensors of the pending jobs
+        self.targets = set()             # data_ptr of the gradients with a pending job: a batch folds into each at most once
+
+    def begin(self):
+        hip.lib().irr_wgrad_defer_begin(ctypes.addressof(self.buf) + self.n * self.jb, self.cap - self.n)
+
+    def end(self, ws: torch.Tensor, gw: torch.Tensor):
+        got = hip.lib().irr_wgrad_defer_end()
+        if got:
+            self.n += got
+            self.keep += [ws, gw]
+            self.targets.add(gw.data_ptr())
+
+    def full_for(self, gw: torch.Tensor) -> bool:
+        return self.n >= self.cap - 1 or gw.data_ptr() in self.targets
+
+    def run(self):
+        """launch the fold of every pending job on the current stream; returns the tensors that must outlive it"""
+        keep = self.keep
+        if self.n:
+            with hip.device_of(keep[0]):
+                hip.call("irr_wgrad_reduce_batch", ctypes.addressof(self.buf), self.n, hip.stream())
+            LAUNCHES["wgrad_reduce_batch"] += 1
+        self.n, self.keep, self.targets = 0, [], set()
+        return keep
+
+
 def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil: int,
-               gw: Optional[torch.Tensor] = None, gbias: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+               gw: Optional[torch.Tensor] = None, gbias: Optional[torch.Tensor] = None, alpha: float = 1.0,
+               defer: Optional[ReduceBatch] = None) -> torch.Tensor:
     """gw += d/dW; gw (Cout,Cin,k,k) is created zeroed when not given.  gbias (optional, (Cout,)) += sum of gy over
-    (b, h, w): the bias gradient comes out of the same launch (the gy tiles are staged there anyway)."""
+    (b, h, w): the bias gradient comes out of the same launch (the gy tiles are staged there anyway).
+    ``defer``: the MFMA kernels leave the fold of their partial images to ``defer.run()`` (gw is complete only after it)."""
     cout, cin, k, _ = weight_shape
     B, _, H, W = x.shape
     _, _, oh, ow = gy.shape
@@ -403,16 +443,21 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
         hip.call("irr_conv2d_smallco_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W, cout, k, dil,
                  hip.bs(x), hip.bs(gy), hip.stream())
         return gw
-    if use_x3 and dil > 1:
-        hip.call("irr_conv2d_wgrad_x3_dil", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
-                 cout, dil, hip.bs(x), hip.bs(gy), hip.stream())
-        return gw
-    if use_x3:
-        hip.call("irr_conv2d_wgrad_x3", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
-                 cout, hip.bs(x), hip.bs(gy), hip.stream())
-        return gw
-    hip.call("irr_conv2d_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W, cout, oh, ow, k, stride, dil,
-             hip.bs(x), hip.bs(gy), nws, hip.stream())
+    if defer is not None:
+        defer.begin()
+    try:
+        if use_x3 and dil > 1:
+            hip.call("irr_conv2d_wgrad_x3_dil", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
+                     cout, dil, hip.bs(x), hip.bs(gy), hip.stream())
+        elif use_x3:
+            hip.call("irr_conv2d_wgrad_x3", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
+                     cout, hip.bs(x), hip.bs(gy), hip.stream())
+        else:
+            hip.call("irr_conv2d_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W, cout, oh, ow, k, stride, dil,
+                     hip.bs(x), hip.bs(gy), nws, hip.stream())
+    finally:
+        if defer is not None:
+            defer.end(ws, gw)
     return gw
 
 
@@ -434,7 +479,10 @@ class WgradSide:
         # makes the allocator record one (system-scope) event on the lane per freed tensor -- 500 per step (A/B switch: 1 = on)
         self.record_streams = os.environ.get("IRR_LANE_RECORD_STREAM", "0") != "0"
         self._inflight = collections.deque()    # (done marker on the lane, tensors its launch reads)
-        self.on_launch = None                   # optional hook(weight, bias) after each routed launch (ddp: early buckets)
+        self.on_launch = None                   # optional hook(weight, bias) once a routed gradient is complete (ddp: early buckets)
+        # the ~210 partial-image folds of a step run as a few batched launches (ReduceBatch); IRR_LANE_BATCH_REDUCE=0: A/B
+        self.batch = ReduceBatch() if os.environ.get("IRR_LANE_BATCH_REDUCE", "1") != "0" else None
+        self._pending = []                      # (weight, bias) of launches whose fold has not been launched yet
 
     def route(self, weight, bias):
         gw = self.views.get(id(weight))
@@ -443,13 +491,28 @@ class WgradSide:
         gb = self.views.get(id(bias)) if bias is not None else None
         return gw, gb
 
-    def launch(self, fn, tensors, params=(None, None)):
+    def flush(self):
+        """fold every pending partial image (one launch on the lane) and report the gradients that are complete now"""
+        if self.batch is not None and self.batch.n:
+            with torch.cuda.stream(self.stream):
+                keep = self.batch.run()
+                done = torch.cuda.Event()
+                done.record(self.stream)
+            self._inflight.append((done, keep))
+        pending, self._pending = self._pending, []
+        if self.on_launch is not None:
+            for p_ in pending:
+                self.on_launch(*p_)
+
+    def launch(self, fn, tensors, params=(None, None), gw=None):
         """Run ``fn`` on the lane after everything enqueued so far on the current stream.  The tensors it reads are kept
         ALIVE (strong references) until the lane has passed the launch: (a) the caching allocator cannot recycle them, and
         (b) a tensor with a second owner is never accumulated into IN PLACE by the autograd engine (InputBuffer::accumulate
         only steals a gradient whose use_count is 1), nor handed to a consumer as its exclusive property -- whatever the
         model code around the node does with the same gradient tensor (``a = a + b`` feeding two nodes,
         models/pwcnet_irr*.py)."""
+        if self.batch is not None and gw is not None and self.batch.full_for(gw):
+            self.flush()
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(main)
@@ -467,10 +530,12 @@ class WgradSide:
         if not capturing:                                      # (an event recorded inside a capture cannot be queried)
             while self._inflight and self._inflight[0][0].query():
                 self._inflight.popleft()
-        if self.on_launch is not None:
-            self.on_launch(*params)
+        self._pending.append(params)
+        if self.batch is None or not self.batch.n:
+            self.flush()                                       # nothing deferred: the gradient is complete already
 
     def join(self):
+        self.flush()
         torch.cuda.current_stream().wait_stream(self.stream)
         self._inflight.clear()                   # later work on the current stream is ordered after the lane
 
@@ -487,7 +552,8 @@ def wgrad_param(x, gy, weight, bias, stride: int, dil: int, want_bias: bool = Tr
     if routed is not None:
         gwv, gbv = routed
         SIDE.launch(lambda: conv_wgrad(x, gy, weight.shape, stride, dil, gw=gwv, gbias=gbv if want_bias else None,
-                                       alpha=alpha), (x, gy), (weight, bias if (want_bias and gbv is not None) else None))
+                                       alpha=alpha, defer=SIDE.batch), (x, gy),
+                    (weight, bias if (want_bias and gbv is not None) else None), gw=gwv)
         return None, None
     if acc is not None:
         gw, gb = acc

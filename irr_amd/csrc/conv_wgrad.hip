@@ -14,6 +14,7 @@
 // interleaved with the MFMAs of the current stage.  Split-K partials are added with COALESCED fp32 atomics
 // into a [co][tap][ci] workspace (lanes = ci are contiguous) and then folded into dW[co][ci][tap].
 #include "common.h"
+#include "wgrad_reduce.h"
 #include <stdlib.h>
 
 #ifndef WG_ABL
@@ -520,23 +521,10 @@ int dispatch(const WgArgs& a, hipStream_t st) {
 
 // gw[co][ci][tap] += sum over the P block columns of ws[p][co][tap][ci]: 256 threads = 64 consecutive workspace elements
 // x 4 column lanes (coalesced reads), fixed summation order -> no atomics, no zeroed workspace, reproducible bits.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw, int Cin, int KK,
-                                                          long n, int P) {
+// (body shared with the batched fold of many launches: wgrad_reduce.h)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const IrrReduceJob J) {
   __shared__ float red[3][64];
-  const int jl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const long j = (long)blockIdx.x * 64 + jl;
-  float s = 0.f;
-  if (j < n)
-    for (int p = pl; p < P; p += 4) s += ws[(long)p * n + j];
-  if (pl > 0) red[pl - 1][jl] = s;
-  __syncthreads();
-  if (pl > 0 || j >= n) return;
-  s = ((s + red[0][jl]) + red[1][jl]) + red[2][jl];
-  const int ci = (int)(j % Cin);
-  const long r = j / Cin;
-  const int tap = (int)(r % KK);
-  const long co = r / KK;
-  gw[(co * Cin + ci) * KK + tap] += s;
+  irr_reduce_block(J, blockIdx.x, red);
 }
 
 // gpre = gy * lrelu'(y) ; gbias[c] += sum_p gpre
@@ -731,13 +719,19 @@ extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
     const int rc = wgrad_slice(a, k, stride, dil, (hipStream_t)stream);
     if (rc) return rc;
     if (!atomic) {
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, ws, gw, Cin, k * k, n,
-                         (int)g_parts);
-      IRR_LAUNCH_CHECK();
+      // (the scratch is reused by the next batch slice: only a single-slice launch may defer its fold)
+      if (!(per >= B && irr_reduce_defer(ws, gw, n, (int)g_parts, Cin, Cout, k * k, 0))) {
+        IrrReduceJob J{};
+        J.ws = ws; J.gw = gw; J.n = n; J.P = (int)g_parts; J.Cin = Cin; J.Cout = Cout; J.KK = k * k;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, J);
+        IRR_LAUNCH_CHECK();
+      }
     }
   }
   if (atomic) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, ws, gw, Cin, k * k, n, 1);
+    IrrReduceJob J{};
+    J.ws = ws; J.gw = gw; J.n = n; J.P = 1; J.Cin = Cin; J.Cout = Cout; J.KK = k * k;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, J);
     IRR_LAUNCH_CHECK();
   }
   return 0;

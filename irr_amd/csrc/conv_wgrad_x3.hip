@@ -18,6 +18,7 @@
 //     [co][tap][ci] workspace that wgrad_unpack_kernel (conv_wgrad.hip) folds into dW; the bias gradient is summed by
 //     the gy stagers (fixed channel per thread) and added once per block.
 #include "x3_split.h"
+#include "wgrad_reduce.h"
 #include <stdlib.h>
 
 #ifndef WX3_STAGGER
@@ -613,28 +614,20 @@ static int pick_kg(int W) {
 }  // namespace
 
 // gw[co][ci][tap] += sum over the P partials of ws[p][co][tap][ci]   (swapped: the launch ran with the operand roles
-// exchanged, see below, and produced ws[p][ci][8-tap][co]).  256 threads = 64 consecutive workspace elements x 4 partial
-// lanes (coalesced 256-B reads per partial), fixed summation order.
-__global__ __launch_bounds__(256) void wgrad_reduce_x3_kernel(const float* __restrict__ ws, float* __restrict__ gw, int Cin, int Cout,
-                                                             int swapped, long n, int P) {
+// exchanged, see below, and produced ws[p][ci][8-tap][co]).  Body shared with the batched fold: wgrad_reduce.h.
+__global__ __launch_bounds__(256) void wgrad_reduce_x3_kernel(const IrrReduceJob J) {
   __shared__ float red[3][64];
-  const int jl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const long j = (long)blockIdx.x * 64 + jl;
-  float s = 0.f;
-  if (j < n)
-    for (int p = pl; p < P; p += 4) s += ws[(long)p * n + j];
-  if (pl > 0) red[pl - 1][jl] = s;
-  __syncthreads();
-  if (pl > 0 || j >= n) return;
-  s = ((s + red[0][jl]) + red[1][jl]) + red[2][jl];
-  // workspace element j = [c1][t][c2] with c2 the fastest (the "input channel" role of the launch)
-  const int d2 = swapped ? Cout : Cin;
-  const int c2 = (int)(j % d2);
-  const long r = j / d2;
-  const int t = (int)(r % 9);
-  const long c1 = r / 9;
-  const long dst = swapped ? ((long)c2 * Cin + c1) * 9 + (8 - t) : (c1 * Cin + c2) * 9 + t;
-  gw[dst] += s;
+  irr_reduce_block(J, blockIdx.x, red);
+}
+
+// fold now, or -- between irr_wgrad_defer_begin / _end -- leave a job for irr_wgrad_reduce_batch
+static int reduce_or_defer(const float* ws, float* gw, long n, int P, int Cin, int Cout, int swapped, bool may_defer, hipStream_t st) {
+  if (may_defer && irr_reduce_defer(ws, gw, n, P, Cin, Cout, 9, swapped)) return 0;
+  IrrReduceJob J{};
+  J.ws = ws; J.gw = gw; J.n = n; J.P = P; J.Cin = Cin; J.Cout = Cout; J.KK = 9; J.swapped = swapped;
+  hipLaunchKernelGGL(wgrad_reduce_x3_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, st, J);
+  IRR_LAUNCH_CHECK();
+  return 0;
 }
 
 // gbias[c] += alpha * sum over (b, pixels) of gy (used when the gy stagers of the main kernel cannot provide it)
@@ -721,8 +714,9 @@ extern "C" int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* g
       default: rc = launch_dil<2, 16>(a, kg, st); break;
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_x3_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, st, ws, gw, Cin, Cout, 0, n, g_last_parts);
-    IRR_LAUNCH_CHECK();
+    // (the scratch is reused by the next batch slice: only a single-slice launch may defer its fold)
+    const int rr = reduce_or_defer(ws, gw, n, g_last_parts, Cin, Cout, 0, per >= B, st);
+    if (rr) return rr;
   }
   return 0;
 }
@@ -776,9 +770,8 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
       rc = kg == 4 ? launch_wx3<3, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<3, 2, 2, 2>(a, st) : launch_wx3<3, 2, 1, 4>(a, st);
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_x3_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, st, ws, gw, Cin, Cout, swapped ? 1 : 0, n,
-                       g_last_parts);
-    IRR_LAUNCH_CHECK();
+    const int rr = reduce_or_defer(ws, gw, n, g_last_parts, Cin, Cout, swapped ? 1 : 0, per >= B, st);
+    if (rr) return rr;
   }
   if (swapped && gbias) {
     const int chunk = 8192;

@@ -1,0 +1,58 @@
+// Deferred reduction of the weight-gradient kernels' partial images (conv_wgrad.hip, conv_wgrad_x3.hip).
+// Every weight-gradient launch leaves P partial [c1][tap][c2] images in its scratch and a tiny second kernel folds them into
+// dW in a fixed order (bit-reproducible, no atomics).  A train step has ~210 of those folds, 10-20 us each, on the
+// asynchronous weight-gradient lane where they queue behind millisecond kernels.  Between irr_wgrad_defer_begin() and
+// irr_wgrad_defer_end() on the calling thread the launchers append a job record instead, and ONE launch of
+// irr_wgrad_reduce_batch() folds up to IRR_REDUCE_BATCH_MAX of them (jobs travel by value in the kernel arguments).
+#pragma once
+#include "common.h"
+
+struct IrrReduceJob {         // opaque to the host (irr_wgrad_job_bytes())
+  const float* ws;            // P partial images of n floats each
+  float* gw;                  // (Cout, Cin, k, k) gradient, accumulated into
+  long n;                     // Cout * k*k * Cin
+  int P;
+  int Cin, Cout, KK;
+  int swapped;                // the launch ran with the operand roles exchanged: ws[p][ci][8 - tap][co]
+  int block0;                 // first 256-thread block of the job inside the batched launch
+};
+
+#define IRR_REDUCE_BATCH_MAX 40
+
+struct IrrReduceCollector {
+  IrrReduceJob* jobs;         // host memory owned by the caller of irr_wgrad_defer_begin
+  int capacity, count;
+};
+extern thread_local IrrReduceCollector g_irr_reduce_collector;
+
+// true: the job was recorded and the launcher must NOT run its own reduce kernel
+static inline bool irr_reduce_defer(const float* ws, float* gw, long n, int P, int Cin, int Cout, int KK, int swapped) {
+  IrrReduceCollector& c = g_irr_reduce_collector;
+  if (!c.jobs || c.count >= c.capacity) return false;
+  IrrReduceJob j{};
+  j.ws = ws; j.gw = gw; j.n = n; j.P = P; j.Cin = Cin; j.Cout = Cout; j.KK = KK; j.swapped = swapped; j.block0 = 0;
+  c.jobs[c.count++] = j;
+  return true;
+}
+static inline bool irr_reduce_deferring() { return g_irr_reduce_collector.jobs != nullptr; }
+
+// one (job, 64 consecutive workspace elements): 256 threads = 64 elements x 4 partial lanes, fixed summation order
+__device__ __forceinline__ void irr_reduce_block(const IrrReduceJob& J, long blk, float (*red)[64]) {
+  const int jl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const long j = blk * 64 + jl;
+  float s = 0.f;
+  if (j < J.n)
+    for (int p = pl; p < J.P; p += 4) s += J.ws[(long)p * J.n + j];
+  if (pl > 0) red[pl - 1][jl] = s;
+  __syncthreads();
+  if (pl > 0 || j >= J.n) return;
+  s = ((s + red[0][jl]) + red[1][jl]) + red[2][jl];
+  // workspace element j = [c1][t][c2] with c2 the fastest (the "input channel" role of the launch)
+  const int d2 = J.swapped ? J.Cout : J.Cin;
+  const int c2 = (int)(j % d2);
+  const long r = j / d2;
+  const int t = (int)(r % J.KK);
+  const long c1 = r / J.KK;
+  const long dst = J.swapped ? ((long)c2 * J.Cin + c1) * J.KK + (J.KK - 1 - t) : (c1 * J.Cin + c2) * J.KK + t;
+  J.gw[dst] += s;
+}

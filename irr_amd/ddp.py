@@ -201,6 +201,8 @@ class GradArena:
 
     def disable_async_wgrad(self):
         from . import conv
+        if self._side_lane is not None:
+            self._side_lane.join()                      # (folds whatever the lane still holds as partial images)
         if self._side_lane is not None and conv.SIDE is self._side_lane:
             conv.SIDE = None
         self._side_lane = None

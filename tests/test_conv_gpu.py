@@ -677,3 +677,46 @@ def test_x3_sub_pack_combined_column_launch_vs_fp64(x3_everywhere):
         e = (Gd[:, t0:t1].cpu().double() - ref).abs().max().item() / ref.abs().max().item()
         assert e <= 5e-6, (k_, e)
         assert torch.equal(Gd[:, :t0].cpu(), G0[:, :t0]) and torch.equal(Gd[:, t1:].cpu(), G0[:, t1:])      # nothing else touched
+
+
+def test_deferred_batched_fold_is_bit_identical_to_immediate():
+    """The fold of the weight-gradient partial images, deferred into ONE batched launch (conv.ReduceBatch, what the
+    asynchronous lane uses), against the launch-by-launch fold: same bits, for the x3 family (plain, role-swapped,
+    dilated, K-split) and the fp32 family; a gradient that already has a pending fold forces a flush."""
+    from irr_amd import conv as C, hip
+    old = hip.lib().irr_conv_x3_set_min_blocks(0)
+    try:
+        cases = [(64, 128, 2, 24, 32, 1), (40, 32, 1, 16, 48, 1), (32, 32, 2, 24, 64, 1), (128, 96, 1, 40, 56, 8), (24, 48, 2, 12, 14, 1),
+                 (96, 64, 1, 20, 28, 1)]
+        g = torch.Generator().manual_seed(3)
+        data = []
+        for cin, cout, B, H, W, dil in cases:
+            data.append((torch.randn(B, cin, H, W, generator=g).cuda(), torch.randn(B, cout, H, W, generator=g).cuda(), cin, cout, dil))
+        ref = []
+        for x, gy, cin, cout, dil in data:
+            gw, gb = torch.zeros(cout, cin, 3, 3, device="cuda"), torch.zeros(cout, device="cuda")
+            C.conv_wgrad(x, gy, (cout, cin, 3, 3), 1, dil, gw=gw, gbias=gb, alpha=0.5)
+            ref.append((gw, gb))
+        batch = C.ReduceBatch()
+        got = []
+        for x, gy, cin, cout, dil in data:
+            gw, gb = torch.zeros(cout, cin, 3, 3, device="cuda"), torch.zeros(cout, device="cuda")
+            C.conv_wgrad(x, gy, (cout, cin, 3, 3), 1, dil, gw=gw, gbias=gb, alpha=0.5, defer=batch)
+            got.append((gw, gb))
+        assert batch.n == len(cases) and all(float(gw.abs().max()) == 0.0 for gw, _ in got)     # nothing folded yet
+        assert batch.full_for(got[0][0]) and not batch.full_for(torch.zeros(4, device="cuda"))
+        keep = batch.run()
+        assert batch.n == 0 and len(keep) == 2 * len(cases)
+        torch.cuda.synchronize()
+        for (gw, gb), (rw, rb) in zip(got, ref):
+            assert torch.equal(gw, rw) and float(rw.abs().max()) > 0
+            np.testing.assert_allclose(gb.cpu().numpy(), rb.cpu().numpy(), rtol=1e-5, atol=1e-5)     # (bias sums use atomics)
+        # two folds into ONE gradient in a single batch are refused by the library
+        x, gy, cin, cout, dil = data[0]
+        gw = torch.zeros(cout, cin, 3, 3, device="cuda")
+        C.conv_wgrad(x, gy, (cout, cin, 3, 3), 1, dil, gw=gw, defer=batch)
+        C.conv_wgrad(x, gy, (cout, cin, 3, 3), 1, dil, gw=gw, defer=batch)
+        with pytest.raises(hip.HipError):
+            batch.run()
+    finally:
+        hip.lib().irr_conv_x3_set_min_blocks(old)
