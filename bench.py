@@ -174,6 +174,8 @@ def main():
     arena = ddp.GradArena(model.named_parameters())
     if not a.no_async_wgrad:
         arena.enable_async_wgrad()
+    elif not os.environ.get("IRR_BENCH_AUTOGRAD_WGRAD"):     # single stream: still accumulate straight into the arena
+        arena.enable_direct_wgrad()
     opt = FusedAdam(model, arena, lr=1e-4, weight_decay=4e-4)
 
     def barrier():

@@ -470,10 +470,13 @@ class WgradSide:
     (or a whole coarse-level launch, which cannot fill 256 CUs) leaves idle.  Autograd then receives ``None`` for
     those parameters; GradArena.sync() joins the lane before the all-reduce / optimizer step."""
 
-    def __init__(self, views):
+    def __init__(self, views, inline: bool = False):
         self.views = views                      # id(parameter) -> flat-arena view with the parameter's shape
         dev = next(iter(views.values())).device
-        self.stream = torch.cuda.Stream(device=dev)
+        # inline: no second stream -- the launches stay on the current stream, but still accumulate straight into the arena
+        # (no per-use gradient tensors, no autograd accumulation adds, one batched fold): GradArena.enable_direct_wgrad()
+        self.inline = inline
+        self.stream = None if inline else torch.cuda.Stream(device=dev)
         # The references in _inflight are dropped only after the lane has passed the launch (marker) or after the current stream
         # has joined the lane, so the caching allocator can never hand the memory out early; Tensor.record_stream on top of that
         # makes the allocator record one (system-scope) event on the lane per freed tensor -- 500 per step (A/B switch: 1 = on)
@@ -494,11 +497,14 @@ class WgradSide:
     def flush(self):
         """fold every pending partial image (one launch on the lane) and report the gradients that are complete now"""
         if self.batch is not None and self.batch.n:
-            with torch.cuda.stream(self.stream):
-                keep = self.batch.run()
-                done = torch.cuda.Event()
-                done.record(self.stream)
-            self._inflight.append((done, keep))
+            if self.inline:
+                self.batch.run()                               # (same stream: the allocator orders any reuse after the fold)
+            else:
+                with torch.cuda.stream(self.stream):
+                    keep = self.batch.run()
+                    done = torch.cuda.Event()
+                    done.record(self.stream)
+                self._inflight.append((done, keep))
         pending, self._pending = self._pending, []
         if self.on_launch is not None:
             for p_ in pending:
@@ -513,6 +519,12 @@ class WgradSide:
         models/pwcnet_irr*.py)."""
         if self.batch is not None and gw is not None and self.batch.full_for(gw):
             self.flush()
+        if self.inline:
+            fn()
+            self._pending.append(params)
+            if self.batch is None or not self.batch.n:
+                self.flush()
+            return
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(main)
@@ -536,6 +548,8 @@ class WgradSide:
 
     def join(self):
         self.flush()
+        if self.inline:
+            return
         torch.cuda.current_stream().wait_stream(self.stream)
         self._inflight.clear()                   # later work on the current stream is ordered after the lane
 
@@ -918,6 +932,21 @@ def conv_chain(x, layers, res=None):
 # ----------------------------------------------------------------------------------------------
 # autograd: OccUpsampleNetwork (models/irr_modules.py:30-56) as ONE node
 # ----------------------------------------------------------------------------------------------
+def _padded_cin(weight: torch.Tensor, cpad: int) -> torch.Tensor:
+    """persistent copy of ``weight`` (Cout, Cin, k, k) with its input channels zero-padded to ``cpad`` -- refreshed when the
+    parameter changed (same tag as the packed-weight caches); its own packed copies follow through its version counter"""
+    holder = weight.__dict__.setdefault("_irr_cinpad", {})
+    w = weight.detach()
+    tag = _weight_tag(w)
+    hit = holder.get(cpad)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    wp = hit[1] if hit is not None else torch.zeros(w.shape[0], cpad, w.shape[2], w.shape[3], device=w.device, dtype=torch.float32)
+    wp[:, :w.shape[1]].copy_(w)
+    holder[cpad] = (tag, wp)
+    return wp
+
+
 class _OccUpsampleFn(hip.Function):
     """x_in -> init_conv -> 3 x [x += 0.1 * res_convs(x)] (shared weights) -> x_init + res_end_conv(x) -> out_convs + occ.
 
@@ -925,13 +954,33 @@ class _OccUpsampleFn(hip.Function):
     SURVEY.md Appendix A (iv)), so elementwise passes are expensive here.  The backward therefore uses the
     epilogue features of the MFMA data-gradient launch for every skip connection and activation:
     ``g_x = g_y + dgrad(...)`` (res), ``0.1 *`` (alpha), ``*= LeakyReLU'(t)`` (mask) and ``+=`` (accumulate);
-    bias gradients come from the wgrad launches."""
+    bias gradients come from the wgrad launches.
+
+    The input arrives as its parts (nearest-x2 occlusion map first, then the guide tensors of models/IRR_PWC.py:166-167): they
+    are copied straight into the channel slices of ONE buffer (no torch.cat of the 10-channel guide and again of the 11-channel
+    input at full resolution).  When the bf16x3 streaming kernel accepts the problem with 16 input channels, that buffer gets
+    16 channels (five of them zero) and init_conv runs there with zero-padded weights -- forward and data gradient: the 11 -> 32
+    layer at 384x448 was the largest launch left on the fp32-MFMA kernels (1.35 ms at 52 TFLOP/s; the streaming kernel is bound by
+    writing the 32-channel map).  The weight gradient reads the 11 real channels of the same buffer."""
 
     @staticmethod
-    def forward(ctx, occ_up, x_in, w_init, b_init, w_r0, b_r0, w_r1, b_r1, w_end, b_end, w_out, b_out, mul_const):
-        x_in = x_in if _planes_dense(x_in) else x_in.contiguous()
-        occ_up = occ_up if _planes_dense(occ_up) else occ_up.contiguous()
-        x_init = conv_forward(x_in, w_init, b_init, 1, 1, True)
+    def forward(ctx, nparts, mul_const, *args):
+        parts = args[:nparts]
+        w_init, b_init, w_r0, b_r0, w_r1, b_r1, w_end, b_end, w_out, b_out = args[nparts:]
+        occ_up = parts[0] if _planes_dense(parts[0]) else parts[0].contiguous()
+        B, _, H, W = occ_up.shape
+        widths = tuple(int(p_.shape[1]) for p_ in parts)
+        cin = sum(widths)
+        cpad = 16 if (cin < 16 and x3_code(B, 16, H, W, w_init.shape[0], 3, 1, 1)) else cin
+        x_in = torch.empty(B, cpad, H, W, device=occ_up.device, dtype=torch.float32)
+        c0 = 0
+        for p_, wd in zip(parts, widths):
+            x_in[:, c0:c0 + wd].copy_(p_)
+            c0 += wd
+        if cpad > cin:
+            x_in[:, cin:].zero_()
+        w_first = _padded_cin(w_init, cpad) if cpad > cin else w_init
+        x_init = conv_forward(x_in, w_first, b_init, 1, 1, True)
         xs = [x_init]
         ts = []
         for _ in range(3):
@@ -943,6 +992,7 @@ class _OccUpsampleFn(hip.Function):
         o = conv_forward(x2, w_out, b_out, 1, 1, True)
         out = torch.add(o, occ_up)
         ctx.mul_const = mul_const
+        ctx.widths = widths
         ctx.wobjs = (w_init, w_r0, w_r1, w_end, w_out)
         ctx.bobjs = (b_init, b_r0, b_r1, b_end, b_out)
         ctx.save_for_backward(x_in, xs[0], xs[1], xs[2], xs[3], ts[0], ts[1], ts[2], e, x2, o)
@@ -954,6 +1004,9 @@ class _OccUpsampleFn(hip.Function):
         w_init, w_r0, w_r1, w_end, w_out = ctx.wobjs
         b_init, b_r0, b_r1, b_end, b_out = ctx.bobjs
         mc = ctx.mul_const
+        widths = ctx.widths
+        nparts = len(widths)
+        cin = sum(widths)
         dev = g_out.device
         hw_ = x0.shape[2:]
         g_out = g_out if _planes_dense(g_out) else g_out.contiguous()
@@ -988,15 +1041,28 @@ class _OccUpsampleFn(hip.Function):
         gw_r0, gb_r0 = acc_r0 if acc_r0 is not None else (None, None)
         gw_r1, gb_r1 = acc_r1 if acc_r1 is not None else (None, None)
         gpre_init = g_x2
-        gw_init, gb_init = wgrad_param(x_in, gpre_init, w_init, b_init, 1, 1)
-        g_xin = conv_dgrad(gpre_init, w_init, 1, 1, hw_) if ctx.needs_input_grad[1] else None
-        g_occ_up = g_out if ctx.needs_input_grad[0] else None
-        return (g_occ_up, g_xin, gw_init, gb_init, gw_r0, gb_r0, gw_r1, gb_r1, gw_end, gb_end, gw_out, gb_out, None)
+        x_real = x_in[:, :cin] if x_in.shape[1] > cin else x_in
+        gw_init, gb_init = wgrad_param(x_real, gpre_init, w_init, b_init, 1, 1)
+        gparts = [None] * nparts
+        if any(ctx.needs_input_grad[2:2 + nparts]):
+            w_first = _padded_cin(w_init, x_in.shape[1]) if x_in.shape[1] > cin else w_init
+            g_xin = conv_dgrad(gpre_init, w_first, 1, 1, hw_)
+            c0 = 0
+            for i, wd in enumerate(widths):
+                if ctx.needs_input_grad[2 + i]:
+                    gparts[i] = g_xin[:, c0:c0 + wd]
+                c0 += wd
+        if ctx.needs_input_grad[2]:                           # occ_up: channel 0 of the input AND the final skip
+            gparts[0] = g_out + gparts[0] if gparts[0] is not None else g_out
+        return (None, None, *gparts, gw_init, gb_init, gw_r0, gb_r0, gw_r1, gb_r1, gw_end, gb_end, gw_out, gb_out)
 
 
-def occ_upsample_net(occ_up, x_in, mod):
-    """mod: modules.OccUpsampleNetwork.  occ_up = nearest-x2 occlusion map, x_in = cat([occ_up, guide])."""
-    return _OccUpsampleFn.apply(occ_up, x_in, mod.init_conv.weight, mod.init_conv.bias, mod.res_convs[0].weight,
+def occ_upsample_net(occ_up, guide, mod):
+    """mod: modules.OccUpsampleNetwork.  occ_up = nearest-x2 occlusion map, guide = the guide tensor or the sequence of tensors
+    whose channel concatenation it is; the network's input is cat([occ_up, guide])."""
+    parts = (occ_up,) + (tuple(guide) if isinstance(guide, (list, tuple)) else (guide,))
+    if not all(p_.is_cuda for p_ in parts):
+        raise RuntimeError("irr_amd conv runs on the HIP device only (no CPU fallback)")
+    return _OccUpsampleFn.apply(len(parts), float(mod.mul_const), *parts, mod.init_conv.weight, mod.init_conv.bias, mod.res_convs[0].weight,
                                 mod.res_convs[0].bias, mod.res_convs[1].weight, mod.res_convs[1].bias,
-                                mod.res_end_conv.weight, mod.res_end_conv.bias, mod.out_convs.weight, mod.out_convs.bias,
-                                float(mod.mul_const))
+                                mod.res_end_conv.weight, mod.res_end_conv.bias, mod.out_convs.weight, mod.out_convs.bias)

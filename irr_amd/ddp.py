@@ -157,7 +157,7 @@ class GradArena:
         if self.overlap:
             # the bucket's contributions were enqueued on the main stream (autograd) and / or on the weight-gradient lane
             self._side.wait_stream(torch.cuda.current_stream())
-            if self._side_lane is not None:
+            if self._side_lane is not None and self._side_lane.stream is not None:
                 self._side.wait_stream(self._side_lane.stream)
             with torch.cuda.stream(self._side):
                 self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -194,6 +194,16 @@ class GradArena:
         its critical path.  Autograd no longer sees those gradients; the lane reports each contribution instead."""
         from . import conv
         self._side_lane = conv.WgradSide({id(p): p.grad for _, p in self.order})
+        if self.world > 1:
+            self._side_lane.on_launch = self._on_lane
+        conv.SIDE = self._side_lane
+        self.recalibrate()
+
+    def enable_direct_wgrad(self):
+        """The same routing WITHOUT a second stream: the weight-gradient launches stay on the current stream but accumulate
+        straight into this arena (no per-use gradient tensors, no autograd accumulation adds, batched folds)."""
+        from . import conv
+        self._side_lane = conv.WgradSide({id(p): p.grad for _, p in self.order}, inline=True)
         if self.world > 1:
             self._side_lane.on_launch = self._on_lane
         conv.SIDE = self._side_lane

@@ -232,7 +232,7 @@ class PWCNet(nn.Module):
                     x_in, xo_w_in = _split_halves(both)
                 else:
                     x_in, xo_w_in = x, xo_warp
-                occ = self.occ_shuffle_upsample(occ, torch.cat([x_in, xo_w_in, flow, flow_o_warp], dim=1))
+                occ = self.occ_shuffle_upsample(occ, [x_in, xo_w_in, flow, flow_o_warp])
                 occs.append(list(_split_halves(occ)))
 
         if self.training:

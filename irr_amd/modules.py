@@ -182,8 +182,9 @@ class OccUpsampleNetwork(nn.Module):
         self.out_convs = conv(self.feat_dim, ch_out)
 
     def forward(self, occ, x):
-        occ = Fn.upsample_factor2(occ, x)
-        return C.occ_upsample_net(occ, torch.cat([occ, x], dim=1), self)
+        """x: the 10-channel guide, or the sequence of tensors whose channel concatenation it is"""
+        occ = Fn.upsample_factor2(occ, x[0] if isinstance(x, (list, tuple)) else x)
+        return C.occ_upsample_net(occ, x, self)
 
 
 def subtract_mean(t):

@@ -8,7 +8,7 @@ from irr_amd.optim import FusedAdam
 from irr_amd.train import ModelAndLoss, TrainStep
 import bench
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 32
 args = types.SimpleNamespace(batch_size=B, model_div_flow=0.05)
 torch.manual_seed(0)
 model = irr_amd.PWCNet(args).cuda().train()
@@ -58,6 +58,14 @@ print(f"total conv time {tot:.1f} ms, {sum(v[1] for v in agg.values())/1e12:.2f}
 print(f"{'kind':10s} {'cin':>4s} {'cout':>4s} {'oh':>4s} {'ow':>4s} k dil {'n':>3s} {'ms':>8s} {'TF':>7s} {'%':>5s}")
 for key, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:70]:
     print(f"{key[0]:10s} {key[1]:4d} {key[2]:4d} {key[3]:4d} {key[4]:4d} {key[5]} {key[6]:3d} {v[0]:3d} {v[2]:8.2f} {v[1]/v[2]/1e9:7.1f} {100*v[2]/tot:5.1f}")
+if "--fp32" in sys.argv:
+    print("every fp32-family launch shape:")
+    t32 = 0.0
+    for key, v in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+        if key[0] in ("fwd/dgrad", "wgrad"):
+            t32 += v[2]
+            print(f"{key[0]:10s} {key[1]:4d} {key[2]:4d} {key[3]:4d} {key[4]:4d} {key[5]} {key[6]:3d} {v[0]:3d} {v[2]:8.3f} {v[1]/v[2]/1e9:7.1f}")
+    print(f"fp32 family total {t32:.2f} ms")
 # by level
 lev = collections.OrderedDict()
 for key, v in agg.items():
