@@ -177,6 +177,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   // (row0 / grow0 count rows of the residue walk: image row = res + DIL * k)
   const bool stager = wave < SWAVES;
   const int Hp = a.H + 1;
+  const bool narrow = (a.W & 3) != 0;                      // (uniform)
   int trow = 0, tb = 0, ty = 0;                            // TALL: tall row trow is row ty of sample tb
   auto issue = [&](int b, int c0, int res, int row0, bool with_x, int grow0, bool with_g) {
     if (!stager) return;
@@ -185,10 +186,10 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     int xb = b, xy0 = row0, gb0 = b, gy0 = grow0;
     if (TALL) {
       xb = tb; xy0 = ty + (row0 - trow);
-      if (xy0 >= Hp) { xy0 -= Hp; ++xb; }
+      while (xy0 >= Hp) { xy0 -= Hp; ++xb; }               // (uniform; one or two turns: the rows are at most 2R + 1 <= 9 ahead)
       if (xy0 < 0) xy0 = -1;                               // the row above the tracked one: a separator / the top padding row
       gb0 = tb; gy0 = ty + (grow0 - trow);
-      if (gy0 >= Hp) { gy0 -= Hp; ++gb0; }
+      while (gy0 >= Hp) { gy0 -= Hp; ++gb0; }
     }
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
@@ -210,9 +211,17 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       const int ci = ci0 + RU_CH(xu[r]);
       const bool ok = with_x && xu[r] >= 0 && ci < a.Cin && yy >= 0 && yy < a.H && bb < a.B && xx >= 0 && xx < a.W;
       const uint32_t vo = ok ? (uint32_t)(((long)bb * a.x_bs + (long)ci * hw + (long)yy * a.W + xx) * 4) : OOB;
-      // (W % 4 == 0: a group may straddle the end of the row -- its second half then reads zeros)
-      xraw[r][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)vo, 0, 0));
-      xraw[r][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)((ok && xx + 4 < a.W) ? vo + 16 : OOB), 0, 0));
+      if (!narrow) {
+        // (W % 4 == 0: a group may straddle the end of the row -- its second half then reads zeros)
+        xraw[r][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)vo, 0, 0));
+        xraw[r][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)((ok && xx + 4 < a.W) ? vo + 16 : OOB), 0, 0));
+      } else {
+        // rows that are not a multiple of four pixels (the 6x7 / 12x14 pyramid levels): element-wise loads, every pixel beyond
+        // the row end answered with 0 by the bounds check (and never touched: the last row may end the tensor)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          xraw[r][e >> 2][e & 3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)((ok && xx + e < a.W) ? vo + 4 * e : OOB), 0, 0));
+      }
     }
 #pragma unroll
     for (int r = 0; r < GR; ++r) {
@@ -223,8 +232,14 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       const int co = co0 + RU_CH(gu[r]);
       const bool ok = with_g && gu[r] >= 0 && co < a.Cout && yy >= 0 && yy < a.H && bb < a.B && xx < a.W;
       const uint32_t vo = ok ? (uint32_t)(((long)bb * a.gy_bs + (long)co * hw + (long)yy * a.W + xx) * 4) : OOB;
-      graw[r][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)vo, 0, 0));
-      graw[r][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)((ok && xx + 4 < a.W) ? vo + 16 : OOB), 0, 0));
+      if (!narrow) {
+        graw[r][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)vo, 0, 0));
+        graw[r][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)((ok && xx + 4 < a.W) ? vo + 16 : OOB), 0, 0));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          graw[r][e >> 2][e & 3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, (int)((ok && xx + e < a.W) ? vo + 4 * e : OOB), 0, 0));
+      }
     }
   };
   // split the loaded units and publish them: x rows [row0, row0+R) into their ring slots, gy rows into unit buffer gbuf
@@ -574,7 +589,7 @@ int launch_wx3(WX3Args a, hipStream_t st) {
     const long cmax = 4 * want > 64 ? 4 * want : 64;
     for (long c = 1; c <= cmax; ++c) {
       const long rc = ((tk + c - 1) / c + R - 1) / R * R;
-      if (c > 1 && rc < 8 * R) break;
+      if (c > 1 && rc < R) break;
       const long nch = (tk + rc - 1) / rc;
       const long ncols = (long)a.nstrips * nch;
       const long cpb = (ncols + want - 1) / want;
@@ -668,10 +683,15 @@ extern "C" long irr_conv2d_wgrad_x3_ws_elems(int Cin, int Cout) { return (Cin > 
 extern "C" int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil) {
   if (k != 3 || stride != 1 || B <= 0) return 0;
   if (dil != 1 && !(W % 8 == 0 && W >= 32 && Cin >= 64 && dil_ok(Cout, W, dil))) return 0;
-  if (W % 4) return 0;
   if (dil != 1) return 5000 + dil;
-  if (W < 24 || H < 8 || Cin < 8) return 0;
-  if ((long)B * H * W < 40000 && irr_conv_x3_set_min_blocks(-1) > 0) return 0;    // small levels stay on the fp32 kernels
+  // Any width >= 7 (rows that are not a multiple of four pixels load element-wise) and, with the tall-image walk, any height:
+  // the 6x7 and 12x14 pyramid levels ran on the fp32 kernel at 4-40 TFLOP/s (85 launches, 5.5 ms per step).
+  // IRR_WX3_NO_SMALL=1 (A/B): the round-2 limits.
+  if (IRR_ENV_FLAG("IRR_WX3_NO_SMALL") || !WX3_TALL) {
+    if ((W % 4) || W < 24 || H < 8) return 0;
+    if ((long)B * H * W < 40000 && irr_conv_x3_set_min_blocks(-1) > 0) return 0;
+  }
+  if (W < 7 || H < 3 || Cin < 8) return 0;
   const int kg = pick_kg(W);
   const int cot = (Cout + 31) / 32;
   if (cot == 1 && Cin <= 32) return W % 32 == 0 ? 1144 : 1124;             // <1,1,4,4,KW=8> / <1,1,2,4,KW=4>
@@ -723,7 +743,8 @@ extern "C" int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* g
 
 extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
                                    int Cin, int H, int W, int Cout, long x_bs, long gy_bs, void* stream) {
-  if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (W % 4)) return IRR_EINVAL;
+  if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return IRR_EINVAL;
+  if ((W % 4) && (((uintptr_t)x | (uintptr_t)gy) & 3)) return IRR_EINVAL;
   const long n = (long)Cout * Cin * 9;
   hipStream_t st = (hipStream_t)stream;
   const int kg = pick_kg(W);

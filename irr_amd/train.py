@@ -90,6 +90,13 @@ class GraphedTrainStep:
                              "(use TrainStep with GradArena.sync)")
         if getattr(step.optimizer, "capturable", False) is not True:
             raise ValueError("GraphedTrainStep needs an optimizer whose step count lives on the device (FusedAdam(capturable=True))")
+        side = _conv.SIDE
+        if side is None or getattr(side, "inline", False):
+            # Measured in round 3 (tools/graph_step.py, LANE=none / LANE=direct): replays of a step captured WITHOUT the lane drift
+            # or produce NaN -- with the lane, every tensor a weight-gradient launch reads stays alive until the join at the end of
+            # backward; without it the capture-time allocator recycles them inside the graph and some reuse is not covered by the
+            # captured order.  Until that is understood the graphed step is only offered in the configuration the tests pin.
+            raise ValueError("GraphedTrainStep needs the asynchronous weight-gradient lane (GradArena.enable_async_wgrad())")
         if warmup < 2:
             # step 1 builds the packed weights one by one, step 2 builds the job table of the batched pack launch (a pageable
             # host-to-device copy): neither may happen inside the capture

@@ -165,6 +165,8 @@ def test_graphed_step_recaptures_when_lr_changes():
             GraphedTrainStep(step, warmup=1)
     finally:
         arena.disable_async_wgrad()
+    with pytest.raises(ValueError):                  # (only the lane configuration is validated for capture)
+        GraphedTrainStep(step)
 
 
 def test_train_step_B1_448x1024_vs_reference(golden_dir):
@@ -281,3 +283,31 @@ def test_async_wgrad_lane_is_race_free_at_4x384x448():
         d = (g - ref).double().norm().item() / ref.double().norm().item()
         bad = ((g - ref).abs() > 1e-3 * ref.abs() + 1e-4).sum().item()
         assert d <= 1e-4 and bad == 0, (it, d, bad)
+
+
+def test_direct_wgrad_same_stream_matches_autograd_path():
+    """GradArena.enable_direct_wgrad(): weight gradients accumulated straight into the arena on the CURRENT stream (batched
+    folds, no per-use gradient tensors) == the gradients autograd accumulates, and == the asynchronous lane."""
+    m, mal, arena, opt, step = _setup(2, lane=False)
+    b = _batch(2, 128, 192)
+
+    def grads(mode):
+        if mode == "direct":
+            arena.enable_direct_wgrad()
+        elif mode == "lane":
+            arena.enable_async_wgrad()
+        try:
+            arena.zero_grad()
+            ld, _ = mal(b)
+            ld["total_loss"].backward()
+            arena.sync()
+            torch.cuda.synchronize()
+            return arena.flat.clone()
+        finally:
+            arena.disable_async_wgrad()
+
+    ref = grads("autograd")
+    for mode in ("direct", "lane", "direct"):
+        g = grads(mode)
+        d = (g - ref).double().norm().item() / ref.double().norm().item()
+        assert d <= 1e-5, (mode, d)

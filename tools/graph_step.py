@@ -24,7 +24,10 @@ def make(graph):
     model = irr_amd.PWCNet(args).cuda().train()
     loss = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(args).train()
     arena = ddp.GradArena(model.named_parameters())
-    arena.enable_async_wgrad()
+    if os.environ.get("LANE", "async") == "direct":        # single stream, gradients accumulated straight into the arena
+        arena.enable_direct_wgrad()
+    elif os.environ.get("LANE", "async") != "none":          # "none": weight gradients through autograd
+        arena.enable_async_wgrad()
     step = TrainStep(ModelAndLoss(args, model, loss), FusedAdam(model, arena, capturable=graph), grad_sync=arena.sync)
     return model, arena, (GraphedTrainStep(step) if graph else step)
 

@@ -12,10 +12,18 @@ ACC = [  # cin, cout, B, H, W
     (115, 128, 2, 24, 32), (40, 128, 1, 16, 48), (371, 96, 1, 12, 56), (64, 128, 2, 8, 40), (35, 96, 1, 20, 64), (565, 128, 1, 8, 112),
     (128, 128, 2, 16, 16), (467, 64, 1, 16, 48), (64, 64, 2, 12, 56), (531, 32, 1, 16, 48), (64, 9, 2, 12, 56), (300, 32, 1, 8, 64), (32, 32, 2, 24, 64), (32, 9, 1, 16, 96), (24, 32, 2, 20, 32), (243, 128, 2, 24, 28), (11, 32, 2, 16, 64), (64, 64, 1, 12, 44), (371, 96, 1, 10, 36), (531, 32, 1, 24, 28),
 ]
+ACC += [  # round 3: widths that are not a multiple of four, heights below 8 (tall-image walk), odd batches
+    (565, 128, 8, 6, 7), (128, 128, 4, 12, 14), (371, 96, 6, 6, 7), (64, 32, 8, 12, 14), (32, 32, 8, 6, 7), (115, 128, 5, 12, 14),
+    (64, 64, 3, 6, 7), (467, 64, 7, 12, 14), (531, 32, 9, 6, 7), (40, 128, 6, 5, 10), (64, 96, 5, 3, 9), (35, 128, 11, 4, 20), (128, 64, 3, 9, 22),
+]
 ACC_DIL = [(128, 128, 1, 24, 32, 2), (128, 128, 2, 19, 48, 4), (128, 96, 1, 40, 56, 8), (96, 64, 1, 50, 48, 16), (128, 128, 1, 20, 56, 2),
            (128, 128, 1, 33, 64, 4), (128, 96, 2, 24, 64, 8), (96, 64, 2, 40, 64, 16)]
 PERF_DIL = [("ctx d2 L4", 128, 128, 64, 96, 112, 2), ("ctx d4 L4", 128, 128, 64, 96, 112, 4), ("ctx d8 L4", 128, 96, 64, 96, 112, 8),
             ("ctx d16 L4", 96, 64, 64, 96, 112, 16), ("ctx d2 L3", 128, 128, 64, 48, 56, 2), ("ctx d8 L3", 128, 96, 64, 48, 56, 8)]
+PERF_SMALL = [("ctx.conv0 L1", 565, 128, 64, 12, 14), ("refine 128->128 L1", 128, 128, 64, 12, 14), ("dense.conv4 L1", 467, 64, 64, 12, 14),
+              ("dense.conv5 L1", 531, 32, 64, 12, 14), ("refine 64->32 L1", 64, 32, 64, 12, 14), ("refine 32->32 L1", 32, 32, 64, 12, 14),
+              ("ctx.conv0 L0", 565, 128, 64, 6, 7), ("refine 128->128 L0", 128, 128, 64, 6, 7), ("dense.conv4 L0", 467, 64, 64, 6, 7),
+              ("dense.conv5 L0", 531, 32, 64, 6, 7), ("refine 64->32 L0", 64, 32, 64, 6, 7), ("refine 32->32 L0", 32, 32, 64, 6, 7)]
 PERF = [("ctx.conv0 L4", 565, 128, 64, 96, 112), ("dense.conv1 L4", 115, 128, 64, 96, 112), ("dense.conv3 L4", 371, 96, 64, 96, 112),
         ("refine 128->128 L4", 128, 128, 64, 96, 112), ("dense.conv2 L3", 243, 128, 64, 48, 56), ("ctx.conv0 L3", 565, 128, 64, 48, 56),
         ("128->128 448x1024 L4", 128, 128, 16, 112, 256), ("dense.conv4 L4", 467, 64, 64, 96, 112), ("refine 128->64 L4", 128, 64, 64, 96, 112),
@@ -48,7 +56,7 @@ def main():
     if "--noperf" in sys.argv:
         return
     print("== speed ==")
-    for case in PERF_DIL + PERF:
+    for case in (PERF_SMALL if "--small" in sys.argv else PERF_DIL + PERF + PERF_SMALL):
         if os.environ.get("WX3_ONLY") and os.environ["WX3_ONLY"] not in case[0]:
             continue
         name, cin, cout, B, H, W = case[:6]
