@@ -755,7 +755,13 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
   // unpack kernel transposes and flips the taps.  The bias gradient then comes from a separate pass over the small gy.
   const bool ksplit = cot == 1 && Cin <= 32;               // one (co, ci) tile: eight (four) wave groups split the pixels
   const bool k4 = (cot == 1 && Cin > 32 && Cin <= 64) || (cot == 2 && Cin <= 32);   // two tiles: 2 waves x 4 pixel groups
-  const bool swapped = cot == 1 && !ksplit;
+  // Exchanged roles with FOUR "output-channel" waves over Cin x one "input" tile of Cout x two pixel wave groups (<4,1,*,*,2>):
+  //   * Cout = 96 (three co-tiles): the direct 3 x 2 block has six waves -- two SIMDs carry two of them, two carry one;
+  //   * Cout <= 32 with a Cin tile count that fills the eight-wave column badly (531 channels = 17 tiles: 24 slots).
+  const int cit = (Cin + 31) / 32;
+  const bool sw4 = !IRR_ENV_FLAG("IRR_WX3_NO_SW4") && !ksplit && !k4 &&
+                   ((cot == 3 && cit >= 4) || (cot == 1 && (cit + 7) / 8 * 8 * 5 >= (cit + 3) / 4 * 4 * 6));   // (the eight-wave column pads >= 1.2 x as much)
+  const bool swapped = (cot == 1 && !ksplit) || sw4;
   WX3Args a;
   a.ws = ws; a.gbias = swapped ? nullptr : gbias; a.alpha = alpha;
   a.H = H; a.W = W;
@@ -777,6 +783,8 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
       rc = W % 32 == 0 ? launch_wx3<1, 1, 4, 4, 8>(a, st) : launch_wx3<1, 1, 2, 4, 4>(a, st);
     } else if (k4) {
       rc = launch_wx3<2, 1, 2, 4, 4>(a, st);
+    } else if (sw4) {
+      rc = kg == 4 ? launch_wx3<4, 1, 4, 1, 2>(a, st) : kg == 2 ? launch_wx3<4, 1, 2, 2, 2>(a, st) : launch_wx3<4, 1, 1, 4, 2>(a, st);
     } else if (swapped) {
       rc = kg == 4 ? launch_wx3<8, 1, 4, 1>(a, st) : kg == 2 ? launch_wx3<8, 1, 2, 2>(a, st) : launch_wx3<8, 1, 1, 4>(a, st);
     } else if (cot == 2) {

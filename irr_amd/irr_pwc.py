@@ -234,6 +234,8 @@ class PWCNet(nn.Module):
                     x_in, xo_w_in = x, xo_warp
                 occ = self.occ_shuffle_upsample(occ, [x_in, xo_w_in, flow, flow_o_warp])
                 occs.append(list(_split_halves(occ)))
+            if l == self.__dict__.get("_debug_last_level", -1):      # tools/level_times.py: truncated passes (never set otherwise)
+                break
 
         if self.training:
             return {'flow': flows, 'occ': occs}
