@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide: v_mfma_f32_32x32x16_bf16, dense
 X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0   # conv_x3: six bf16 MFMA products per fp32 product (exact 3-way split)
-X3_PLANES = {1: 352, 2: 616}
+X3_PLANES = {1: 352, 2: 616, 3: 640}
 
 
 def kernel_name(var):

@@ -707,6 +707,17 @@ static bool make_plan_rd(int B, int Cin, int H, int W, int Cout, int dil, int rd
     p->plane = 616;
     // (measured at 96x112: quarter-size sub-tile sets, 3 blocks per CU, beat NT = 8 by 17-21 % for the 64-channel layers)
     ok = pick_tile(Hs, W, dy, dil, 2, 616, nts4, 1, &p->t);
+    {
+      // 640-pixel planes: the 2 x 128 tile of a row-folded dilation-16 layer ((2 + 2) x (128 + 32) halo) -- with 616 the 96 -> 64
+      // forward of the context networks only found a 4 x 64 tile that wastes a third of its pixels and stayed on the fp32 kernel
+      auto eff_of = [&](const TileCfg& t) { return (double)Hs * W / ((double)((Hs + t.tr - 1) / t.tr) * ((W + t.tc - 1) / t.tc) * t.tr * t.tc); };
+      TileCfg t2;
+      if (!IRR_ENV_FLAG("IRR_X3_NO_PLANE640") && pick_tile(Hs, W, dy, dil, 2, 640, nts4, 1, &t2) && (!ok || eff_of(t2) > eff_of(p->t) + 0.1)) {
+        p->t = t2;
+        p->plane = 640;
+        ok = true;
+      }
+    }
     if (!ok) ok = pick_tile(Hs, W, dy, dil, 2, 616, nts78, 2, &p->t);
   } else {
     p->pg = 4;
@@ -953,6 +964,7 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
       case 4141: rc = launch_x3<4, 1, 4, 352>(a, p.t, st); break;
       case 3141: rc = launch_x3<3, 1, 4, 352>(a, p.t, st); break;
       case 2242: rc = launch_x3<2, 2, 4, 616>(a, p.t, st); break;
+      case 2243: rc = launch_x3<2, 2, 4, 640>(a, p.t, st); break;
       default: return IRR_EINVAL;
     }
     if (rc) return rc;
