@@ -188,7 +188,10 @@ def main():
         args = types.SimpleNamespace(batch_size=batch_pairs, model_div_flow=0.05)
         loss = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(args, reduce_fn=ddp.reduce_losses() if world > 1 else None).train()
         mal = ModelAndLoss(args, model, loss).train()
-        step = TrainStep(mal, opt, grad_sync=arena.sync, check_nan=os.environ.get("IRR_BENCH_NO_NANCHECK") is None)   # (diagnostic switch)
+        # the reference's per-step NaN assertion is ON: asserted before the optimizer step (TrainStep docstring);
+        # IRR_BENCH_NANCHECK=before_backward: the reference's exact placement (A/B), =off: diagnostic
+        nc = os.environ.get("IRR_BENCH_NANCHECK", "before_step")
+        step = TrainStep(mal, opt, grad_sync=arena.sync, check_nan=False if (nc == "off" or os.environ.get("IRR_BENCH_NO_NANCHECK")) else nc)
         batch = synthetic_batch(batch_pairs, height, width, 1234 + rank, device)
         marks = [] if os.environ.get("IRR_BENCH_STEPTIMES") else None      # diagnostic: per-step GPU time (events, no extra syncs)
 
@@ -305,7 +308,10 @@ def main():
                                                     a.batch, a.height, a.width).replace("synthetic", "FlyingChairsOcc-shaped synthetic"),
                           "pairs_per_gpu": a.batch, "global_batch": a.batch * world, "height": a.height, "width": a.width,
                           "parallelism": f"dp{world}", "weights": "MSRA init, torch.manual_seed(0)",
-                          "transport": "rccl" if backend == "nccl" else backend},
+                          "transport": "rccl" if backend == "nccl" else backend,
+                          "nan_check": os.environ.get("IRR_BENCH_NANCHECK", "before_step") + " (every step: the reference's assertion on "
+                                       "the training loss, runtime.py:182-183; before_step = asserted before the optimizer step "
+                                       "from a pinned host copy, no pipeline drain between forward and backward)"},
                "loss": head["loss"],
                "conv_math": C.MATH,
                "launches_per_step": head["routing"],

@@ -2,7 +2,11 @@
 ``TrainingEpoch._step`` (runtime.py:131-194) + ``ModelAndLoss.forward`` (configuration.py:45-62) with
 Adam(lr=1e-4, weight_decay=4e-4) (scripts/IRR-PWC_flyingChairsOcc.sh:29-31):
 
-    zero_grad -> forward -> loss -> NaN assert -> backward -> [grad all-reduce] -> optimizer.step
+    zero_grad -> forward -> loss -> backward -> [grad all-reduce] -> NaN assert -> optimizer.step
+
+(the reference asserts between loss and backward; TrainStep(check_nan="before_backward") keeps that placement, the default
+asserts before the optimizer step from a pinned host copy of the loss -- same exception, weights never touched on NaN, no drain of
+the GPU pipeline between forward and backward)
 """
 from __future__ import annotations
 
@@ -42,12 +46,20 @@ class TrainStep:
     """Holds model+loss+optimizer and runs reference-equivalent steps on device-resident batches."""
 
     def __init__(self, model_and_loss: ModelAndLoss, optimizer: torch.optim.Optimizer, training_key: str = "total_loss",
-                 grad_sync=None, check_nan: bool = True):
+                 grad_sync=None, check_nan=True):
+        """check_nan: True / "before_step" -- the reference's per-step assertion (runtime.py:182-183) evaluated BEFORE THE OPTIMIZER
+        STEP: the loss is copied to pinned host memory right after the forward pass, backward is enqueued, and the host reads the
+        value (already there by then) before optimizer.step() -- same exception, no update of the weights on NaN, but no drain of
+        the GPU pipeline between forward and backward.  "before_backward": the reference's exact placement (``.item()`` before
+        ``backward()``; the GPU idles while the host re-issues the backward pass).  False: no check."""
         self.model_and_loss = model_and_loss
         self.optimizer = optimizer
         self.training_key = training_key
         self.grad_sync = grad_sync              # callable() run between backward and optimizer.step (data parallel)
-        self.check_nan = check_nan
+        if check_nan not in (True, False, "before_step", "before_backward"):
+            raise ValueError(check_nan)
+        self.check_nan = "before_step" if check_nan is True else check_nan
+        self._loss_host = None                  # pinned scalar for the deferred check
 
     def __call__(self, example_dict: Dict[str, torch.Tensor]):
         for key, t in example_dict.items():      # runtime.py:158-162
@@ -58,11 +70,21 @@ class TrainStep:
         self.optimizer.zero_grad()
         loss_dict, output_dict = self.model_and_loss(example_dict)
         training_loss = loss_dict[self.training_key]
-        if self.check_nan:                        # runtime.py:182-183 (device->host sync, as in the reference)
+        copied = None
+        if self.check_nan == "before_backward":   # runtime.py:182-183 as placed there (device->host sync between forward and backward)
             assert not math.isnan(training_loss.item()), "training_loss is NaN"
+        elif self.check_nan == "before_step" and not torch.cuda.is_current_stream_capturing():
+            if self._loss_host is None:
+                self._loss_host = torch.empty((), dtype=torch.float32, pin_memory=True)
+            self._loss_host.copy_(training_loss.detach(), non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record()
         training_loss.backward()
         if self.grad_sync is not None:
             self.grad_sync()
+        if copied is not None:                    # the value left the device long ago: this wait does not stall the pipeline
+            copied.synchronize()
+            assert not math.isnan(float(self._loss_host)), "training_loss is NaN"
         self.optimizer.step()
         _conv.WEIGHT_EPOCH[0] += 1                # every packed weight copy is stale now: they are refreshed by ONE launch
         return loss_dict, output_dict, example_dict["input1"].shape[0]
@@ -103,7 +125,7 @@ class GraphedTrainStep:
             raise ValueError("GraphedTrainStep needs warmup >= 2")
         self.step = step
         self.warmup = warmup
-        self.check_nan = step.check_nan
+        self.check_nan = bool(step.check_nan)
         self.graph = None
         self.hyper = None
         self.static_in: Dict[str, torch.Tensor] = {}

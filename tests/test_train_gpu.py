@@ -311,3 +311,28 @@ def test_direct_wgrad_same_stream_matches_autograd_path():
         g = grads(mode)
         d = (g - ref).double().norm().item() / ref.double().norm().item()
         assert d <= 1e-5, (mode, d)
+
+
+@pytest.mark.parametrize("mode", ["before_step", "before_backward"])
+def test_nan_assertion_fires_before_the_weights_change(mode):
+    """The reference's per-step assertion (runtime.py:182-183) in both placements: a NaN loss raises AssertionError and the
+    optimizer step does not run (parameters and Adam moments untouched); a clean step afterwards works."""
+    from irr_amd.train import TrainStep
+    m, mal, arena, opt, _ = _setup(2, lane=True)
+    try:
+        step = TrainStep(mal, opt, grad_sync=arena.sync, check_nan=mode)
+        good = _batch(2, 128, 192)
+        step({k: v.clone() for k, v in good.items()})
+        torch.cuda.synchronize()
+        p0, m0, t0 = opt.param_flat.clone(), opt.exp_avg.clone(), opt.t
+        bad = {k: v.clone() for k, v in good.items()}
+        bad["target1"][0, 0, 5, 7] = float("nan")
+        with pytest.raises(AssertionError):
+            step(bad)
+        torch.cuda.synchronize()
+        assert torch.equal(opt.param_flat, p0) and torch.equal(opt.exp_avg, m0) and opt.t == t0
+        ld, _, _ = step({k: v.clone() for k, v in good.items()})
+        assert float(ld["total_loss"].detach()) == float(ld["total_loss"].detach())          # finite again
+        assert not torch.equal(opt.param_flat, p0)
+    finally:
+        arena.disable_async_wgrad()
