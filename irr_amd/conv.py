@@ -486,6 +486,12 @@ class WgradSide:
         # the ~210 partial-image folds of a step run as a few batched launches (ReduceBatch); IRR_LANE_BATCH_REDUCE=0: A/B
         self.batch = ReduceBatch() if os.environ.get("IRR_LANE_BATCH_REDUCE", "1") != "0" else None
         self._pending = []                      # (weight, bias) of launches whose fold has not been launched yet
+        # Launches are handed to the lane in GROUPS: one event on the main stream + one wait on the lane per group instead of per
+        # launch (~500 per step; every record / wait is a barrier packet in its queue).  Waiting for a LATER point of the main
+        # stream than necessary is always safe -- nothing on the main stream writes what a queued launch reads (the tensors are
+        # held alive here and the backward nodes never touch a gradient slice again once its weight-gradient launch is issued).
+        self.group = max(1, int(os.environ.get("IRR_LANE_GROUP", "4")))
+        self._queued = []                       # (fn, tensors, params) not handed to the lane yet
 
     def route(self, weight, bias):
         gw = self.views.get(id(weight))
@@ -494,8 +500,37 @@ class WgradSide:
         gb = self.views.get(id(bias)) if bias is not None else None
         return gw, gb
 
-    def flush(self):
+    def _kick(self):
+        """hand the queued launches to the lane: after everything enqueued so far on the current stream"""
+        if not self._queued:
+            return
+        queued, self._queued = self._queued, []
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.stream.wait_event(ev)
+        keep = []
+        with torch.cuda.stream(self.stream):
+            for fn, tensors, params, _ in queued:
+                fn()
+                keep += [t for t in tensors if t is not None]
+                self._pending.append(params)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        if self.record_streams:
+            for t in keep:
+                t.record_stream(self.stream)
+        self._inflight.append((done, keep))
+        if not torch.cuda.is_current_stream_capturing():      # (an event recorded inside a capture cannot be queried)
+            while self._inflight and self._inflight[0][0].query():
+                self._inflight.popleft()
+        if self.batch is None or not self.batch.n:
+            self.flush(kick=False)                             # nothing deferred: the gradients are complete already
+
+    def flush(self, kick: bool = True):
         """fold every pending partial image (one launch on the lane) and report the gradients that are complete now"""
+        if kick and not self.inline:
+            self._kick()
         if self.batch is not None and self.batch.n:
             if self.inline:
                 self.batch.run()                               # (same stream: the allocator orders any reuse after the fold)
@@ -517,34 +552,20 @@ class WgradSide:
         only steals a gradient whose use_count is 1), nor handed to a consumer as its exclusive property -- whatever the
         model code around the node does with the same gradient tensor (``a = a + b`` feeding two nodes,
         models/pwcnet_irr*.py)."""
-        if self.batch is not None and gw is not None and self.batch.full_for(gw):
-            self.flush()
+        if self.batch is not None and gw is not None:
+            # a batch folds into each gradient at most once, and holds at most cap jobs: queued launches count
+            if (self.batch.full_for(gw) or any(q[3] == gw.data_ptr() for q in self._queued)
+                    or self.batch.n + len(self._queued) >= self.batch.cap - 1):
+                self.flush()
         if self.inline:
             fn()
             self._pending.append(params)
             if self.batch is None or not self.batch.n:
                 self.flush()
             return
-        main = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)
-        self.stream.wait_event(ev)
-        with torch.cuda.stream(self.stream):
-            fn()
-            done = torch.cuda.Event()
-            done.record(self.stream)
-        capturing = torch.cuda.is_current_stream_capturing()
-        keep = [t for t in tensors if t is not None]
-        if self.record_streams:
-            for t in keep:
-                t.record_stream(self.stream)
-        self._inflight.append((done, keep))
-        if not capturing:                                      # (an event recorded inside a capture cannot be queried)
-            while self._inflight and self._inflight[0][0].query():
-                self._inflight.popleft()
-        self._pending.append(params)
-        if self.batch is None or not self.batch.n:
-            self.flush()                                       # nothing deferred: the gradient is complete already
+        self._queued.append((fn, tensors, params, gw.data_ptr() if gw is not None else 0))
+        if len(self._queued) >= self.group:
+            self._kick()
 
     def join(self):
         self.flush()
