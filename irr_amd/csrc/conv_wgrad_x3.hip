@@ -50,7 +50,9 @@ struct WX3Args {
   const float* gy;
   float* ws;                     // [grid.x][Cout][9][Cin] workspace: one partial result per block column (plain stores)
   long n;                        // Cout * 9 * Cin
-  float* gbias;                  // nullable
+  float* gbias;                  // nullable: bias gradient = sum of the gy-role operand
+  float* xbias;                  // nullable (NW == 1 instantiations): the same sum over the x-role operand -- launches with exchanged
+                                 // roles carry the real output gradient there (it used to take a separate pass over gy per launch)
   float alpha;
   int B, Cin, H, W, Cout;
   long x_bs, gy_bs;
@@ -163,6 +165,10 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   float bsum[GR];
 #pragma unroll
   for (int r = 0; r < GR; ++r) bsum[r] = 0.f;
+  constexpr bool XB = NW == 1;                              // (only the one-tile-wide blocks ever run with exchanged roles)
+  float xsum[XB ? XR : 1];
+#pragma unroll
+  for (int r = 0; r < (XB ? XR : 1); ++r) xsum[r] = 0.f;
 
   f32x16 acc[9];
 #pragma unroll
@@ -179,6 +185,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   const int Hp = a.H + 1;
   const bool narrow = (a.W & 3) != 0;                      // (uniform)
   int trow = 0, tb = 0, ty = 0;                            // TALL: tall row trow is row ty of sample tb
+  int col_row_lo = 0, col_row_hi = 0;                      // the current column's own rows [ya, yb) (x rows outside are halo)
   auto issue = [&](int b, int c0, int res, int row0, bool with_x, int grow0, bool with_g) {
     if (!stager) return;
     // TALL: (sample, row) of the first staged x / gy row (uniform); a thread's row is at most R - 1 further down: one wrap
@@ -271,6 +278,10 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       for (int r = 0; r < XR; ++r) {
         if (xu[r] < 0) continue;
         float v[8] = {xraw[r][0][0], xraw[r][0][1], xraw[r][0][2], xraw[r][0][3], xraw[r][1][0], xraw[r][1][1], xraw[r][1][2], xraw[r][1][3]};
+        // (every own row of the column once: the prologue's second round and the first unit's rows overlap, halo rows belong
+        // to the neighbouring chunks)
+        if (XB && a.xbias && row0 + RU_RR(xu[r]) >= col_row_lo && row0 + RU_RR(xu[r]) < col_row_hi && (!MINI ? (RU_GRP(xu[r]) >= MG && RU_GRP(xu[r]) < MG + KG) : true))
+          xsum[r] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         u32x4 h, m, l;
 #if WX3_ABL == 1
         h = __builtin_bit_cast(u32x4, xraw[r][0]); m = __builtin_bit_cast(u32x4, xraw[r][1]); l = h; (void)v;
@@ -283,6 +294,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
         xs[idx + XPLANE] = m;
         xs[idx + 2 * XPLANE] = l;
       }
+      if (XB && row0 + R > col_row_lo) col_row_lo = row0 + R;      // rows below are counted
     }
     if (with_g) {
 #pragma unroll
@@ -427,6 +439,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     const int ya = chunk * a.rows_per_chunk;
     const int yb = min(hk, ya + a.rows_per_chunk);
     if (TALL) { trow = ya; tb = ya / Hp; ty = ya - tb * Hp; }
+    col_row_lo = ya; col_row_hi = yb;
     // prologue: x rows ya-1 .. ya+R and the first gy unit
     __syncthreads();
     for (int r0 = ya - 1; r0 <= ya + R; r0 += R) {
@@ -504,6 +517,21 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
       const int ci = ci0 + wn * 32 + j;
       if (co < a.Cout && ci < a.Cin) wsp[((long)co * 9 + t) * a.Cin + ci] = a.alpha * acc[t][r];
+    }
+  }
+  if constexpr (XB) if (a.xbias && bz == 0) {
+    // threads with the same x channel are adjacent (R * XGS of them): fold, then one atomic per channel
+#pragma unroll
+    for (int r = 0; r < XR; ++r) {
+      float s2 = xsum[r];
+      constexpr int PERX = R * XGS;
+      constexpr int P2 = PERX <= 1 ? 1 : PERX <= 2 ? 2 : PERX <= 4 ? 4 : PERX <= 8 ? 8 : 16;
+      static_assert(!MINI || PERX == P2, "x units per channel must be a power of two for the shuffle fold");
+      if (PERX != P2) __builtin_trap();                      // (group-margin builds of the one-tile-wide blocks: not a product configuration)
+#pragma unroll
+      for (int off = 1; off < PERX; off <<= 1) s2 += __shfl_xor(s2, off, 64);
+      const int u = r * SNTHR + tid;
+      if (xu[r] >= 0 && (u % PERX) == 0 && ci0 + RU_CH(xu[r]) < a.Cin) unsafeAtomicAdd(a.xbias + ci0 + RU_CH(xu[r]), a.alpha * s2);
     }
   }
   if (a.gbias && by == 0) {
@@ -714,7 +742,7 @@ extern "C" int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* g
   const long n = (long)Cout * Cin * 9;
   hipStream_t st = (hipStream_t)stream;
   WX3Args a;
-  a.ws = ws; a.gbias = gbias; a.alpha = alpha;
+  a.ws = ws; a.gbias = gbias; a.xbias = nullptr; a.alpha = alpha;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.x_bs = x_bs; a.gy_bs = gy_bs;
   const long lim = (1L << 29) - 64;
   const long bsmax = x_bs > gy_bs ? x_bs : gy_bs;
@@ -763,7 +791,7 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
                    ((cot == 3 && cit >= 4) || (cot == 1 && (cit + 7) / 8 * 8 * 5 >= (cit + 3) / 4 * 4 * 6));   // (the eight-wave column pads >= 1.2 x as much)
   const bool swapped = (cot == 1 && !ksplit) || sw4;
   WX3Args a;
-  a.ws = ws; a.gbias = swapped ? nullptr : gbias; a.alpha = alpha;
+  a.ws = ws; a.gbias = swapped ? nullptr : gbias; a.xbias = swapped ? gbias : nullptr; a.alpha = alpha;
   a.H = H; a.W = W;
   a.Cin = swapped ? Cout : Cin;
   a.Cout = swapped ? Cin : Cout;
@@ -801,12 +829,6 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
     if (rc) return rc;
     const int rr = reduce_or_defer(ws, gw, n, g_last_parts, Cin, Cout, swapped ? 1 : 0, per >= B, st);
     if (rr) return rr;
-  }
-  if (swapped && gbias) {
-    const int chunk = 8192;
-    dim3 grid(irr_cdiv((long)H * W, chunk), Cout, B);
-    hipLaunchKernelGGL(wx3_bias_kernel, grid, dim3(256), 0, st, gy, gbias, (long)H * W, gy_bs, alpha, chunk);
-    IRR_LAUNCH_CHECK();
   }
   return 0;
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes over tools/pmc_run.py on the GPU box: HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and MFMA-pipe
 # utilisation of the heavy conv shapes + cost volume / warp at 96x112x64.   bash tools/pmc_ops.sh <tag>
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=gpurun_out/prof
 mkdir -p $OUT
 cd /tmp 2>/dev/null; cd - > /dev/null

@@ -4,7 +4,7 @@
 # 1. bench.py default (two-lane) with the CPU baseline          -> <tag>_bench.json
 # 2. rocprofv3 --kernel-trace --stats, default and single-stream -> <tag>_kernel_stats{,_serial}.txt (+ the JSON line of the same run)
 # 3. two separate PMC passes (FETCH_SIZE, WRITE_SIZE)            -> <tag>_hbm_traffic.txt, hbm_traffic.json
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
