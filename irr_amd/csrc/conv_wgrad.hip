@@ -523,7 +523,7 @@ int dispatch(const WgArgs& a, hipStream_t st) {
 // x 4 column lanes (coalesced reads), fixed summation order -> no atomics, no zeroed workspace, reproducible bits.
 // (body shared with the batched fold of many launches: wgrad_reduce.h)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const IrrReduceJob J) {
-  __shared__ float red[3][64];
+  __shared__ float red[3][256];
   irr_reduce_block(J, blockIdx.x, red);
 }
 
@@ -723,7 +723,7 @@ extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
       if (!(per >= B && irr_reduce_defer(ws, gw, n, (int)g_parts, Cin, Cout, k * k, 0))) {
         IrrReduceJob J{};
         J.ws = ws; J.gw = gw; J.n = n; J.P = (int)g_parts; J.Cin = Cin; J.Cout = Cout; J.KK = k * k;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, J);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, J);
         IRR_LAUNCH_CHECK();
       }
     }
@@ -731,7 +731,7 @@ extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
   if (atomic) {
     IrrReduceJob J{};
     J.ws = ws; J.gw = gw; J.n = n; J.P = 1; J.Cin = Cin; J.Cout = Cout; J.KK = k * k;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, J);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, J);
     IRR_LAUNCH_CHECK();
   }
   return 0;

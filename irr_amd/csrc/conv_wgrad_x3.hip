@@ -659,7 +659,7 @@ static int pick_kg(int W) {
 // gw[co][ci][tap] += sum over the P partials of ws[p][co][tap][ci]   (swapped: the launch ran with the operand roles
 // exchanged, see below, and produced ws[p][ci][8-tap][co]).  Body shared with the batched fold: wgrad_reduce.h.
 __global__ __launch_bounds__(256) void wgrad_reduce_x3_kernel(const IrrReduceJob J) {
-  __shared__ float red[3][64];
+  __shared__ float red[3][256];
   irr_reduce_block(J, blockIdx.x, red);
 }
 
@@ -668,7 +668,7 @@ static int reduce_or_defer(const float* ws, float* gw, long n, int P, int Cin, i
   if (may_defer && irr_reduce_defer(ws, gw, n, P, Cin, Cout, 9, swapped)) return 0;
   IrrReduceJob J{};
   J.ws = ws; J.gw = gw; J.n = n; J.P = P; J.Cin = Cin; J.Cout = Cout; J.KK = 9; J.swapped = swapped;
-  hipLaunchKernelGGL(wgrad_reduce_x3_kernel, dim3(irr_cdiv(n, 64)), dim3(256), 0, st, J);
+  hipLaunchKernelGGL(wgrad_reduce_x3_kernel, dim3(irr_cdiv(n, 256)), dim3(256), 0, st, J);
   IRR_LAUNCH_CHECK();
   return 0;
 }

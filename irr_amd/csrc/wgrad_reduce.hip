@@ -10,7 +10,7 @@ struct ReduceBatch {
 };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch T) {
-  __shared__ float red[3][64];
+  __shared__ float red[3][256];
   const int blk = blockIdx.x;
   int i = 0;
   while (i + 1 < T.njobs && T.job[i + 1].block0 <= blk) ++i;       // (uniform: <= 40 scalar compares)
@@ -44,7 +44,7 @@ extern "C" int irr_wgrad_reduce_batch(const void* jobs, int njobs, void* stream)
     for (int k = 0; k < i; ++k)
       if (src[k].gw == src[i].gw) return IRR_EINVAL;               // two folds into one gradient would race inside a launch
     T.job[i].block0 = (int)blk;
-    blk += irr_cdiv(src[i].n, 64);
+    blk += irr_cdiv(src[i].n, 256);
   }
   T.njobs = njobs;
   hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, T);
