@@ -33,6 +33,9 @@
 #ifndef WX3_TALL
 #define WX3_TALL 1     // 1: DIL == 1 walks all samples of a strip as one tall image (see TALL); 0 (A/B): one column per sample
 #endif
+#ifndef WX3_STRIP_FAST
+#define WX3_STRIP_FAST 1   // 1: tall columns are ordered strip-fastest (L2 sharing of x lines between neighbouring strips); 0 (A/B)
+#endif
 #ifndef WX3_ABL
 #define WX3_ABL 0      // ablation builds (timing only): 1 = no operand split (VALU) in the staging path
 #endif
@@ -413,24 +416,51 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   const long col_end = min(a.ncols, col_begin + a.cols_per_block);
   // column = (b, strip, res, chunk) in mixed radix, chunk fastest: decoded once, then stepped (the 64-bit divisions of a
   // per-column decode are ~2k cycles of scalar work on every wave)
+  // Columns in mixed radix with the STRIP fastest, then chunk, residue, sample (WX3_STRIP_FAST; round 2 had the chunk fastest):
+  // neighbouring strips share every 128-B line of x (a strip is 32 ... 128 B wide and reads one more pixel on each side);
+  // consecutive columns sit on one XCD and walk the same rows at the same time, so those lines come out of that XCD's L2
+  // instead of being fetched once per strip (565 -> 128 at 96x112: 6.6 -> 3.1 GB fetched per launch for 1.9 GB of operands).
+  // Decoded once, then stepped (the 64-bit divisions of a per-column decode are ~2k cycles of scalar work on every wave).
   int chunk, res, strip, b;
   {
     long t = col_begin;
-    chunk = (int)(t % a.nchunks_y);
-    t /= a.nchunks_y;
-    res = (int)(t % DIL);
-    t /= DIL;
-    strip = (int)(t % a.nstrips);
-    b = (int)(t / a.nstrips);
+    if (WX3_STRIP_FAST) {
+      strip = (int)(t % a.nstrips);
+      t /= a.nstrips;
+      chunk = (int)(t % a.nchunks_y);
+      t /= a.nchunks_y;
+      res = (int)(t % DIL);
+      b = (int)(t / DIL);
+    } else {
+      chunk = (int)(t % a.nchunks_y);
+      t /= a.nchunks_y;
+      res = (int)(t % DIL);
+      t /= DIL;
+      strip = (int)(t % a.nstrips);
+      b = (int)(t / a.nstrips);
+    }
   }
   for (long col = col_begin; col < col_end; ++col) {
-    if (col != col_begin && ++chunk == a.nchunks_y) {
-      chunk = 0;
-      if (++res == DIL) {
-        res = 0;
+    if (col != col_begin) {
+      if (WX3_STRIP_FAST) {
         if (++strip == a.nstrips) {
           strip = 0;
-          ++b;
+          if (++chunk == a.nchunks_y) {
+            chunk = 0;
+            if (++res == DIL) {
+              res = 0;
+              ++b;
+            }
+          }
+        }
+      } else if (++chunk == a.nchunks_y) {
+        chunk = 0;
+        if (++res == DIL) {
+          res = 0;
+          if (++strip == a.nstrips) {
+            strip = 0;
+            ++b;
+          }
         }
       }
     }
