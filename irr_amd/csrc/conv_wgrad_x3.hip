@@ -20,6 +20,7 @@
 #include "x3_split.h"
 #include "wgrad_reduce.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #ifndef WX3_STAGGER
 #define WX3_STAGGER 0  // 1 (A/B): the two waves of a SIMD publish / compute in opposite orders (see the unit loop); 0: all compute first
@@ -75,7 +76,7 @@ __device__ __forceinline__ uint32_t alignbit16(uint32_t hi, uint32_t lo) { retur
 // DIL > 1 (dilated context-network layers): the three vertical taps are DIL rows apart, so a column additionally fixes a
 // row residue and walks rows res, res + DIL, res + 2 DIL, ...: in that walk the taps are again neighbouring rows and the
 // ring works unchanged.  The +-DIL column taps are whole dwords (DIL = 2, 4) or whole groups (8, 16) of the neighbours.
-template <int MW, int NW, int KG, int R, int KW = 1, int DIL = 1>
+template <int MW, int NW, int KG, int R, int KW = 1, int DIL = 1, bool NARROW = false>
 __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const WX3Args a) {
   constexpr int NTHR = MW * NW * KW * 64;
   constexpr int RING = 2 * R + 2;                          // x rows resident
@@ -186,7 +187,10 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   // (row0 / grow0 count rows of the residue walk: image row = res + DIL * k)
   const bool stager = wave < SWAVES;
   const int Hp = a.H + 1;
-  const bool narrow = (a.W & 3) != 0;                      // (uniform)
+  // NARROW is a TEMPLATE parameter on purpose: as a run-time branch around the loads it cost every variant its graded
+  // vmcnt(7 .. 0) waits (the compiler cannot count loads behind a branch and waited with vmcnt(0): the two-deep prefetch of the
+  // unit loop was gone -- dilation-16 layers -21 %, the Cout = 64 layers -7 %).
+  constexpr bool narrow = NARROW;
   int trow = 0, tb = 0, ty = 0;                            // TALL: tall row trow is row ty of sample tb
   int col_row_lo = 0, col_row_hi = 0;                      // the current column's own rows [ya, yb) (x rows outside are halo)
   auto issue = [&](int b, int c0, int res, int row0, bool with_x, int grow0, bool with_g) {
@@ -601,7 +605,7 @@ long ws_capacity(int Cin, int Cout) {
   return parts * n;
 }
 
-template <int MW, int NW, int KG, int R, int KW = 1, int DIL = 1>
+template <int MW, int NW, int KG, int R, int KW = 1, int DIL = 1, bool NARROW = false>
 int launch_wx3(WX3Args a, hipStream_t st) {
   constexpr int RING = 2 * R + 2, XG = KG + 2 * (DIL > 8 ? DIL / 8 : 1);
   constexpr size_t lds_stage = 16 * (3 * (size_t)(32 * NW) * (RING * XG + 1) + 3 * (size_t)(32 * MW) * (2 * R * KG + 1));
@@ -610,7 +614,7 @@ int launch_wx3(WX3Args a, hipStream_t st) {
   static_assert(lds_bytes <= 160 * 1024, "unit does not fit the 160 KiB LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e0 = hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<MW, NW, KG, R, KW, DIL>,
+    hipError_t e0 = hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<MW, NW, KG, R, KW, DIL, NARROW>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e0 != hipSuccess) return (int)e0;
     attr_set = true;
@@ -666,7 +670,7 @@ int launch_wx3(WX3Args a, hipStream_t st) {
 #endif
   a.n = (long)a.Cout * 9 * a.Cin;
   if ((long)a.ngx * a.n > ws_capacity(a.Cin, a.Cout)) return IRR_EINVAL;      // (cannot happen: gx <= want)
-  hipLaunchKernelGGL((conv_wgrad_x3_kernel<MW, NW, KG, R, KW, DIL>), dim3((unsigned)a.ngx * gy_ * gz_), dim3(MW * NW * KW * 64),
+  hipLaunchKernelGGL((conv_wgrad_x3_kernel<MW, NW, KG, R, KW, DIL, NARROW>), dim3((unsigned)a.ngx * gy_ * gz_), dim3(MW * NW * KW * 64),
                      lds_bytes, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
@@ -837,25 +841,30 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
     a.x = (swapped ? gy : x) + (long)b0 * a.x_bs;
     a.gy = (swapped ? x : gy) + (long)b0 * a.gy_bs;
     int rc;
+    auto dispatch = [&](auto narrow_tag) {
+      constexpr bool NW_ = decltype(narrow_tag)::value;
     if (ksplit) {
-      rc = W % 32 == 0 ? launch_wx3<1, 1, 4, 4, 8>(a, st) : launch_wx3<1, 1, 2, 4, 4>(a, st);
-    } else if (k4) {
-      rc = launch_wx3<2, 1, 2, 4, 4>(a, st);
-    } else if (sw4) {
-      rc = kg == 4 ? launch_wx3<4, 1, 4, 1, 2>(a, st) : kg == 2 ? launch_wx3<4, 1, 2, 2, 2>(a, st) : launch_wx3<4, 1, 1, 4, 2>(a, st);
-    } else if (swapped) {
-      rc = kg == 4 ? launch_wx3<8, 1, 4, 1>(a, st) : kg == 2 ? launch_wx3<8, 1, 2, 2>(a, st) : launch_wx3<8, 1, 1, 4>(a, st);
-    } else if (cot == 2) {
-      // 2 x 2 tiles = four waves would leave one wave per SIMD: two wave groups split the k-steps of a unit (eight waves)
-      if (IRR_ENV_FLAG("IRR_WX3_NO_KW2"))
-        rc = kg == 4 ? launch_wx3<2, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<2, 2, 2, 2>(a, st) : launch_wx3<2, 2, 1, 4>(a, st);
-      else
-        rc = kg == 4 ? launch_wx3<2, 2, 4, 1, 2>(a, st) : kg == 2 ? launch_wx3<2, 2, 2, 2, 2>(a, st) : launch_wx3<2, 2, 1, 4, 2>(a, st);
-    } else if (cot % 4 == 0 || cot > 4) {
-      rc = kg == 4 ? launch_wx3<4, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<4, 2, 2, 2>(a, st) : launch_wx3<4, 2, 1, 4>(a, st);
-    } else {
-      rc = kg == 4 ? launch_wx3<3, 2, 4, 1>(a, st) : kg == 2 ? launch_wx3<3, 2, 2, 2>(a, st) : launch_wx3<3, 2, 1, 4>(a, st);
-    }
+        rc = W % 32 == 0 ? launch_wx3<1, 1, 4, 4, 8, 1, NW_>(a, st) : launch_wx3<1, 1, 2, 4, 4, 1, NW_>(a, st);
+      } else if (k4) {
+        rc = launch_wx3<2, 1, 2, 4, 4, 1, NW_>(a, st);
+      } else if (sw4) {
+        rc = kg == 4 ? launch_wx3<4, 1, 4, 1, 2, 1, NW_>(a, st) : kg == 2 ? launch_wx3<4, 1, 2, 2, 2, 1, NW_>(a, st) : launch_wx3<4, 1, 1, 4, 2, 1, NW_>(a, st);
+      } else if (swapped) {
+        rc = kg == 4 ? launch_wx3<8, 1, 4, 1, 1, 1, NW_>(a, st) : kg == 2 ? launch_wx3<8, 1, 2, 2, 1, 1, NW_>(a, st) : launch_wx3<8, 1, 1, 4, 1, 1, NW_>(a, st);
+      } else if (cot == 2) {
+        // 2 x 2 tiles = four waves would leave one wave per SIMD: two wave groups split the k-steps of a unit (eight waves)
+        if (IRR_ENV_FLAG("IRR_WX3_NO_KW2"))
+          rc = kg == 4 ? launch_wx3<2, 2, 4, 1, 1, 1, NW_>(a, st) : kg == 2 ? launch_wx3<2, 2, 2, 2, 1, 1, NW_>(a, st) : launch_wx3<2, 2, 1, 4, 1, 1, NW_>(a, st);
+        else
+          rc = kg == 4 ? launch_wx3<2, 2, 4, 1, 2, 1, NW_>(a, st) : kg == 2 ? launch_wx3<2, 2, 2, 2, 2, 1, NW_>(a, st) : launch_wx3<2, 2, 1, 4, 2, 1, NW_>(a, st);
+      } else if (cot % 4 == 0 || cot > 4) {
+        rc = kg == 4 ? launch_wx3<4, 2, 4, 1, 1, 1, NW_>(a, st) : kg == 2 ? launch_wx3<4, 2, 2, 2, 1, 1, NW_>(a, st) : launch_wx3<4, 2, 1, 4, 1, 1, NW_>(a, st);
+      } else {
+        rc = kg == 4 ? launch_wx3<3, 2, 4, 1, 1, 1, NW_>(a, st) : kg == 2 ? launch_wx3<3, 2, 2, 2, 1, 1, NW_>(a, st) : launch_wx3<3, 2, 1, 4, 1, 1, NW_>(a, st);
+      }
+    };
+    if (W & 3) dispatch(std::true_type{});
+    else dispatch(std::false_type{});
     if (rc) return rc;
     const int rr = reduce_or_defer(ws, gw, n, g_last_parts, Cin, Cout, swapped ? 1 : 0, per >= B, st);
     if (rr) return rr;
