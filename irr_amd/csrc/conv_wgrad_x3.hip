@@ -96,7 +96,8 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   // padding row of one sample and the upper one of the next; its gy row is zero too) -- so the ring never has to be refilled:
   // one prologue per block instead of one per (sample, strip) (at 48x56 a column was 12 units + a 2-unit prologue with its loads
   // exposed), and the vertical split into chunks can balance the blocks' shares to a unit.
-  const bool TALL = WX3_TALL && DIL == 1 && a.tall;       // (chosen per launch by the host's cost model, see launch_wx3)
+  // (dilated layers: the same with the rows of ONE residue class -- sample b's k-th row of the class is tall row b * (Hk + 1) + k)
+  const bool TALL = WX3_TALL && a.tall;                   // (chosen per launch by the host's cost model, see launch_wx3)
   constexpr int XGS = MINI ? KG : XG;                      // groups of a row staged as full 32-B units
   constexpr int GOFS = MINI ? MG : 0;                      // ... stored from this group slot on
   constexpr int XUNITS = R * XGS * 32 * NW;                // (channel, row, group) staging units per step
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   // issue the global loads of x rows [row0, row0+R) and (optionally) gy rows [grow0, grow0+R) of column (b, strip c0)
   // (row0 / grow0 count rows of the residue walk: image row = res + DIL * k)
   const bool stager = wave < SWAVES;
-  const int Hp = a.H + 1;
+  int Hp = a.H + 1;                                        // rows per sample in the tall image (set per column when dilated)
   // NARROW is a TEMPLATE parameter on purpose: as a run-time branch around the loads it cost every variant its graded
   // vmcnt(7 .. 0) waits (the compiler cannot count loads behind a branch and waited with vmcnt(0): the two-deep prefetch of the
   // unit loop was gone -- dilation-16 layers -21 %, the Cout = 64 layers -7 %).
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     for (int r = 0; r < MR; ++r) {
       int kk = xy0 + RU_RR(mu[r]), bb = xb;
       if (TALL && kk >= Hp) { kk -= Hp; ++bb; }
-      const int yy = TALL ? kk : (kk < 0 ? -1 : res + DIL * kk);
+      const int yy = kk < 0 ? -1 : res + DIL * kk;           // (TALL: kk = Hk, the separator, lands beyond the image)
       const int xx = RU_GRP(mu[r]) ? c0 + KG * 8 : c0 - 1;
       const int ci = ci0 + RU_CH(mu[r]);
       const bool ok = with_x && mu[r] >= 0 && ci < a.Cin && yy >= 0 && yy < a.H && bb < a.B && xx >= 0 && xx < a.W;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     for (int r = 0; r < XR; ++r) {
       int kk = xy0 + RU_RR(xu[r]), bb = xb;
       if (TALL && kk >= Hp) { kk -= Hp; ++bb; }
-      const int yy = TALL ? kk : (kk < 0 ? -1 : res + DIL * kk);
+      const int yy = kk < 0 ? -1 : res + DIL * kk;
       const int xx = c0 + (RU_GRP(xu[r]) + GOFS - MG) * 8;
       const int ci = ci0 + RU_CH(xu[r]);
       const bool ok = with_x && xu[r] >= 0 && ci < a.Cin && yy >= 0 && yy < a.H && bb < a.B && xx >= 0 && xx < a.W;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     for (int r = 0; r < GR; ++r) {
       int kk = gy0 + RU_RR(gu[r]), bb = gb0;
       if (TALL && kk >= Hp) { kk -= Hp; ++bb; }
-      const int yy = TALL ? kk : res + DIL * kk;
+      const int yy = res + DIL * kk;
       const int xx = c0 + RU_GRP(gu[r]) * 8;
       const int co = co0 + RU_CH(gu[r]);
       const bool ok = with_g && gu[r] >= 0 && co < a.Cout && yy >= 0 && yy < a.H && bb < a.B && xx < a.W;
@@ -469,7 +470,9 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       }
     }
     const int c0 = strip * KG * 8;
-    const int hk = TALL ? a.B * Hp : (a.H - res + DIL - 1) / DIL;   // rows of this walk (TALL: all samples, b stays 0)
+    const int Hk = (a.H - res + DIL - 1) / DIL;              // rows of this residue class in one sample
+    Hp = Hk + 1;
+    const int hk = TALL ? a.B * Hp : Hk;                     // rows of this walk (TALL: all samples, b stays 0)
     const int ya = chunk * a.rows_per_chunk;
     const int yb = min(hk, ya + a.rows_per_chunk);
     if (TALL) { trow = ya; tb = ya / Hp; ty = ya - tb * Hp; }
@@ -644,16 +647,18 @@ int launch_wx3(WX3Args a, hipStream_t st) {
   a.rows_per_chunk = rows;
   a.ncols = (long)a.B * a.nstrips * DIL * a.nchunks_y;
   a.tall = 0;
-  if (WX3_TALL && DIL == 1 && !IRR_ENV_FLAG("IRR_WX3_NO_TALL")) {
+  // (dilated layers: the kernel supports the tall walk of one residue class too, but a class has only H / d rows per sample, so the
+  // separator row costs 8-17 % there: measured 3-9 % slower at 96x112, faster only at 48x56 d8 -- off unless IRR_WX3_TALL_DIL=1)
+  if (WX3_TALL && (DIL == 1 || IRR_ENV_FLAG("IRR_WX3_TALL_DIL")) && !IRR_ENV_FLAG("IRR_WX3_NO_TALL")) {
     // (b) columns = (strip, chunk of the tall image of B * (H + 1) rows), any number of chunks: one extra row per sample, but a
     // block's share is ONE column (one prologue) and the shares are equal to a unit
-    const long tk = (long)a.B * (a.H + 1);
+    const long tk = (long)a.B * (hk + 1);                    // (hk: rows of the longest residue class; shorter ones leave a chunk short)
     const long cmax = 4 * want > 64 ? 4 * want : 64;
     for (long c = 1; c <= cmax; ++c) {
       const long rc = ((tk + c - 1) / c + R - 1) / R * R;
       if (c > 1 && rc < R) break;
       const long nch = (tk + rc - 1) / rc;
-      const long ncols = (long)a.nstrips * nch;
+      const long ncols = (long)a.nstrips * DIL * nch;
       const long cpb = (ncols + want - 1) / want;
       const double t = (double)cpb * ((double)(rc / R) + PROLOGUE);
       if (t < best * 0.99) { best = t; a.tall = 1; a.rows_per_chunk = (int)rc; a.nchunks_y = (int)nch; a.ncols = ncols; }
