@@ -56,6 +56,7 @@ struct X3Args {
   const float* mask;
   long mask_bs;
   int nmask;
+  int ngy;                                 // co-tile groups per pixel tile (folded into the 1-D x grid, see the kernel)
   int ksplit;                              // > 1 (small pyramid levels): blockIdx.z walks a slice of the 16-channel chunks and
   float* part;                             // stores raw partial sums part[kz][b][co][pixel]; x3_splitk_epilogue_kernel finishes
 };
@@ -81,9 +82,14 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
   // XCD-major block order (common.h): blocks of one XCD take CONSECUTIVE tiles (their halos overlap in that XCD's L2), and
   // the co-tile groups of one pixel tile (blockIdx.y, layers with more co-tiles than CT) stay on one XCD: they read the
   // same input patch.  K-split slices (blockIdx.z) read different channels and are left alone.
-  const unsigned xpos = irr_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
-  const int by = (int)(xpos % gridDim.y);
-  int bt = (int)(xpos / gridDim.y);
+  // (launched with a ONE-dimensional x grid of ntiles * ngy blocks, like the weight-gradient kernel: the XCD placement of a
+  // workgroup is only observed for the linear id of a 1-D grid.  Open: the 128 -> 565 data gradient -- five co-tile groups per
+  // pixel tile -- still fetches 2.7 GB per launch for a 0.35 GB input (3.0 GB with the groups in gridDim.y): the groups do not
+  // share the patch through L2 although they are dispatched back to back on one XCD.  That launch runs at the power wall
+  // (232 TFLOP/s, 0.6 TB/s), so this was left; profiles/r3_traffic_dgrad_128to565.txt.)
+  const unsigned xpos = irr_xcd_order(blockIdx.x, gridDim.x);
+  const int by = (int)(xpos % (unsigned)a.ngy);
+  int bt = (int)(xpos / (unsigned)a.ngy);
   const int tx = bt % a.tiles_x;
   bt /= a.tiles_x;
   const int ty = bt % a.tiles_y;
@@ -652,7 +658,8 @@ int launch_x3(X3Args& a, const TileCfg& t, hipStream_t st) {
   const int Hs = (a.H + a.RD - 1) / a.RD;
   a.tiles_x = (a.W + t.tc - 1) / t.tc;
   a.tiles_y = (Hs + t.tr - 1) / t.tr;
-  dim3 grid((unsigned)((long)a.B * a.RD * a.tiles_x * a.tiles_y), (unsigned)((a.CoT + CT - 1) / CT), (unsigned)a.ksplit);
+  a.ngy = (a.CoT + CT - 1) / CT;
+  dim3 grid((unsigned)((long)a.B * a.RD * a.tiles_x * a.tiles_y * a.ngy), 1, (unsigned)a.ksplit);
   hipLaunchKernelGGL((conv_x3_kernel<CT, PG, NT, PLANE_PIX>), grid, dim3(CT * PG * 64), 0, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
