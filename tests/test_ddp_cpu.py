@@ -130,6 +130,74 @@ def test_two_rank_gloo_matches_single_process():
     assert torch.allclose(arena.flat, res[0][1], rtol=1e-4, atol=1e-6), (arena.flat - res[0][1]).abs().max()
 
 
+def _failsafe_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import warnings
+    from irr_amd import ddp
+    torch.manual_seed(0)
+    model = Toy()
+    ddp.broadcast_params(model)
+    arena = ddp.GradArena(model.named_parameters())
+    model.arena_box[0] = arena
+    mine = ddp.shard_batch(_make_batch(4), rank, world)
+    out = {}
+    # (a) the ranks' calibration steps see DIFFERENT contribution counts (rank 1 reports one extra lane contribution): the arena
+    #     must notice (one MIN / MAX all-reduce), stay in reduce-at-sync mode on EVERY rank for that step and calibrate on the next
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it in range(2):
+            arena.zero_grad()
+            ld = _loss(model, mine, ddp.reduce_losses())
+            ld["total_loss"].backward()
+            if rank == 1 and it == 0:
+                arena._on_lane(model.body.weight, None)
+            arena.sync()
+            out[f"log{it}"] = list(arena.launch_log)
+    out["mismatch"] = arena.calibration_mismatch
+    out["calibrated_after_mismatch"] = arena._expected is not None
+    # (b) calibrated, then ONE rank delivers a contribution after its bucket's all-reduce was started: no exception inside the
+    #     hook (the other rank would hang in its matching collective); sync() completes the step's collectives, then raises there
+    arena.recalibrate()
+    arena.zero_grad()
+    _loss(model, mine, ddp.reduce_losses())["total_loss"].backward()
+    arena.sync()
+    assert arena._expected is not None
+    arena.zero_grad()
+    _loss(model, mine, ddp.reduce_losses())["total_loss"].backward()
+    late = None
+    if rank == 1:
+        arena._on_lane(model.occ_shuffle_upsample.weight, None)        # bucket 0 was launched inside backward already
+    try:
+        arena.sync()
+    except RuntimeError as e:
+        late = str(e)[:40]
+    out["late"] = late
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_arena_is_fail_safe_when_ranks_disagree():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 7) % 1000
+    procs = [ctx.Process(target=_failsafe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=100) for _ in range(2))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        # the step after the mismatch still reduces at sync() and is the new calibration step (the ranks agree there)
+        assert res[r]["mismatch"] is True and res[r]["calibrated_after_mismatch"] is True, res
+        assert res[r]["log0"] == res[r]["log1"] == [(0, "sync"), (1, "sync"), (2, "sync")], res
+    assert res[0]["late"] is None and res[1]["late"] is not None and "contribution" in res[1]["late"], res
+
+
 def test_shard_batch():
     from irr_amd import ddp
     b = {"input1": torch.arange(8).view(8, 1), "index": 3}
