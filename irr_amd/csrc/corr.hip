@@ -108,15 +108,21 @@ __global__ __launch_bounds__(256) void corr81_fwd_kernel(const float* __restrict
 //   * both operands are staged per 8-channel stage as aligned 16-B units with all loads of a thread issued together
 //     (f2: (8+8) x (32+8) halo tile, f1: the block's own pixels), so the FMA loop contains no global load.
 // 8 rows x 8 quads x 3 displacement groups = 192 threads.
-constexpr int QX = 32, QY = 8;                     // tile
-constexpr int QTX = QX + 2 * HALO, QTY = QY + 2 * HALO;   // 40 x 16 halo tile
-constexpr int QP = QTX;                            // LDS row pitch (floats; 16-B aligned rows)
+// Tile shape QX x QY (256 pixels; a template parameter since round 3): 32 x 8 where the width is a multiple of 32, 16 x 16 where
+// it is only a multiple of 16 -- at 96x112 (the heaviest level) the fourth 32-wide tile of a row was half empty: 12.5 % of the
+// lanes of every block idle.  Halo tile (QX + 8) x (QY + 8).
 constexpr int QC = 8;                              // channels per LDS stage
-// Forward tile pitch: a 16-lane pass of ds_read_b128 covers two tile rows (8 quads = 128 B each); with the natural 160-B
-// pitch the second row's window wraps onto the first row's banks (2-way conflict on every window read).  384 B = 128 B
-// (mod 256 B) puts consecutive rows on disjoint bank halves.
-constexpr int FP = 96;
+// Forward tile pitch: a 16-lane pass of ds_read_b128 covers two tile rows of a 32-wide tile (8 quads = 128 B each); with the
+// natural 160-B pitch the second row's window wraps onto the first row's banks (2-way conflict on every window read).  384 B =
+// 128 B (mod 256 B) puts consecutive rows on disjoint bank halves.  16-wide tiles: four rows per pass, 192 B = 64 B x 3 (mod
+// 256 B) puts them on the four bank quarters.
+template <int QX> struct QTile { static constexpr int FP = QX == 32 ? 96 : 48, BP = QX == 32 ? QX + 2 * HALO : 48; };
 
+#ifndef CORR_NT_STORE
+#define CORR_NT_STORE 1   // 1: an 81-plane output too large for the caches (56 % of the forward's bytes) is stored non-temporally
+                          // (96x112x64: 124 -> 110 us; at 48x56x64, 56 MB, the consumer still finds it in L2 / MALL and nt stores
+                          // cost 12 %: the launcher decides by size); 0: A/B
+#endif
 #ifndef CORR_ABL
 #define CORR_ABL 0      // ablation builds (timing only): 1 = no output stores, 2 = no FMA loop, 3 = no global loads in the staging
 #endif
@@ -124,15 +130,18 @@ typedef float f32x4c __attribute__((ext_vector_type(4)));
 typedef float f32x2c __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // dword-aligned 16-B global access
 
+template <int QX, int QY>
 __global__ __launch_bounds__(192) void corr81_fwd4_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                          float* __restrict__ out, int C, int H, int W, long f1_bs,
-                                                         long f2_bs, long out_bs, int fuse_lrelu) {
+                                                         long f2_bs, long out_bs, int fuse_lrelu, int nt_store) {
+  static_assert(QX * QY == 256 && (QX == 32 || QX == 16), "256-pixel tiles of 32 x 8 or 16 x 16");
+  constexpr int QTX = QX + 2 * HALO, QTY = QY + 2 * HALO, FP = QTile<QX>::FP, NQ = QX / 4;
   __shared__ __attribute__((aligned(16))) float tile[QC][QTY][FP];
   __shared__ __attribute__((aligned(16))) float t1[QC][QY][QX];      // the block's own f1 pixels
   const int tid = threadIdx.x;
   const int grp = tid / 64;                       // vertical displacements 3*grp .. 3*grp + 2
   const int t64 = tid - grp * 64;
-  const int q = t64 & 7, ty = t64 >> 3;           // quad column (4 pixels), tile row
+  const int q = t64 % NQ, ty = t64 / NQ;          // quad column (4 pixels), tile row
   // XCD-major tile order (common.h): the tiles of one XCD are neighbours, their 2.5x halo overlap is served by that XCD's L2
   const unsigned tpos = irr_xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
   const int x0 = (int)(tpos % gridDim.x) * QX, y0 = (int)((tpos / gridDim.x) % gridDim.y) * QY, b = (int)(tpos / (gridDim.x * gridDim.y));
@@ -264,7 +273,10 @@ __global__ __launch_bounds__(192) void corr81_fwd4_kernel(const float* __restric
           if (fuse_lrelu) t = irr_lrelu(t);
           v[i] = t;
         }
-        if (CORR_ABL != 1 || v[0] == 12345.f) *(f32x4c*)(o + (long)((3 * grp + r) * 9 + d) * plane) = v;
+        if (CORR_ABL != 1 || v[0] == 12345.f) {
+          if (CORR_NT_STORE && nt_store) __builtin_nontemporal_store(v, (f32x4c*)(o + (long)((3 * grp + r) * 9 + d) * plane));
+          else *(f32x4c*)(o + (long)((3 * grp + r) * 9 + d) * plane) = v;
+        }
       }
   };
   if (pow2) store_all([&](float v) { return v * rc; });
@@ -334,17 +346,19 @@ __global__ __launch_bounds__(256) void corr81_bwd_kernel(const float* __restrict
 // meet in LDS once per 8-channel stage (one 16-B write per channel and lane, 16-B global stores of full 128-B lines).
 //   SECOND == false: g1[c,p] = (1/C) sum_d g[d][p]   * f2[c][p+d]     (tile = f2)
 //   SECOND == true : g2[c,p] = (1/C) sum_d g[d][p-d] * f1[c][p-d]     (tile = f1, window mirrored)
-template <bool SECOND>
+template <bool SECOND, int QX, int QY>
 __global__ __launch_bounds__(192) void corr81_bwd4_kernel(const float* __restrict__ other, const float* __restrict__ gout,
                                                          const float* __restrict__ fwd_out, float* __restrict__ gin,
                                                          int C, int H, int W, long other_bs, long gout_bs, long out_bs,
                                                          long gin_bs) {
+  static_assert(QX * QY == 256 && (QX == 32 || QX == 16), "256-pixel tiles of 32 x 8 or 16 x 16");
+  constexpr int QTX = QX + 2 * HALO, QTY = QY + 2 * HALO, QP = QTile<QX>::BP, NQ = QX / 4;
   __shared__ __attribute__((aligned(16))) float tile[QC][QTY][QP];
   __shared__ __attribute__((aligned(16))) float red[3][QC][QY][QX];
   const int tid = threadIdx.x;
   const int grp = tid / 64;
   const int t64 = tid - grp * 64;
-  const int q = t64 & 7, ty = t64 >> 3;
+  const int q = t64 % NQ, ty = t64 / NQ;
   // XCD-major tile order (common.h): the tiles of one XCD are neighbours, their 2.5x halo overlap is served by that XCD's L2
   const unsigned tpos = irr_xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
   const int x0 = (int)(tpos % gridDim.x) * QX, y0 = (int)((tpos / gridDim.x) % gridDim.y) * QY, b = (int)(tpos / (gridDim.x * gridDim.y));
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(192) void corr81_bwd4_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < K2; ++k) {
       const int i = tid + k * 192;
-      if (i < N2) *(f32x4c*)(&tile[0][0][0] + 4 * i) = v2[k];
+      if (i < N2) *(f32x4c*)(&tile[0][0][0] + (i / RU) * QP + (i % RU) * 4) = v2[k];      // (row i / RU of [c][sy], 16-B column i % RU)
     }
     __syncthreads();
     if (c0 + QC < C) issue(c0 + QC);
@@ -477,6 +491,12 @@ __global__ __launch_bounds__(192) void corr81_bwd4_kernel(const float* __restric
   }
 }
 
+// 16 x 16 tiles where they waste fewer lanes than 32 x 8 ones (96x112: 7 full tiles per row instead of 3.5); IRR_CORR_TILE32=1: A/B
+static bool corr_tile16(int W) {
+  if (IRR_ENV_FLAG("IRR_CORR_TILE32")) return false;
+  return irr_cdiv(W, 16) * 16 < irr_cdiv(W, 32) * 32;
+}
+
 }  // namespace
 
 extern "C" int irr_corr81_fwd_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, long f1_bs,
@@ -484,10 +504,15 @@ extern "C" int irr_corr81_fwd_f32(const float* f1, const float* f2, float* out, 
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !f1 || !f2 || !out) return IRR_EINVAL;
   if (B > 65535) return IRR_EINVAL;
   dim3 grid(irr_cdiv(W, TS), irr_cdiv(H, TS), B);
-  dim3 grid4(irr_cdiv(W, QX), irr_cdiv(H, QY), B);
   if ((W & 3) == 0 && ((f1_bs | out_bs) & 3) == 0 && (((uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)out) & 15) == 0 && ((f2_bs & 3) == 0) && !IRR_ENV_FLAG("IRR_CORR_SCALAR")) {
-    hipLaunchKernelGGL(corr81_fwd4_kernel, grid4, dim3(192), 0, (hipStream_t)stream, f1, f2, out, C, H, W, f1_bs, f2_bs,
-                       out_bs, fuse_lrelu);
+    const int nt = (long)B * 81 * H * W * 4 > (128L << 20) ? 1 : 0;      // output beyond the L2s + most of the MALL: stream it out
+    if (corr_tile16(W)) {
+      hipLaunchKernelGGL((corr81_fwd4_kernel<16, 16>), dim3(irr_cdiv(W, 16), irr_cdiv(H, 16), B), dim3(192), 0, (hipStream_t)stream, f1, f2,
+                         out, C, H, W, f1_bs, f2_bs, out_bs, fuse_lrelu, nt);
+    } else {
+      hipLaunchKernelGGL((corr81_fwd4_kernel<32, 8>), dim3(irr_cdiv(W, 32), irr_cdiv(H, 8), B), dim3(192), 0, (hipStream_t)stream, f1, f2,
+                         out, C, H, W, f1_bs, f2_bs, out_bs, fuse_lrelu, nt);
+    }
     IRR_LAUNCH_CHECK();
     return 0;
   }
@@ -506,15 +531,20 @@ extern "C" int irr_corr81_bwd_f32(const float* f1, const float* f2, const float*
   const bool al16 = (((uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)gout | (uintptr_t)out | (uintptr_t)g1 | (uintptr_t)g2) & 15) == 0 &&
                     ((f1_bs | f2_bs | gout_bs | out_bs | g1_bs | g2_bs) & 3) == 0;
   if ((W & 3) == 0 && al16 && !IRR_ENV_FLAG("IRR_CORR_SCALAR")) {
-    dim3 grid4(irr_cdiv(W, QX), irr_cdiv(H, QY), B);
+    const bool t16 = corr_tile16(W);
+    const dim3 grid4 = t16 ? dim3(irr_cdiv(W, 16), irr_cdiv(H, 16), B) : dim3(irr_cdiv(W, 32), irr_cdiv(H, 8), B);
     if (g1) {
-      hipLaunchKernelGGL(corr81_bwd4_kernel<false>, grid4, dim3(192), 0, (hipStream_t)stream, f2, gout, out, g1, C, H, W, f2_bs,
-                         gout_bs, out_bs, g1_bs);
+      if (t16) hipLaunchKernelGGL((corr81_bwd4_kernel<false, 16, 16>), grid4, dim3(192), 0, (hipStream_t)stream, f2, gout, out, g1, C, H, W,
+                                  f2_bs, gout_bs, out_bs, g1_bs);
+      else hipLaunchKernelGGL((corr81_bwd4_kernel<false, 32, 8>), grid4, dim3(192), 0, (hipStream_t)stream, f2, gout, out, g1, C, H, W,
+                              f2_bs, gout_bs, out_bs, g1_bs);
       IRR_LAUNCH_CHECK();
     }
     if (g2) {
-      hipLaunchKernelGGL(corr81_bwd4_kernel<true>, grid4, dim3(192), 0, (hipStream_t)stream, f1, gout, out, g2, C, H, W, f1_bs,
-                         gout_bs, out_bs, g2_bs);
+      if (t16) hipLaunchKernelGGL((corr81_bwd4_kernel<true, 16, 16>), grid4, dim3(192), 0, (hipStream_t)stream, f1, gout, out, g2, C, H, W,
+                                  f1_bs, gout_bs, out_bs, g2_bs);
+      else hipLaunchKernelGGL((corr81_bwd4_kernel<true, 32, 8>), grid4, dim3(192), 0, (hipStream_t)stream, f1, gout, out, g2, C, H, W,
+                              f1_bs, gout_bs, out_bs, g2_bs);
       IRR_LAUNCH_CHECK();
     }
     return 0;

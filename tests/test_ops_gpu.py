@@ -133,6 +133,28 @@ def test_cost_volume_full_size_properties():
     assert torch.allclose(cv[:, 47, :-1, 2:], ref, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 32, 48), (1, 16, 20, 112), (2, 8, 17, 16), (1, 12, 9, 80)])
+def test_cost_volume_16x16_tiles_vs_oracle(shape):
+    """Widths that are a multiple of 16 but not of 32 (48, 112, 16, 80) run the quad kernels on 16 x 16 tiles (round 3: 7 full
+    tiles per row at 96x112 instead of 3.5): values with the fused LeakyReLU and both gradients against the oracle, and
+    against the 32 x 8 tiles of the same library (IRR_CORR_TILE32 is read once per process, so that A/B lives in tools/corr_bench.py)."""
+    from irr_amd import functional as Fn
+    from oracle import irr_pwc_oracle as O
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(W)
+    f1 = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    f2 = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    go = torch.randn(B, 81, H, W, generator=g)
+    ref = torch.nn.functional.leaky_relu(O.cost_volume(f1, f2), 0.1)
+    ref.backward(go)
+    a, b = f1.detach().cuda().requires_grad_(True), f2.detach().cuda().requires_grad_(True)
+    out = Fn.cost_volume(a, b, lrelu=True)
+    out.backward(go.cuda())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), f1.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), f2.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_warp_swap_halves_equals_swapped_copy():
     """swap_halves=True warps the OTHER batch half of x (the model's [x1; x2] / [x2; x1] pairing) without the copy: values,
     the gradient scattered into the other half of gx, and the flow gradient equal those of an explicit torch.cat swap"""
