@@ -60,6 +60,75 @@ __global__ __launch_bounds__(256) void conv_smallco_fwd_kernel(const float* __re
   }
 }
 
+// The same sums for planes of a few hundred pixels with many input channels (conv_last 565 -> 2 at 6x7 and 12x14, where the
+// quad kernel's W % 4 == 0 does not hold): the kernel above launches ONE block per sample there and walks the 565 channels
+// serially (235 us at 6x7x64).  Here a block is 64 pixels x KSL channel slices (wave k: channels k, k + KSL, ...) whose partial
+// sums meet in LDS, like conv_smallco_fwd4_kernel.
+template <int NC, int KS, int KSL>
+__global__ __launch_bounds__(64 * KSL) void conv_smallco_fwd_sl_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                      const float* __restrict__ bias, const float* __restrict__ res,
+                                                                      float* __restrict__ y, int Cin, int H, int W, int dil,
+                                                                      long x_bs, long y_bs, long res_bs, int lrelu, float alpha,
+                                                                      int accumulate) {
+  constexpr int KK = KS * KS;
+  __shared__ float red[(KSL - 1) * NC * 64];
+  const int lane = threadIdx.x & 63;
+  const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hw = H * W;
+  const int p = blockIdx.x * 64 + lane;
+  const bool pok = p < hw;
+  const int b = blockIdx.y;
+  const int oy = (pok ? p : 0) / W, ox = (pok ? p : 0) - oy * W;
+  const int pad = ((KS - 1) * dil) / 2;
+  int off[KK];
+  bool ok[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) {
+    const int iy = oy - pad + (t / KS) * dil, ix = ox - pad + (t % KS) * dil;
+    ok[t] = pok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    off[t] = ok[t] ? iy * W + ix : 0;
+  }
+  float acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+  const float* xb = x + (long)b * x_bs;
+#pragma unroll 2
+  for (int ci = ks; ci < Cin; ci += KSL) {
+    const float* xc = xb + (long)ci * hw;
+    float v[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      const float l = xc[off[t]];
+      v[t] = ok[t] ? l : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float* wc = w + ((long)c * Cin + ci) * KK;      // wave-uniform -> scalar loads
+#pragma unroll
+      for (int t = 0; t < KK; ++t) acc[c] = fmaf(wc[t], v[t], acc[c]);
+    }
+  }
+  if (ks > 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) red[((ks - 1) * NC + c) * 64 + lane] = acc[c];
+  }
+  __syncthreads();
+  if (ks > 0 || !pok) return;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int k = 0; k < KSL - 1; ++k) v += red[(k * NC + c) * 64 + lane];
+    v += bias ? bias[c] : 0.f;
+    if (lrelu) v = irr_lrelu(v);
+    float* dst = y + (long)b * y_bs + (long)c * hw + p;
+    if (res) v = res[(long)b * res_bs + (long)c * hw + p] + alpha * v;
+    else v *= alpha;
+    if (accumulate) v += *dst;
+    *dst = v;
+  }
+}
+
 // ws[co][tap][ci] += sum over this block's pixels of gy[co][p] * x[ci][p + off(tap)]
 template <int NC, int KS>
 __global__ __launch_bounds__(256) void conv_smallco_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
@@ -659,6 +728,19 @@ extern "C" int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const 
     }
 #undef IRR_FWD4_R
 #undef IRR_FWD4
+    IRR_LAUNCH_CHECK();
+    return 0;
+  }
+  if (k == 3 && Cout <= 2 && Cin >= 64 && (long)H * W <= 4096 && (long)irr_cdiv((long)H * W, 256) * B < 512 &&
+      !IRR_ENV_FLAG("IRR_SMALLCO_NO_SLICES")) {
+    // few pixels, many channels: 16 channel slices per 64 pixels
+    const dim3 gs(irr_cdiv((long)H * W, 64), B, 1);
+    if (Cout == 1)
+      hipLaunchKernelGGL((conv_smallco_fwd_sl_kernel<1, 3, 16>), gs, dim3(1024), 0, (hipStream_t)stream, x, w, bias, res, y, Cin, H, W,
+                         dil, x_bs, y_bs, res_bs, lrelu, alpha, accumulate);
+    else
+      hipLaunchKernelGGL((conv_smallco_fwd_sl_kernel<2, 3, 16>), gs, dim3(1024), 0, (hipStream_t)stream, x, w, bias, res, y, Cin, H, W,
+                         dil, x_bs, y_bs, res_bs, lrelu, alpha, accumulate);
     IRR_LAUNCH_CHECK();
     return 0;
   }

@@ -98,6 +98,90 @@ __global__ __launch_bounds__(256) void corr81_fwd_kernel(const float* __restrict
   }
 }
 
+// ---- tiny planes whose width is not a multiple of 4 (the 6x7 and 12x14 pyramid levels) ----------------------------------------
+// The 16 x 16-tile kernels launch ONE block per sample there (64 blocks, 42 or 168 of 256 lanes busy) and walk the channels
+// serially: 185 us for 86 MFLOP at 6x7x64x196.  These variants spread the same sums over the chip.
+//   forward : a block = 64 pixels x 4 channel slices of ONE displacement (81 x chunks x B blocks), slices meet in LDS;
+//   gradient: a block = 64 pixels x 4 waves, each wave a few channels (grid.y splits the channels until ~512 blocks exist); the 81
+//             weights of a pixel (output gradient x LeakyReLU') live in registers, summed in the same order as corr81_bwd_kernel.
+__global__ __launch_bounds__(256) void corr81_small_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                              float* __restrict__ out, int C, int H, int W, long f1_bs,
+                                                              long f2_bs, long out_bs, int fuse_lrelu) {
+  __shared__ float red[3][64];
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int d = blockIdx.x, b = blockIdx.z;
+  const int dy = d / 9 - HALO, dx = d % 9 - HALO;
+  const int plane = H * W;
+  const int p = blockIdx.y * 64 + lane;
+  const bool pok = p < plane;
+  const int y = p / W, x = p - y * W;
+  const int y2 = y + dy, x2 = x + dx;
+  const bool ok = pok && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+  const float* a = f1 + (long)b * f1_bs + (ok ? p : 0);
+  const float* o = f2 + (long)b * f2_bs + (ok ? y2 * W + x2 : 0);
+  float s = 0.f;
+#pragma unroll 4
+  for (int c = sl; c < C; c += 4) s = fmaf(a[(long)c * plane], o[(long)c * plane], s);
+  if (!ok) s = 0.f;
+  if (sl) red[sl - 1][lane] = s;
+  __syncthreads();
+  if (sl || !pok) return;
+  s = (s + red[0][lane]) + (red[1][lane] + red[2][lane]);
+  float v = s / (float)C;
+  if (fuse_lrelu) v = irr_lrelu(v);
+  out[(long)b * out_bs + (long)d * plane + p] = v;
+}
+
+template <bool SECOND>
+__global__ __launch_bounds__(256) void corr81_small_bwd_kernel(const float* __restrict__ other, const float* __restrict__ gout,
+                                                              const float* __restrict__ fwd_out, float* __restrict__ gin,
+                                                              int C, int H, int W, long other_bs, long gout_bs, long out_bs,
+                                                              long gin_bs, int cpb) {
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int b = blockIdx.z;
+  const int plane = H * W;
+  const int p = blockIdx.x * 64 + lane;
+  const bool pok = p < plane;
+  const int y = p / W, x = p - y * W;
+  const float* gb = gout + (long)b * gout_bs;
+  const float* fb = fwd_out ? fwd_out + (long)b * out_bs : nullptr;
+  float wgt[81];
+#pragma unroll
+  for (int d = 0; d < 81; ++d) {
+    const int dy = d / 9 - HALO, dx = d % 9 - HALO;
+    const int yo = SECOND ? y - dy : y + dy, xo = SECOND ? x - dx : x + dx;      // position read in the other map
+    const bool ok = pok && yo >= 0 && yo < H && xo >= 0 && xo < W;
+    const int go = ok ? (SECOND ? yo * W + xo : p) : 0;                            // position of the output gradient
+    float g = gb[(long)d * plane + go];
+    if (fb) g *= irr_lrelu_grad(fb[(long)d * plane + go]);
+    wgt[d] = ok ? g : 0.f;
+  }
+  // The other map is read through a buffer resource over this sample's C planes at p +- d WITHOUT a per-displacement offset
+  // register: positions outside the image carry weight 0 and land in a neighbouring row / plane or, beyond the sample, in the
+  // hardware bounds check (returns 0) -- 81 weights are all the kernel keeps per lane (333 -> ~110 VGPRs: four waves per SIMD).
+  const uint32_t obytes = (uint32_t)min((long)0x7ffffffcL, (long)C * plane * 4);
+  const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)(other + (long)b * other_bs), (short)0, (int)obytes, 0x00020000);
+  const float inv_c = 1.f / (float)C;
+  const int c_end = min(C, ((int)blockIdx.y + 1) * cpb);
+  for (int c = blockIdx.y * cpb + sl; c < c_end; c += 4) {
+    const uint32_t vo = (uint32_t)(c * plane + p) * 4u;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 81; ++d) {
+      const int dy = d / 9 - HALO, dx = d % 9 - HALO;
+      const int sh = (SECOND ? -(dy * W + dx) : dy * W + dx) * 4;                  // wave-uniform
+      s = fmaf(wgt[d], __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(orr, (int)(vo + (uint32_t)sh), 0, 0)), s);
+    }
+    if (pok) gin[(long)b * gin_bs + (long)c * plane + p] = s * inv_c;
+  }
+}
+
+// the 16 x 16-tile launch would leave most of the chip empty
+static inline bool corr_small(int B, int H, int W) {
+  static const int off = IRR_ENV_FLAG("IRR_CORR_NO_SMALL");
+  return !off && (long)irr_cdiv(W, TS) * irr_cdiv(H, TS) * B < 512 && (long)H * W <= 65536;
+}
+
 // ---- forward, quad variant (W % 4 == 0) ----------------------------------------------------------------------------
 // The kernel above issues one LDS read per FMA (81 per channel and pixel), stages its tile one dword at a time and
 // writes 64-B row segments: 317 us at 96x112x64 (1.3 TB/s of algorithmic traffic).  Here
@@ -516,8 +600,12 @@ extern "C" int irr_corr81_fwd_f32(const float* f1, const float* f2, float* out, 
     IRR_LAUNCH_CHECK();
     return 0;
   }
-  hipLaunchKernelGGL(corr81_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, f1, f2, out, C, H, W, f1_bs, f2_bs,
-                     out_bs, fuse_lrelu);
+  if (corr_small(B, H, W))
+    hipLaunchKernelGGL(corr81_small_fwd_kernel, dim3(81, irr_cdiv(H * W, 64), B), dim3(256), 0, (hipStream_t)stream, f1, f2, out, C, H,
+                       W, f1_bs, f2_bs, out_bs, fuse_lrelu);
+  else
+    hipLaunchKernelGGL(corr81_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, f1, f2, out, C, H, W, f1_bs, f2_bs,
+                       out_bs, fuse_lrelu);
   IRR_LAUNCH_CHECK();
   return 0;
 }
@@ -545,6 +633,24 @@ extern "C" int irr_corr81_bwd_f32(const float* f1, const float* f2, const float*
                                   f1_bs, gout_bs, out_bs, g2_bs);
       else hipLaunchKernelGGL((corr81_bwd4_kernel<true, 32, 8>), grid4, dim3(192), 0, (hipStream_t)stream, f1, gout, out, g2, C, H, W,
                               f1_bs, gout_bs, out_bs, g2_bs);
+      IRR_LAUNCH_CHECK();
+    }
+    return 0;
+  }
+  if (corr_small(B, H, W)) {
+    const int chunks = irr_cdiv(H * W, 64);
+    int cs = irr_cdiv(512, chunks * B);                            // channel splits: ~512 blocks
+    cs = cs < 1 ? 1 : (cs > irr_cdiv(C, 4) ? irr_cdiv(C, 4) : cs);
+    const int cpb = irr_cdiv(irr_cdiv(C, cs), 4) * 4;               // channels per block, a multiple of the four waves
+    const dim3 gs(chunks, irr_cdiv(C, cpb), B);
+    if (g1) {
+      hipLaunchKernelGGL(corr81_small_bwd_kernel<false>, gs, dim3(256), 0, (hipStream_t)stream, f2, gout, out, g1, C, H, W, f2_bs,
+                         gout_bs, out_bs, g1_bs, cpb);
+      IRR_LAUNCH_CHECK();
+    }
+    if (g2) {
+      hipLaunchKernelGGL(corr81_small_bwd_kernel<true>, gs, dim3(256), 0, (hipStream_t)stream, f1, gout, out, g2, C, H, W, f1_bs,
+                         gout_bs, out_bs, g2_bs, cpb);
       IRR_LAUNCH_CHECK();
     }
     return 0;
