@@ -407,6 +407,34 @@ def test_conv_smallco_quad_kernels(cout):
     np.testing.assert_allclose(gb.cpu().numpy(), 2 * gy.double().sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(64, 6, 7), (64, 12, 14), (3, 9, 11)])
+@pytest.mark.parametrize("cout", [1, 2])
+def test_conv_smallco_tiny_planes_channel_slices(cout, shape):
+    """conv_last at the 6x7 / 12x14 pyramid levels (W % 4 != 0, 565 input channels, BASELINE batch): the scalar kernel with 16
+    channel slices per 64 pixels (conv_smallco_fwd_sl_kernel) -- bias + LeakyReLU, residual + alpha and accumulate on a
+    channel-slice view, against fp64 on the host."""
+    from irr_amd import conv as C
+    B, H, W = shape
+    cin = 563 + cout % 2 * 2                                  # 565 -> 1 and 563 -> 2
+    g = torch.Generator().manual_seed(300 + cout + H)
+    big = torch.randn(B, cin + 3, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, H, W, generator=g)
+    x = big[:, 3:]
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xd = big.cuda()[:, 3:]
+    y = C.conv_forward(xd, w.cuda(), b.cuda(), 1, 1, True)
+    np.testing.assert_allclose(y.cpu().numpy(), F.leaky_relu(ref, 0.1).numpy(), rtol=1e-5, atol=2e-5)
+    y = C.conv_forward(xd, w.cuda(), b.cuda(), 1, 1, False, res=res.cuda(), alpha=0.5)
+    np.testing.assert_allclose(y.cpu().numpy(), (res.double() + 0.5 * ref).numpy(), rtol=1e-5, atol=2e-5)
+    base = torch.randn(B, cout, H, W, generator=g)
+    acc = base.clone().cuda()
+    C.conv_forward(xd, w.cuda(), None, 1, 1, False, out=acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), (base.double() + F.conv2d(x.double(), w.double(), None, padding=1)).numpy(),
+                               rtol=1e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("cout", [1, 2])
 def test_conv_smallco_heads_large_level(cout):
     """The head kernels in their large-level configuration (>= 400000 pixels: four output rows per thread, channel split

@@ -155,6 +155,35 @@ def test_cost_volume_16x16_tiles_vs_oracle(shape):
     np.testing.assert_allclose(b.grad.cpu().numpy(), f2.grad.numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(64, 196, 6, 7), (64, 128, 12, 14), (3, 21, 5, 9), (2, 7, 31, 33)])
+def test_cost_volume_tiny_planes_vs_oracle(shape):
+    """Planes whose width is not a multiple of 4: at the BASELINE batch the 6x7 and 12x14 levels run corr81_small_fwd_kernel /
+    corr81_small_bwd_kernel (pixels x channel slices x displacements over the chip instead of one 16 x 16 tile per sample); the
+    last shape is large enough to stay on the tile kernels.  Values with the fused LeakyReLU and both gradients against the oracle."""
+    from irr_amd import functional as Fn
+    from oracle import irr_pwc_oracle as O
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(H * W)
+    f1 = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    f2 = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    go = torch.randn(B, 81, H, W, generator=g)
+    ref = torch.nn.functional.leaky_relu(O.cost_volume(f1, f2), 0.1)
+    ref.backward(go)
+    a, b = f1.detach().cuda().requires_grad_(True), f2.detach().cuda().requires_grad_(True)
+    out = Fn.cost_volume(a, b, lrelu=True)
+    out.backward(go.cuda())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), f1.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), f2.grad.numpy(), rtol=1e-5, atol=1e-6)
+    # without the fused activation (no mask operand in the gradient kernels)
+    a2, b2 = f1.detach().cuda().requires_grad_(True), f2.detach().cuda().requires_grad_(True)
+    Fn.cost_volume(a2, b2).backward(go.cuda())
+    f1.grad = f2.grad = None
+    O.cost_volume(f1, f2).backward(go)
+    np.testing.assert_allclose(a2.grad.cpu().numpy(), f1.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(b2.grad.cpu().numpy(), f2.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_warp_swap_halves_equals_swapped_copy():
     """swap_halves=True warps the OTHER batch half of x (the model's [x1; x2] / [x2; x1] pairing) without the copy: values,
     the gradient scattered into the other half of gx, and the flow gradient equal those of an explicit torch.cat swap"""
