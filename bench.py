@@ -316,7 +316,8 @@ def main():
                "conv_math": C.MATH,
                "launches_per_step": head["routing"],
                "step_conv_tflops": round(value / world * gf * 1e9 / 1e12, 1) if gf else None,
-               "step_mfma_frac": round(value / world * gf * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4) if gf else None,
+               # whole-step conv rate over the fp32-MFMA peak (157.3): above 1 because the x3 family runs fp32 products on the bf16 pipe
+               "step_conv_vs_fp32_mfma_peak": round(value / world * gf * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4) if gf else None,
                "roofline": head["roofline"]}
         if second is not None:
             gf2 = CONV_GFLOP_PER_PAIR[(SECONDARY[1], SECONDARY[2])]
