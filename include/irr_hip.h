@@ -185,6 +185,13 @@ int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bias, const f
                       long x_bs, long y_bs, long res_bs,
                       int lrelu, float alpha, int accumulate,
                       const float* mask, long mask_bs, int nmask, void* stream);
+/* irr_conv2d_fwd_x3 with a SECOND output, for the problems the streaming 32-channel kernel takes (irr_conv2d_x3_eligible ==
+ * 9001; anything else, or res == NULL, is rejected with IRR_EINVAL): y2 = alpha * act(conv(x) + bias) and y = res + y2.
+ * A skip connection whose branch output is needed again in backward -- x_init + res_end_conv(x_res),
+ * models/irr_modules.py:54 -- then costs no elementwise pass over two 32-channel full-resolution maps. */
+int irr_conv2d_fwd_x3_dual(const float* x, const void* wq, const float* bias, const float* res, float* y, float* y2,
+                           int B, int Cin, int H, int W, int Cout, int dil,
+                           long x_bs, long y_bs, long res_bs, long y2_bs, int lrelu, float alpha, void* stream);
 /* Small pyramid levels (launches of fewer blocks than the chip has slots): the same kernel with blockIdx.z splitting the
  * 16-channel chunks (K); the slices store raw partial sums into ws and a second kernel sums them and applies the epilogue.
  * irr_conv2d_fwd_x3_ws_elems: floats of scratch the problem needs (0 = runs unsplit, use irr_conv2d_fwd_x3).
@@ -337,6 +344,20 @@ int irr_epe_sum_multi_fwd_f32(const void* terms, int nterms, float* out, void* s
 int irr_epe_sum_multi_bwd_f32(const void* terms, int nterms, const float* gscale, void* stream);
 int irr_f1bal_multi_fwd_f32(const void* terms, int nterms, float* out, void* stream);
 int irr_f1bal_multi_bwd_f32(const void* terms, int nterms, const float* gscale, void* stream);
+
+/* ---- channel concatenation in one launch --------------------------------------------------------------
+ * Replaces torch.cat on the decoder / upsampler inputs (models/IRR_PWC.py:104-107, 166-167; models/pwc_modules.py:164-168 builds
+ * its DenseNet buffer the same way): `parts` is a HOST array of nparts (<= IRR_CAT_MAX_PARTS) records, copied into the kernel
+ * arguments.  Part i = (B, channels_i, hw) with dense planes and batch stride src_bs (elements) is written to the channels
+ * [sum_{j<i} channels_j, ...) of dst (batch stride dst_bs, channel stride hw); src == NULL writes zeros. */
+#define IRR_CAT_MAX_PARTS 8
+typedef struct IrrCatPart {
+  const float* src;
+  long src_bs;
+  int channels;
+  int reserved;
+} IrrCatPart;
+int irr_cat_channels_f32(float* dst, long dst_bs, const void* parts, int nparts, int B, long hw, void* stream);
 
 /* ---- fused Adam over one flat arena ------------------------------------------------------------------
  * torch.optim.Adam semantics (runtime.py:189; lr 1e-4, weight_decay 4e-4 as L2-in-gradient,

@@ -293,6 +293,27 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return out
 
 
+def conv_forward_skip(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], lrelu: bool, skip: torch.Tensor):
+    """(e, y) with e = act(conv3x3(x) + bias) and y = skip + e.  On the streaming 32-channel kernel both come out of ONE launch
+    (irr_conv2d_fwd_x3_dual); elsewhere e is computed and the sum is an elementwise pass."""
+    B, cin, H, W = x.shape
+    cout = weight.shape[0]
+    if x3_code(B, cin, H, W, cout, 3, 1, 1) == 9001 and _planes_dense(skip) and not os.environ.get("IRR_X3S_NO_DUAL"):      # (A/B switch)
+        e = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+        y = torch.empty_like(e)
+        wq = packed_weights_x3(weight, False)
+        LAUNCHES["fwd_x3s"] += 1
+        args = ("irr_conv2d_fwd_x3_dual", hip.ptr(x), hip.ptr(wq), hip.ptr(bias.detach() if bias is not None else None), hip.ptr(skip),
+                hip.ptr(y), hip.ptr(e), B, cin, H, W, cout, 1, hip.bs(x), hip.bs(y), hip.bs(skip), hip.bs(e), int(lrelu), 1.0, hip.stream())
+        if TIMER is None:
+            hip.call(*args)
+        else:
+            TIMER.wrap(100000 + 9001, 2.0 * B * H * W * cout * cin * 9, lambda: hip.call(*args))
+        return e, y
+    e = conv_forward(x, weight, bias, 1, 1, lrelu)
+    return e, torch.add(skip, e)
+
+
 S2_GATHER_MAX_CIN = 96   # stride-2 3x3 data gradients with at most this many result channels use the 2x2-block kernel
                          # (measured at the BASELINE batch: faster up to 128 -> 96 at 24x28, slower for 196 -> 128 at 12x14; A/B: 0)
 
@@ -661,6 +682,32 @@ class _ConvBlock(hip.Function):
         return gx, gw, gb, None, None, None, gres, None
 
 
+class _CatPart(ctypes.Structure):
+    """IrrCatPart of include/irr_hip.h"""
+    _fields_ = [("src", ctypes.c_void_p), ("src_bs", ctypes.c_long), ("channels", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+CAT_MAX_PARTS = 8            # IRR_CAT_MAX_PARTS
+
+
+def cat_channels_into(dst: torch.Tensor, parts, zero_tail: int = 0) -> None:
+    """dst[:, :sum(channels)] = cat(parts, dim=1) (+ ``zero_tail`` zero channels behind them) in ONE launch
+    (irr_cat_channels_f32) -- dst is a channel-slice view of the consumer's buffer.  Parts whose planes are not dense are made
+    contiguous first."""
+    B, _, H, W = dst.shape
+    srcs = [p_ if _planes_dense(p_) else p_.contiguous() for p_ in parts]
+    recs = [(hip.ptr(p_), p_.stride(0), int(p_.shape[1])) for p_ in srcs]
+    if zero_tail > 0:
+        recs.append((None, 0, int(zero_tail)))
+    c0 = 0
+    for i in range(0, len(recs), CAT_MAX_PARTS):
+        chunk = recs[i:i + CAT_MAX_PARTS]
+        arr = (_CatPart * len(chunk))(*[_CatPart(s_, bs_, ch_, 0) for s_, bs_, ch_ in chunk])
+        view = dst[:, c0:]
+        hip.call("irr_cat_channels_f32", hip.ptr(view), dst.stride(0), ctypes.addressof(arr), len(chunk), B, H * W, hip.stream())
+        c0 += sum(ch_ for _, _, ch_ in chunk)
+
+
 def _planes_dense(t: torch.Tensor) -> bool:
     b, c, h, w = t.shape
     sb, sc, sh, sw = t.stride()
@@ -701,10 +748,7 @@ class _DenseEstimatorFn(hip.Function):
         ctot = 448 + cin0
         has_base = base is not None
         buf = torch.empty(B, ctot + (E if has_base else 0), H, W, device=parts[0].device, dtype=torch.float32)
-        c0 = 448
-        for p_, wd in zip(parts, widths):
-            buf[:, c0:c0 + wd].copy_(p_)
-            c0 += wd
+        cat_channels_into(buf[:, 448:], parts)
         off = 448
         for i in range(5):
             co = _DenseEstimatorFn.GROW[i]
@@ -994,12 +1038,7 @@ class _OccUpsampleFn(hip.Function):
         cin = sum(widths)
         cpad = 16 if (cin < 16 and x3_code(B, 16, H, W, w_init.shape[0], 3, 1, 1)) else cin
         x_in = torch.empty(B, cpad, H, W, device=occ_up.device, dtype=torch.float32)
-        c0 = 0
-        for p_, wd in zip(parts, widths):
-            x_in[:, c0:c0 + wd].copy_(p_)
-            c0 += wd
-        if cpad > cin:
-            x_in[:, cin:].zero_()
+        cat_channels_into(x_in, (occ_up,) + tuple(parts[1:]), zero_tail=cpad - cin)
         w_first = _padded_cin(w_init, cpad) if cpad > cin else w_init
         x_init = conv_forward(x_in, w_first, b_init, 1, 1, True)
         xs = [x_init]
@@ -1008,8 +1047,7 @@ class _OccUpsampleFn(hip.Function):
             t = conv_forward(xs[-1], w_r0, b_r0, 1, 1, True)
             ts.append(t)
             xs.append(conv_forward(t, w_r1, b_r1, 1, 1, False, res=xs[-1], alpha=mul_const))
-        e = conv_forward(xs[-1], w_end, b_end, 1, 1, True)
-        x2 = torch.add(x_init, e)
+        e, x2 = conv_forward_skip(xs[-1], w_end, b_end, True, x_init)
         o = conv_forward(x2, w_out, b_out, 1, 1, True)
         out = torch.add(o, occ_up)
         ctx.mul_const = mul_const

@@ -325,6 +325,8 @@ struct X3SArgs {
   int nmask;
   unsigned long long* dbg;      // X3S_TRACE builds only
   int wCoT, wcot;               // co-tiles in the packed weights / the one this launch computes
+  float* y2;                    // EPI 3: second output, the value before the residual is added
+  long y2_bs;
 };
 
 // s_memtime trace points (IRR_X3S_TRACE=1 builds, tools/x3s_trace.py): block 7, lane 0 of every wave
@@ -338,7 +340,8 @@ struct X3SArgs {
 #define X3S_PRODUCERS_OLD 1   // 1: waves 0..3 produce, 4..7 run the MFMAs; 0 (A/B): the other way round
 #endif
 // EPI: what the epilogue has to read besides the accumulators -- 0: nothing (bias, LeakyReLU, alpha), 1: + a residual operand,
-// 2: everything (residual, accumulate-into-output, LeakyReLU'-mask).  The kernel is bound by the producer waves' VALU issue
+// 2: everything (residual, accumulate-into-output, LeakyReLU'-mask), 3: residual + a SECOND output y2 = the value before the
+// residual is added (y = res + y2; irr_conv2d_fwd_x3_dual).  The kernel is bound by the producer waves' VALU issue
 // slots (operand split + epilogue), so the plain layers do not pay for 24 operand loads and 5 unused VALU per output.
 template <int EPI>
 __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
     const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, (int)0x80000000u, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, (short)0, (int)0x80000000u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)a.mask, (short)0, (int)0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 3 ? a.y2 : a.y), (short)0, (int)0x80000000u, 0x00020000);
     // Staging unit = (k-group gg, patch row ly, aligned pixel quad q): 8 channels x 4 pixels as eight 16-B loads (the
     // vector-memory INSTRUCTION rate, not bandwidth, limited the dword version of this kernel).  The loaded window is
     // columns x0-4 .. x0+35 (ten aligned quads; only x0-1 and x0+32 of the two margin quads are used), so every
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias_r[e] = (a.bias && eq_c8 * 8 + e < a.Cout) ? a.bias[eq_c8 * 8 + e] : 0.f;
     f32x4 erv[8], edv[8], emv[8];
-    uint32_t evd = OOB;
+    uint32_t evd = OOB, evd2 = OOB;
     auto epilogue_loads = [&](const TileAt& at, bool valid) {
       const int tx = at.tx, ty = at.ty, b = at.b;
       const int oy = ty * 8 + eq_row, ox = tx * 32 + eq_q * 4;
@@ -448,6 +452,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
       const long pofs = (long)oy * a.W + ox + (long)eq_c8 * 8 * hw;
       const uint32_t vr = (EPI >= 1 && pv && a.res) ? (uint32_t)(((long)b * a.res_bs + pofs) * 4) : OOB;
       evd = pv ? (uint32_t)(((long)b * a.y_bs + pofs) * 4) : OOB;
+      if (EPI == 3) evd2 = pv ? (uint32_t)(((long)b * a.y2_bs + pofs) * 4) : OOB;
       const uint32_t vm = (EPI == 2 && pv && a.mask) ? (uint32_t)(((long)b * a.mask_bs + pofs) * 4) : OOB;
       if (EPI >= 1) {
 #pragma unroll
@@ -472,12 +477,13 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int co = eq_c8 * 8 + e;
-        f32x4 o;
+        f32x4 o, o2;
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
           float v = eacc[e][px] + bias_r[e];
           if (a.lrelu) v = irr_lrelu(v);
           if (EPI == 0) v *= a.alpha;
+          else if (EPI == 3) { v *= a.alpha; o2[px] = v; v = erv[e][px] + v; }
           else v = erv[e][px] + a.alpha * v;        // erv = 0 without a residual operand
           if (EPI == 2) {
             v += edv[e][px];                        // edv = 0 unless accumulating
@@ -487,6 +493,8 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, (int)((co < a.Cout && X3_ABL != 7 && X3_ABL != 10 && X3_ABL != 11) ? evd : OOB),
                                                (int)((uint32_t)e * hw4), 0);
+        if (EPI == 3)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o2), ry2, (int)(co < a.Cout ? evd2 : OOB), (int)((uint32_t)e * hw4), 0);
       }
     };
     TileAt at_prev = {0, 0, 0}, at_cur, at_next;            // tiles t - t_step (epilogue), t, t + t_step (loads in flight)
@@ -869,8 +877,9 @@ extern "C" long irr_conv2d_fwd_x3_ws_elems(int B, int Cin, int H, int W, int Cou
 static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const float* res, float* y, int B,
                        int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
                        float alpha, int accumulate, const float* mask, long mask_bs, int nmask, float* ws, long ws_elems,
-                       void* stream) {
+                       void* stream, float* y2 = nullptr, long y2_bs = 0) {
   if (!x || !wq || !y || B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1) return IRR_EINVAL;
+  if (y2 && (!res || accumulate || mask || !x3s_ok(B, Cin, H, W, Cout, dil))) return IRR_EINVAL;      // second output: streaming kernel only
   if (x3s_ok(B, Cin, H, W, Cout, dil)) {
     X3SArgs s;
     s.wq = (const u32x4*)wq; s.bias = bias;
@@ -893,12 +902,15 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
       IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       attr_set = true;
     }
     // every operand is addressed through 32-bit byte voffsets below the 2 GiB out-of-range marker
     long bsmax = x_bs > y_bs ? x_bs : y_bs;
     if (res && res_bs > bsmax) bsmax = res_bs;
     if (mask && mask_bs > bsmax) bsmax = mask_bs;
+    if (y2 && y2_bs > bsmax) bsmax = y2_bs;
+    s.y2 = nullptr; s.y2_bs = y2_bs;
     const long lim = (1L << 29) - (long)(Cin + 48) * H * W - 64;
     if (lim <= 0) return IRR_EINVAL;
     long per = bsmax > 0 ? lim / bsmax : B;
@@ -920,8 +932,10 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
         s.res = res ? res + (long)b0 * res_bs + co0 * hw_ : nullptr;
         s.mask = (mask && nmask > co0) ? mask + (long)b0 * mask_bs + co0 * hw_ : nullptr;
         s.nmask = nmask - (int)co0 < 0 ? 0 : (nmask - (int)co0 > 32 ? 32 : nmask - (int)co0);
-        const int epi = (s.accumulate || s.mask) ? 2 : s.res ? 1 : 0;
-        if (epi == 0) hipLaunchKernelGGL(conv_x3s_kernel<0>, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
+        s.y2 = y2 ? y2 + (long)b0 * y2_bs + co0 * hw_ : nullptr;
+        const int epi = (s.accumulate || s.mask) ? 2 : s.res ? (s.y2 ? 3 : 1) : 0;
+        if (epi == 3) hipLaunchKernelGGL(conv_x3s_kernel<3>, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
+        else if (epi == 0) hipLaunchKernelGGL(conv_x3s_kernel<0>, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
         else if (epi == 1) hipLaunchKernelGGL(conv_x3s_kernel<1>, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
         else hipLaunchKernelGGL(conv_x3s_kernel<2>, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
         IRR_LAUNCH_CHECK();
@@ -990,6 +1004,14 @@ extern "C" int irr_conv2d_fwd_x3(const float* x, const void* wq, const float* bi
                                  float alpha, int accumulate, const float* mask, long mask_bs, int nmask, void* stream) {
   return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, accumulate, mask, mask_bs, nmask,
                      nullptr, 0, stream);
+}
+
+extern "C" int irr_conv2d_fwd_x3_dual(const float* x, const void* wq, const float* bias, const float* res, float* y, float* y2, int B,
+                                      int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, long y2_bs,
+                                      int lrelu, float alpha, void* stream) {
+  if (!y2 || !res) return IRR_EINVAL;
+  return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, 0, nullptr, 0, 0, nullptr, 0, stream,
+                     y2, y2_bs);
 }
 
 extern "C" int irr_conv2d_fwd_x3_splitk(const float* x, const void* wq, const float* bias, const float* res, float* y, int B,

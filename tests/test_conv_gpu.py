@@ -574,6 +574,33 @@ def test_wgrad_x3_matches_fp32_kernel_at_baseline_sizes(case):
     assert (out["x3"][1] - out["f32"][1]).abs().max().item() <= 1e-5 * sb
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 40, 64), (1, 24, 22, 96), (3, 32, 8, 32)])
+def test_conv_x3s_second_output_is_the_unfused_pair(shape, x3_everywhere):
+    """irr_conv2d_fwd_x3_dual (conv_forward_skip): e = lrelu(conv(x) + b) and y = skip + e from one launch of the streaming kernel
+    are bit-identical to the plain launch followed by torch.add (the pair it replaces in the occlusion upsampler), ragged tiles and
+    a channel-slice view as input included; a problem the streaming kernel does not take falls back to that pair."""
+    from irr_amd import conv as C
+    B, cin, H, W = shape
+    g = torch.Generator().manual_seed(H * W + cin)
+    big = torch.randn(B, cin + 5, H, W, generator=g).cuda()
+    x = big[:, 5:]
+    w = (torch.randn(32, cin, 3, 3, generator=g) * 0.1).cuda()
+    b = torch.randn(32, generator=g).cuda()
+    skip = torch.randn(B, 32, H, W, generator=g).cuda()
+    assert C.x3_code(B, cin, H, W, 32, 3, 1, 1) == 9001
+    e, y = C.conv_forward_skip(x, w, b, True, skip)
+    e_ref = C.conv_forward(x, w, b, 1, 1, True)
+    assert torch.equal(e, e_ref)
+    assert torch.equal(y, torch.add(skip, e_ref))
+    ref = F.leaky_relu(F.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1), 0.1)
+    np.testing.assert_allclose(e.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    # not a streaming-kernel problem (64 input channels): the fallback pair
+    x64 = torch.randn(B, 64, H, W, generator=g).cuda()
+    w64 = (torch.randn(32, 64, 3, 3, generator=g) * 0.1).cuda()
+    e2, y2 = C.conv_forward_skip(x64, w64, b, True, skip)
+    assert torch.equal(y2, skip + e2) and torch.equal(e2, C.conv_forward(x64, w64, b, 1, 1, True))
+
+
 @pytest.mark.parametrize("nmask", [0, 40, 64])
 def test_conv_x3s_two_cotiles(nmask, x3_everywhere):
     """conv_x3s_kernel launched once per 32-channel co-tile (Cout = 64, Cin = 32): the forward epilogues and the data gradient

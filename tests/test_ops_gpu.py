@@ -184,6 +184,32 @@ def test_cost_volume_tiny_planes_vs_oracle(shape):
     np.testing.assert_allclose(b2.grad.cpu().numpy(), f2.grad.numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("hw", [(6, 7), (12, 16), (5, 3)])
+def test_cat_channels_one_launch(hw):
+    """irr_cat_channels_f32: parts (one of them a channel-slice view, one non-contiguous) land in consecutive channel slices of a
+    channel-slice view of the destination, zero tail behind them; 16-byte and scalar paths; more than IRR_CAT_MAX_PARTS parts."""
+    from irr_amd import conv as C
+    H, W = hw
+    B = 3
+    g = torch.Generator().manual_seed(H * 31 + W)
+    widths = [81, 32, 2, 1, 5, 7, 3, 4, 6, 2]
+    parts = []
+    for i, wd in enumerate(widths):
+        if i == 1:
+            parts.append(torch.randn(B, wd + 4, H, W, generator=g).cuda()[:, 3:3 + wd])            # channel-slice view
+        elif i == 2:
+            parts.append(torch.randn(B, H, W, wd, generator=g).cuda().permute(0, 3, 1, 2))         # planes not dense
+        else:
+            parts.append(torch.randn(B, wd, H, W, generator=g).cuda())
+    tot = sum(widths)
+    dst = torch.full((B, 5 + tot + 4 + 2, H, W), 7.0, device="cuda")
+    C.cat_channels_into(dst[:, 5:], parts, zero_tail=4)
+    ref = torch.cat([p_ for p_ in parts], dim=1)
+    assert torch.equal(dst[:, 5:5 + tot], ref)
+    assert torch.equal(dst[:, 5 + tot:5 + tot + 4], torch.zeros(B, 4, H, W, device="cuda"))
+    assert torch.equal(dst[:, :5], torch.full((B, 5, H, W), 7.0, device="cuda")) and torch.equal(dst[:, -2:], torch.full((B, 2, H, W), 7.0, device="cuda"))
+
+
 def test_warp_swap_halves_equals_swapped_copy():
     """swap_halves=True warps the OTHER batch half of x (the model's [x1; x2] / [x2; x1] pairing) without the copy: values,
     the gradient scattered into the other half of gx, and the flow gradient equal those of an explicit torch.cat swap"""

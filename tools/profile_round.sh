@@ -16,6 +16,7 @@ python tools/rocpd_timeline.py $(find $OUT/kt -name "*.db" | head -1) > $OUT/${T
 rm -rf $OUT/kt
 rocprofv3 --kernel-trace --stats -d $OUT/kts -o kts -- python3 bench.py --no-cpu-baseline --no-secondary --no-async-wgrad --steps 5 > $OUT/${TAG}_bench_serial_under_rocprof.json 2>> $OUT/${TAG}_bench.err
 python tools/rocpd_stats.py $(find $OUT/kts -name "*.db" | head -1) 50 > $OUT/${TAG}_kernel_stats_serial.txt
+python tools/rocpd_timeline.py $(find $OUT/kts -name "*.db" | head -1) > $OUT/${TAG}_timeline_serial.txt 2>&1
 rm -rf $OUT/kts
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pf -o pf -- python3 bench.py --no-cpu-baseline --no-secondary --no-async-wgrad --no-kernel-timer --steps 2 --warmup 1 > /dev/null 2>> $OUT/${TAG}_bench.err
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pw -o pw -- python3 bench.py --no-cpu-baseline --no-secondary --no-async-wgrad --no-kernel-timer --steps 2 --warmup 1 > /dev/null 2>> $OUT/${TAG}_bench.err

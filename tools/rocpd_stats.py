@@ -22,6 +22,9 @@ def main():
     print(f"{'kernel':110s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
     for name, calls, tot, avg, mn, mx in rows[:top]:
         print(f"{short(name):110s} {calls:7d} {tot / 1e6:10.3f} {avg / 1e3:10.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * tot / total:6.2f}")
+    aten = [r for r in rows if "at::native" in r[0] or "rocclr" in r[0]]
+    print(f"# torch / runtime kernels (at::native::*, __amd_rocclr_*): {sum(r[1] for r in aten)} dispatches, "
+          f"{sum(r[2] for r in aten) / 1e6:.3f} ms; library kernels: {sum(r[1] for r in rows) - sum(r[1] for r in aten)} dispatches")
     rest = rows[top:]
     if rest:
         print(f"{'(other ' + str(len(rest)) + ' kernels)':110s} {sum(r[1] for r in rest):7d} {sum(r[2] for r in rest) / 1e6:10.3f}")

@@ -74,6 +74,9 @@ def main():
     for r in rows:
         k = short(r[0])[:90]
         c2 = cnt.setdefault(k, [0, 0]); c2[0] += 1; c2[1] += r[2] - r[1]
+    tk = [v for k, v in cnt.items() if "at::native" in k or "rocclr" in k]
+    print(f"torch / runtime kernels of the step (at::native::*, __amd_rocclr_*): {sum(v[0] for v in tk)} dispatches, "
+          f"{sum(v[1] for v in tk) / 1e6:.2f} ms of kernel time; library kernels: {len(rows) - sum(v[0] for v in tk)} dispatches")
     print("dispatches of the step by kernel (count, total ms):")
     for k, v in sorted(cnt.items(), key=lambda kv: -kv[1][0])[:30]:
         print(f"   {v[0]:5d}  {v[1] / 1e6:7.2f} ms  {k}")
