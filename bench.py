@@ -15,6 +15,14 @@ weak scaling: every rank gets its own 32 pairs).  Prints ONE JSON line on rank 0
 runs 5 steps of the per-GPU workload of BASELINE configs[4] (448x1024, 8 pairs per GPU: north_star's second crop) and reports it
 under ``"secondary"`` (own roofline object); ``metric`` / ``value`` are the headline's.
 
+Further keys of the line (rank 0, N = 1): ``reference_harness`` -- the same model under the REFERENCE's own loop, literally
+(runtime.py:158-189: ``optimizer.zero_grad()``, forward, ``.item()`` NaN assertion before ``backward()``, stock
+``torch.optim.Adam.step()``; no GradArena / FusedAdam / TrainStep), as a user who swaps the model class into runtime.py gets it
+(the model installs arena + lane itself, irr_amd/harness.py) and with that switched off (``plain_autograd``); ``forward_only`` --
+BASELINE configs[1] (eval forward, 8 pairs of 384x448) with its EPE against the oracle on the first two pairs;
+``roofline.single_stream`` -- the dominant kernel over 3 steps without the second stream, same process (kernel quality without
+lane time-sharing).  ``--harness reference`` makes the reference loop the HEADLINE instead (A/B runs).
+
 ``IRR_DDP_BACKEND=gloo`` (single-GPU boxes, tests): the ranks share the visible GPUs (rank r -> cuda:r % device_count) and
 exchange through gloo -- RCCL refuses two ranks on one device; everything but the transport is the same code.
 """
@@ -48,6 +56,20 @@ CONV_GFLOP_PER_PAIR = {(384, 448): 1088.4, (448, 1024): 2902.5}   # SURVEY.md 8(
 SECONDARY = (8, 448, 1024)             # per-GPU share of BASELINE configs[4] (Sintel-shaped 448x1024, bs64 on 8 GPUs)
 SECONDARY_STEPS = 5
 TRAFFIC_FILES = {(384, 448, 32): "hbm_traffic.json", (448, 1024, 8): "hbm_traffic_448x1024.json"}
+
+
+NBATCHES = 4                           # distinct synthetic batches resident in HBM, fed round-robin (no step sees the batch of the step before)
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
 
 
 def synthetic_batch(batch, height, width, seed, device):
@@ -94,10 +116,25 @@ def cpu_baseline(height, width, quick=False):
         out.append({"batch": bp, "threads": thr, "pairs_per_s": round(_cpu_leg(O, height, width, bp, thr), 4)})
     top = max(out, key=lambda r: r["pairs_per_s"])
     return {"value": top["pairs_per_s"], "unit": "image-pairs/s", "cores": top["threads"], "kind": "port",
-            "host_cpus": ncpu, "legs": out,
+            "host_cpus": ncpu, "cpu_model": cpu_model(), "legs": out,
             "sample": f"oracle train step (fwd+loss+bwd+Adam) at {height}x{width}: 2 warm-up + 5 timed steps per leg, median step "
                       f"time; legs = (batch, torch threads) {[(r['batch'], r['threads']) for r in out]}; value = the fastest "
                       f"leg (batch {top['batch']}, {top['threads']} threads; {ncpu} host CPUs visible, more threads are slower)"}
+
+
+def cpu_forward_leg(height, width, pairs=2, threads=16):
+    """forward-only CPU baseline for BASELINE configs[1] + the checker's outputs: the oracle's eval forward on the first ``pairs``
+    pairs of the forward-only leg's batch (robust-mask parity mode), timed once after one warm-up -> (pairs/s, flow, occ)"""
+    from oracle import irr_pwc_oracle as O
+    torch.set_num_threads(min(threads, os.cpu_count() or threads))
+    P = O.synthetic_params(0)
+    b = O.synthetic_batch(pairs, height, width, 4321)
+    with torch.no_grad():
+        O.irr_pwc_forward(P, b["input1"][:1], b["input2"][:1], False, mask_threshold=0.9999)
+        t0 = time.perf_counter()
+        out = O.irr_pwc_forward(P, b["input1"], b["input2"], False, mask_threshold=0.9999)
+        dt = time.perf_counter() - t0
+    return pairs / dt, out["flow"], out["occ"], P, b
 
 
 def launch_ranks(n):
@@ -132,6 +169,9 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-async-wgrad", action="store_true", help="keep weight gradients on the main stream")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 448x1024 leg after the headline timing")
+    ap.add_argument("--harness", choices=["own", "reference"], default="own",
+                    help="own: TrainStep + GradArena + FusedAdam (headline); reference: the reference's literal loop as the headline")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip reference_harness / forward_only / single_stream")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -155,10 +195,17 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import irr_amd
+    from irr_amd import build as B_
     from irr_amd import conv as C
-    from irr_amd import ddp
+    from irr_amd import ddp, harness
     from irr_amd.train import ModelAndLoss, TrainStep
     from irr_amd.optim import FusedAdam
+
+    # the loaded library must be the one built from the sources in the tree: the stamp next to it is written by
+    # irr_amd.build only after a link of exactly these sources
+    if not os.environ.get("IRR_HIP_LIB") and B_.built_hash() != B_.source_hash():
+        raise SystemExit(f"irr_amd/lib/libirr_hip.so was built from sources {B_.built_hash() or '?'}, the tree is "
+                         f"{B_.source_hash()}: run `python -m irr_amd.build`")
 
     pre_gb = a.prealloc_gb if a.prealloc_gb >= 0 else 0.30 * torch.cuda.get_device_properties(device).total_memory / 1e9
     if backend != "nccl" and world > 1:
@@ -168,31 +215,55 @@ def main():
         # segments during the first timed steps
         blk = torch.empty(int(pre_gb * 1e9), dtype=torch.uint8, device=device)
         del blk
-    torch.manual_seed(0)                                     # same MSRA init on every rank
-    model = irr_amd.PWCNet(types.SimpleNamespace(batch_size=a.batch, model_div_flow=0.05)).to(device).train()
-    ddp.broadcast_params(model)
-    arena = ddp.GradArena(model.named_parameters())
-    if not a.no_async_wgrad:
-        arena.enable_async_wgrad()
-    elif not os.environ.get("IRR_BENCH_AUTOGRAD_WGRAD"):     # single stream: still accumulate straight into the arena
-        arena.enable_direct_wgrad()
-    opt = FusedAdam(model, arena, lr=1e-4, weight_decay=4e-4)
+
+    def new_model(batch_pairs):
+        torch.manual_seed(0)                                 # same MSRA init on every rank
+        return irr_amd.PWCNet(types.SimpleNamespace(batch_size=batch_pairs, model_div_flow=0.05)).to(device).train()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(batch_pairs, height, width, steps, warmup, timed_kernels):
+    def own_step_factory(model, arena, opt):
+        def make(batch_pairs):
+            args = types.SimpleNamespace(batch_size=batch_pairs, model_div_flow=0.05)
+            loss = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(args, reduce_fn=ddp.reduce_losses() if world > 1 else None).train()
+            mal = ModelAndLoss(args, model, loss).train()
+            # the reference's per-step NaN assertion is ON: asserted before the optimizer step (TrainStep docstring);
+            # IRR_BENCH_NANCHECK=before_backward: the reference's exact placement (A/B), =off: diagnostic
+            nc = os.environ.get("IRR_BENCH_NANCHECK", "before_step")
+            return TrainStep(mal, opt, grad_sync=arena.sync,
+                             check_nan=False if (nc == "off" or os.environ.get("IRR_BENCH_NO_NANCHECK")) else nc)
+        return make
+
+    def reference_step_factory(model):
+        """the reference's loop, literally (runtime.py:158-189); optimizer as configuration.py:488-573 builds it from
+        scripts/IRR-PWC_flyingChairsOcc.sh:29-31"""
+        import math
+        optimizer = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=4e-4)
+
+        def make(batch_pairs):
+            args = types.SimpleNamespace(batch_size=batch_pairs, model_div_flow=0.05)
+            mal = ModelAndLoss(args, model, irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(args).train()).train()
+
+            def step(example_dict):
+                for key, t in example_dict.items():
+                    t.requires_grad_("input" in key)
+                optimizer.zero_grad()
+                loss_dict, output_dict = mal(example_dict)
+                training_loss = loss_dict["total_loss"]
+                assert not math.isnan(training_loss.item()), "training_loss is NaN"
+                training_loss.backward()
+                optimizer.step()
+                return loss_dict, output_dict, batch_pairs
+            return step
+        return make
+
+    def run(make_step, batch_pairs, height, width, steps, warmup, timed_kernels):
         """W untimed + exactly K timed train steps of one workload -> dict(dt, value, loss, routing, roofline)"""
-        args = types.SimpleNamespace(batch_size=batch_pairs, model_div_flow=0.05)
-        loss = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(args, reduce_fn=ddp.reduce_losses() if world > 1 else None).train()
-        mal = ModelAndLoss(args, model, loss).train()
-        # the reference's per-step NaN assertion is ON: asserted before the optimizer step (TrainStep docstring);
-        # IRR_BENCH_NANCHECK=before_backward: the reference's exact placement (A/B), =off: diagnostic
-        nc = os.environ.get("IRR_BENCH_NANCHECK", "before_step")
-        step = TrainStep(mal, opt, grad_sync=arena.sync, check_nan=False if (nc == "off" or os.environ.get("IRR_BENCH_NO_NANCHECK")) else nc)
-        batch = synthetic_batch(batch_pairs, height, width, 1234 + rank, device)
+        step = make_step(batch_pairs)
+        batches = [synthetic_batch(batch_pairs, height, width, 1234 + rank + 1000 * i, device) for i in range(NBATCHES)]
         marks = [] if os.environ.get("IRR_BENCH_STEPTIMES") else None      # diagnostic: per-step GPU time (events, no extra syncs)
 
         def mark():
@@ -201,9 +272,9 @@ def main():
                 ev.record()
                 marks.append((time.perf_counter(), ev))
 
-        for _ in range(warmup):
+        for i in range(warmup):
             mark()
-            step(batch)
+            step(batches[i % NBATCHES])
         seg0 = torch.cuda.memory_stats(device).get("segment.all.allocated", 0) if marks is not None else 0
         timer = None
         if timed_kernels:
@@ -211,9 +282,9 @@ def main():
             C.TIMER = timer
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
             mark()
-            ld, _, _ = step(batch)
+            ld, _, _ = step(batches[(warmup + i) % NBATCHES])
         mark()
         barrier()
         dt = time.perf_counter() - t0
@@ -228,17 +299,21 @@ def main():
                      torch.cuda.max_memory_allocated(device) / 1e9, torch.cuda.max_memory_reserved(device) / 1e9), file=sys.stderr)
         # what one step was ROUTED to (launch counters of irr_amd.conv), taken on one extra step outside the timed region
         C.LAUNCHES.clear()
-        step(batch)
+        step(batches[0])
         torch.cuda.synchronize()
         routing = dict(C.LAUNCHES)
+        spread = None
         if world > 1:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        res = {"dt": dt, "value": batch_pairs * world * steps / dt, "routing": routing,
+            allt = torch.zeros(world, device=device, dtype=torch.float64)      # every rank fills its slot: SUM == gather
+            allt[rank] = dt
+            dist.all_reduce(allt, op=dist.ReduceOp.SUM)
+            per_rank = [float(t) for t in allt.tolist()]
+            dt = max(per_rank)                                                 # MAX over ranks
+            spread = {"per_rank_ms_per_step": [round(t / steps * 1e3, 3) for t in per_rank]}
+        res = {"dt": dt, "value": batch_pairs * world * steps / dt, "routing": routing, "spread": spread,
                "loss": {k: float(v.detach()) for k, v in ld.items()},
                "roofline": roofline(timer, steps, height, width, batch_pairs) if (timer is not None and rank == 0) else None}
-        del batch, step, mal, loss
+        del batches, step
         return res
 
     def roofline(timer, steps, height, width, batch_pairs):
@@ -269,6 +344,9 @@ def main():
                               if st["fwd_calls"] else None),
                 "all_conv_fwd_dgrad": {"achieved": round(tot_f / tot_s / 1e12, 2), "seconds_per_step": round(tot_s / steps, 5),
                                        "flops_per_step": tot_f / steps},
+                "by_kernel_all": {kernel_name(v)[0]: {"launches": s_["calls"], "achieved": round(s_["flops"] / s_["seconds"] / 1e12, 2),
+                                                      "avg_launch_us": round(s_["seconds"] / s_["calls"] * 1e6, 2)}
+                                  for v, s_ in summ.items()},
                 "by_kernel": {kernel_name(v)[0]: {"launches": s_["calls"], "ms_per_step": round(s_["seconds"] / steps * 1e3, 2),
                                                   "achieved": round(s_["flops"] / s_["seconds"] / 1e12, 1)}
                               for v, s_ in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:6]}}
@@ -276,10 +354,9 @@ def main():
         # WRITE_SIZE runs of THIS command, FETCH x2 gfx950 correction).  PMC counters cannot be collected from inside the process,
         # so the bytes are only reported when the json was measured on a library built from the very sources that are loaded now.
         try:
-            from irr_amd import build as B_
             tr = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILES[(height, width, batch_pairs)])))
             k = roof["kernel"].replace(",", ", ")
-            if tr.get("_source_hash") != B_.source_hash():
+            if tr.get("_source_hash") != B_.source_hash() or B_.built_hash() != B_.source_hash():
                 roof["traffic_source"] = (f"stale: {TRAFFIC_FILES[(height, width, batch_pairs)]} was measured on sources "
                                           f"{tr.get('_source_hash')}, the library is built from {B_.source_hash()}")
             elif k in tr:
@@ -294,13 +371,93 @@ def main():
         return (f"BASELINE {cfg}: IRR_PWC train step (fwd + MultiScaleEPE_PWC_Bi_Occ_upsample + bwd + Adam), "
                 f"synthetic {height}x{width}, {batch_pairs} pairs per GPU")
 
-    head = run(a.batch, a.height, a.width, a.steps, a.warmup, not a.no_kernel_timer)
+    model = new_model(a.batch)
+    ddp.broadcast_params(model)
+    arena = opt = None
+    if a.harness == "own":
+        arena = ddp.GradArena(model.named_parameters())
+        if not a.no_async_wgrad:
+            arena.enable_async_wgrad()
+        elif not os.environ.get("IRR_BENCH_AUTOGRAD_WGRAD"):     # single stream: still accumulate straight into the arena
+            arena.enable_direct_wgrad()
+        opt = FusedAdam(model, arena, lr=1e-4, weight_decay=4e-4)
+        make_step = own_step_factory(model, arena, opt)
+    else:
+        if world > 1:
+            raise SystemExit("--harness reference is the reference's single-process loop (the reference has no data parallelism)")
+        make_step = reference_step_factory(model)
+
+    head = run(make_step, a.batch, a.height, a.width, a.steps, a.warmup, not a.no_kernel_timer)
+    # rank 0's bucket schedule of the last step: (bucket, where it was started, ms since zero_grad)
+    launch_log = ([(b_, w_, t_) for (b_, w_), t_ in zip(arena.launch_log, arena.launch_times)]
+                  if (arena is not None and world > 1) else None)
     second = None
     if not a.no_secondary and (a.height, a.width) == (384, 448):
-        second = run(SECONDARY[0], SECONDARY[1], SECONDARY[2], SECONDARY_STEPS, 2, not a.no_kernel_timer)
+        second = run(make_step, SECONDARY[0], SECONDARY[1], SECONDARY[2], SECONDARY_STEPS, 2, not a.no_kernel_timer)
+
+    extra = {}
+    if world == 1 and not a.no_extra_legs and a.harness == "own" and not a.no_async_wgrad and not a.no_kernel_timer:
+        # (1) kernel quality without lane time-sharing: 3 steps with the weight gradients on the main stream, same process
+        arena.disable_async_wgrad()
+        arena.enable_direct_wgrad()
+        ss = run(make_step, a.batch, a.height, a.width, 3, 1, True)
+        arena.disable_async_wgrad()
+        if head["roofline"] is not None and ss["roofline"] is not None:
+            kn = head["roofline"]["kernel"]
+            k_ss = ss["roofline"]["by_kernel_all"].get(kn)
+            if k_ss is not None:
+                head["roofline"]["single_stream"] = {
+                    "achieved": k_ss["achieved"], "frac": round(k_ss["achieved"] / head["roofline"]["peak"], 4),
+                    "avg_launch_us": k_ss["avg_launch_us"], "launches": k_ss["launches"], "ms_per_step": round(ss["dt"] / 3 * 1e3, 3),
+                    "note": "3 timed steps of the same workload with the weight-gradient launches on the main stream "
+                            "(GradArena.enable_direct_wgrad): no second kernel shares the chip"}
+        # (2) the reference's own loop around a FRESH model (the headline's model / arena / optimizer are dropped first)
+        del make_step, opt, arena, model
+        ref_steps = max(3, min(a.steps, 8))
+        legs = {}
+        for name, auto in (("auto", True), ("plain_autograd", False)):
+            harness.set_enabled(auto)
+            m2 = new_model(a.batch)
+            r = run(reference_step_factory(m2), a.batch, a.height, a.width, ref_steps, 3, False)
+            legs[name] = {"value": round(r["value"], 3), "ms_per_step": round(r["dt"] / ref_steps * 1e3, 3), "loss": r["loss"],
+                          "launches_per_step": r["routing"], "installed": harness.installed(m2)}
+            harness.uninstall(m2)
+            del m2, r
+        harness.set_enabled(True)
+        extra["reference_harness"] = {
+            "value": legs["auto"]["value"], "unit": "image-pairs/s", "ms_per_step": legs["auto"]["ms_per_step"],
+            "steps": ref_steps, "warmup": 3, "loss": legs["auto"]["loss"], "launches_per_step": legs["auto"]["launches_per_step"],
+            "loop": "runtime.py:158-189 literally: optimizer.zero_grad() (set_to_none), forward, .item() NaN assertion before "
+                    "backward(), torch.optim.Adam(lr 1e-4, weight_decay 4e-4).step(); no GradArena / FusedAdam / TrainStep",
+            "route": "the model installs gradient arena + weight-gradient lane itself (irr_amd/harness.py), joined at the end of "
+                     "backward by an autograd final callback; packed weights refreshed by one batched launch per step",
+            "arena_installed_by_model": legs["auto"]["installed"],
+            "plain_autograd": {"value": legs["plain_autograd"]["value"], "ms_per_step": legs["plain_autograd"]["ms_per_step"],
+                               "launches_per_step": legs["plain_autograd"]["launches_per_step"],
+                               "note": "IRR_AUTO_LANE=0: per-use gradient tensors, autograd accumulation, weight gradients on "
+                                       "the critical path"}}
+        # (3) BASELINE configs[1]: forward only, 8 pairs of 384x448, eval mode
+        if (a.height, a.width) == (384, 448):
+            m3 = new_model(8).eval()
+            fb = synthetic_batch(8, a.height, a.width, 4321, device)
+            with torch.no_grad():
+                for _ in range(3):
+                    m3(fb)
+                torch.cuda.synchronize()
+                n_f = 20
+                t0 = time.perf_counter()
+                for _ in range(n_f):
+                    fo = m3(fb)
+                torch.cuda.synchronize()
+                dtf = time.perf_counter() - t0
+            extra["forward_only"] = {"workload": "BASELINE configs[1]: IRR_PWC forward only (eval), synthetic 384x448, 8 pairs, 1 GPU",
+                                     "value": round(8 * n_f / dtf, 2), "unit": "image-pairs/s", "ms_per_forward": round(dtf / n_f * 1e3, 3),
+                                     "steps": n_f, "warmup": 3}
+            extra["_fwd"] = (m3, fo)
     if rank == 0:
         gf = CONV_GFLOP_PER_PAIR.get((a.height, a.width))
         value = head["value"]
+        own = a.harness == "own"
         out = {"metric": "image-pairs/sec fwd+bwd IRR-PWC 384x448 bs32", "value": round(value, 3), "unit": "image-pairs/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(head["dt"] / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -309,9 +466,13 @@ def main():
                           "pairs_per_gpu": a.batch, "global_batch": a.batch * world, "height": a.height, "width": a.width,
                           "parallelism": f"dp{world}", "weights": "MSRA init, torch.manual_seed(0)",
                           "transport": "rccl" if backend == "nccl" else backend,
-                          "nan_check": os.environ.get("IRR_BENCH_NANCHECK", "before_step") + " (every step: the reference's assertion on "
-                                       "the training loss, runtime.py:182-183; before_step = asserted before the optimizer step "
-                                       "from a pinned host copy, no pipeline drain between forward and backward)"},
+                          "harness": ("TrainStep + GradArena + FusedAdam (irr_amd/train.py)" if own else
+                                      "the reference's loop (runtime.py:158-189) with torch.optim.Adam"),
+                          "batches": f"{NBATCHES} distinct synthetic batches resident in HBM, fed round-robin",
+                          "nan_check": (os.environ.get("IRR_BENCH_NANCHECK", "before_step") + " (every step: the reference's assertion on "
+                                        "the training loss, runtime.py:182-183; before_step = asserted before the optimizer step "
+                                        "from a pinned host copy, no pipeline drain between forward and backward)") if own else
+                                       "before_backward (.item(), as the reference)"},
                "loss": head["loss"],
                "conv_math": C.MATH,
                "launches_per_step": head["routing"],
@@ -319,16 +480,41 @@ def main():
                # whole-step conv rate over the fp32-MFMA peak (157.3): above 1 because the x3 family runs fp32 products on the bf16 pipe
                "step_conv_vs_fp32_mfma_peak": round(value / world * gf * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4) if gf else None,
                "roofline": head["roofline"]}
+        if out["roofline"] is not None:
+            out["roofline"].pop("by_kernel_all", None)
+        if head["spread"] is not None:
+            out["ranks"] = head["spread"]
+            out["ranks"]["bucket_launches_last_step"] = launch_log      # rank 0: (bucket, "backward" | "sync")
         if second is not None:
             gf2 = CONV_GFLOP_PER_PAIR[(SECONDARY[1], SECONDARY[2])]
+            if second["roofline"] is not None:
+                second["roofline"].pop("by_kernel_all", None)
             out["secondary"] = {"workload": workload_name("configs[4] per-GPU share", *SECONDARY).replace("synthetic", "Sintel-shaped synthetic"),
                                 "metric": "image-pairs/sec fwd+bwd IRR-PWC 448x1024 bs8", "value": round(second["value"], 3),
                                 "unit": "image-pairs/s", "steps": SECONDARY_STEPS, "warmup": 2,
                                 "ms_per_step": round(second["dt"] / SECONDARY_STEPS * 1e3, 3), "loss": second["loss"],
                                 "step_conv_tflops": round(second["value"] / world * gf2 * 1e9 / 1e12, 1),
                                 "launches_per_step": second["routing"], "roofline": second["roofline"]}
+        fwd = extra.pop("_fwd", None)
+        out.update(extra)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.height, a.width, quick=a.quick_cpu_baseline)
+            if fwd is not None:
+                # configs[1]'s "EPE check": the oracle's eval forward on the first two pairs of the forward-only batch, timed as
+                # that leg's CPU baseline and compared with the HIP outputs (robust-mask parity mode on both sides)
+                m3, _ = fwd
+                pps, flow_ref, occ_ref, P, cb = cpu_forward_leg(a.height, a.width)
+                m3.load_state_dict(P)
+                m3.mask_threshold = 0.9999
+                with torch.no_grad():
+                    got = m3({"input1": cb["input1"].to(device), "input2": cb["input2"].to(device)})
+                epe = torch.norm(got["flow"].cpu() - flow_ref, dim=1).mean().item()
+                out["forward_only"]["epe_vs_oracle_px"] = float(f"{epe:.3e}")
+                out["forward_only"]["occ_logit_mad_vs_oracle"] = float(f"{(got['occ'].cpu() - occ_ref).abs().mean().item():.3e}")
+                out["forward_only"]["epe_check"] = ("2 pairs of 384x448, oracle weights (synthetic_params(0)), mask threshold 0.9999 "
+                                                    "on both sides; bar 1e-4 px (SURVEY 8(c))")
+                out["forward_only"]["cpu_baseline"] = {"value": round(pps, 4), "unit": "image-pairs/s", "cores": min(16, os.cpu_count() or 16),
+                                                       "kind": "port", "sample": "oracle eval forward, 2 pairs of 384x448, one timed pass"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

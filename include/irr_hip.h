@@ -305,8 +305,11 @@ int irr_upsample_nearest2x_bwd_f32(const float* gout, float* gx, int B, int C, i
  * do everything that touches pixels.
  *   irr_avgpool_f32      out = scale * s x s mean of in  (== adaptive_avg_pool2d for the integer ratios 1..64), in (BC,h*s,w*s)
  *   irr_epe_sum_fwd      *out += weight * sum_{b,p} || tgt - flow ||_2            flow, tgt: (B,2,h,w)
+ *                        (ONE add of a sum formed in a fixed order: block partials in `scratch`, then one finishing block --
+ *                        no atomics, bit-reproducible; scratch >= irr_loss_partial_blocks(B, HW) floats)
  *   irr_epe_sum_bwd      gflow = gscale[0]*weight * (flow - tgt)/||.||            (0 where the norm is 0)
- *   irr_f1bal_sums       sums[b][0..3] += { -sum t log(s+eps), -sum (1-t) log(1-s+eps), sum t, sum s },  s = sigmoid(logit)
+ *   irr_f1bal_sums       sums[b][0..3] = { -sum t log(s+eps), -sum (1-t) log(1-s+eps), sum t, sum s },  s = sigmoid(logit)
+ *                        (overwritten; fixed summation order; scratch >= 4 * irr_loss_partial_blocks(B, HW) floats, 16-B aligned)
  *   irr_f1bal_value      out[0] = scale * sum_b [ tp/(st+sp+eps) + fn/((N-st)+(N-sp)+eps) ]   (sums from irr_f1bal_sums, N = HW)
  *   irr_f1bal_bwd        glogit = gscale[0]*weight * d/dlogit [ tp/(st+sp+eps) + fn/((N-st)+(N-sp)+eps) ]
  * gscale is a 1-element DEVICE array (the upstream gradient times the balancing weight), so nothing syncs. */
@@ -314,11 +317,13 @@ int irr_avgpool_f32(const float* in, float* out, int BC, int h, int w, int s, fl
 /* the general case of losses.py:16-18: out (BC,h,w) = scale * adaptive_avg_pool2d(in (BC,H,W), [h, w]) for level sizes that do
  * not divide the target size (window [floor(o*H/h), ceil((o+1)*H/h)) per axis, as ATen) -- odd pyramid sizes */
 int irr_adaptive_avgpool_f32(const float* in, float* out, int BC, int H, int W, int h, int w, float scale, void* stream);
+long irr_loss_partial_blocks(int B, long HW);   /* blocks (= partial-sum slots) the forward reductions use for one (B, HW) term */
 int irr_epe_sum_fwd_f32(const float* flow, const float* tgt, float* out, int B, int HW, long flow_bs, long tgt_bs,
-                        float weight, void* stream);
+                        float weight, float* scratch, long scratch_elems, void* stream);
 int irr_epe_sum_bwd_f32(const float* flow, const float* tgt, const float* gscale, float* gflow, int B, int HW,
                         long flow_bs, long tgt_bs, long g_bs, float weight, void* stream);
-int irr_f1bal_sums_f32(const float* logit, const float* tgt, float* sums, int B, int HW, long l_bs, long t_bs, void* stream);
+int irr_f1bal_sums_f32(const float* logit, const float* tgt, float* sums, int B, int HW, long l_bs, long t_bs,
+                       float* scratch, long scratch_elems, void* stream);
 int irr_f1bal_value_f32(const float* sums, float* out, int B, int HW, float scale, void* stream);
 int irr_f1bal_bwd_f32(const float* logit, const float* tgt, const float* sums, const float* gscale, float* glogit,
                       int B, int HW, long l_bs, long t_bs, long g_bs, float weight, void* stream);
@@ -326,10 +331,13 @@ int irr_f1bal_bwd_f32(const float* logit, const float* tgt, const float* sums, c
 /* All terms of one kind in ONE launch (the loss has 24 EPE and 24 balanced-F1 terms).  `terms` is a HOST array of nterms
  * (<= IRR_LOSS_MAX_TERMS) records; it is copied into the kernel arguments, nothing is read from it after the call returns.
  *   pred / tgt   the term's prediction (flow (B,2,h,w) or occlusion logits (B,1,h,w)) and its pooled target
- *   grad         (bwd) where the gradient w.r.t. pred goes;  aux: (F1) the term's zeroed sums[B][4] scratch, kept for bwd
+ *   grad         (bwd) where the gradient w.r.t. pred goes;  aux: (F1) the term's sums[B][4] (written by fwd, read by bwd; 16-B aligned)
  *   weight       EPE: level weight;  F1: level weight * h*w*0.5  (what irr_f1bal_value_f32 takes as `scale`)
  *   hw, *_bs     pixels per plane and batch strides in elements;  nbx / block0 are filled in by the library
- * fwd:  out[0] += sum over terms of the term's weighted loss (out is NOT zeroed);  bwd: grad_t = gscale[0] * d term / d pred. */
+ * fwd:  out[0] += sum over terms of the term's weighted loss (out is NOT zeroed), summed in a FIXED order: every block stores its
+ *       partial sum(s) in `scratch` (EPE: sum_t irr_loss_partial_blocks(B_t, hw_t) floats, F1: four times that, 16-B aligned) and one
+ *       finishing block adds them in index order -- no atomics, the loss values are bit-reproducible;
+ * bwd:  grad_t = gscale[0] * d term / d pred. */
 #define IRR_LOSS_MAX_TERMS 32
 typedef struct IrrLossTerm {
   const float* pred;
@@ -340,9 +348,9 @@ typedef struct IrrLossTerm {
   float weight;
   int B, nbx, block0;
 } IrrLossTerm;
-int irr_epe_sum_multi_fwd_f32(const void* terms, int nterms, float* out, void* stream);
+int irr_epe_sum_multi_fwd_f32(const void* terms, int nterms, float* out, float* scratch, long scratch_elems, void* stream);
 int irr_epe_sum_multi_bwd_f32(const void* terms, int nterms, const float* gscale, void* stream);
-int irr_f1bal_multi_fwd_f32(const void* terms, int nterms, float* out, void* stream);
+int irr_f1bal_multi_fwd_f32(const void* terms, int nterms, float* out, float* scratch, long scratch_elems, void* stream);
 int irr_f1bal_multi_bwd_f32(const void* terms, int nterms, const float* gscale, void* stream);
 
 /* ---- channel concatenation in one launch --------------------------------------------------------------

@@ -2,8 +2,10 @@
 
     python -m irr_amd.build [--force]
 
-One object per source (rebuilt when the source, a header or the compiler flags changed), linked into ONE C-ABI shared
-library whose exported symbols are exactly the functions declared in include/irr_hip.h.
+One object per source, keyed on a CONTENT hash of (source, every header, compiler flags) written next to the object -- never on
+modification times, which do not survive the copy to the GPU box -- linked into ONE C-ABI shared library whose exported symbols
+are exactly the functions declared in include/irr_hip.h.  ``source.hash`` next to the library is written only after a link that
+contains exactly the objects of that hash.
 
 Ablation / trace builds (the IRR_*_ABL, IRR_X3S_TRACE ... macro switches below) never overwrite the product library: they
 require ``IRR_BUILD_TAG=<name>`` and go to irr_amd/lib_<name>/; load one with ``IRR_HIP_LIB=<path to that .so>``.
@@ -77,8 +79,20 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def _newer(a: str, b: str) -> bool:
-    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+def _digest(paths, extra: str = "") -> str:
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for f in paths:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _read(path: str) -> str:
+    try:
+        return open(path).read().strip()
+    except OSError:
+        return ""
 
 
 def sources():
@@ -107,22 +121,26 @@ def stale(lib: str = LIB) -> bool:
     return (not os.path.exists(lib)) or (not os.path.exists(stamp)) or open(stamp).read().strip() != source_hash()
 
 
+def built_hash(lib: str = LIB) -> str:
+    """the source hash the library at ``lib`` was linked from ("" if unknown) -- bench.py / hip.py compare it with the tree"""
+    return _read(os.path.join(os.path.dirname(lib), "source.hash"))
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
-           [os.path.join(ROOT, "include", "irr_hip.h"), os.path.abspath(__file__)]
-    # the flag set is part of the build's identity: a library built with other flags is rebuilt from scratch
-    stamp = os.path.join(LIBDIR, "flags.stamp")
-    flags = " ".join(COMMON) + " | " + repr(sorted(EXTRA.items()))
-    if not os.path.exists(stamp) or open(stamp).read() != flags:
-        force = True
-    jobs = []
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
+        [os.path.join(ROOT, "include", "irr_hip.h")]
+    hdr_digest = _digest(hdrs)
+    jobs, stamps = [], {}
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s[:-4] + ".o")
-        if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs):
-            jobs.append([hipcc] + COMMON + EXTRA.get(s, []) + ["-c", src, "-o", obj])
+        flags = COMMON + EXTRA.get(s, [])
+        want = _digest([src], hdr_digest + " ".join(flags))
+        stamps[obj] = want
+        if force or not os.path.exists(obj) or _read(obj + ".hash") != want:
+            jobs.append((obj, [hipcc] + flags + ["-c", src, "-o", obj]))
 
     def run(cmd):
         if verbose:
@@ -132,13 +150,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
         return r
 
+    def compile_one(job):
+        obj, cmd = job
+        if os.path.exists(obj + ".hash"):
+            os.remove(obj + ".hash")               # (an interrupted compile must not leave a valid stamp behind)
+        run(cmd)
+        with open(obj + ".hash", "w") as f:
+            f.write(stamps[obj])
+
     with ThreadPoolExecutor(max_workers=4) as ex:
-        list(ex.map(run, jobs))
+        list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJDIR, s[:-4] + ".o") for s in srcs]
-    if force or jobs or not os.path.exists(LIB):
+    link_id = _digest([], " ".join(stamps[o] for o in objs))
+    link_stamp = os.path.join(LIBDIR, "link.hash")
+    if force or jobs or not os.path.exists(LIB) or _read(link_stamp) != link_id:
+        for st in (link_stamp, os.path.join(LIBDIR, "source.hash")):
+            if os.path.exists(st):
+                os.remove(st)
         run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
-    with open(stamp, "w") as f:
-        f.write(flags)
+        with open(link_stamp, "w") as f:
+            f.write(link_id)
     with open(os.path.join(LIBDIR, "source.hash"), "w") as f:
         f.write(source_hash())
     return LIB

@@ -148,6 +148,15 @@ def _weight_tag(w: torch.Tensor):
     return (w.data_ptr(), w._version, tuple(w.shape), WEIGHT_EPOCH[0])
 
 
+def _announce_rewrite(reg: _PackRegistry, old_tag, new_tag) -> None:
+    """A cached packed copy is stale although nobody moved the weight epoch: the parameter was rewritten in place by code that
+    does not know about the caches -- ``torch.optim.Adam.step()`` under the reference's own training loop (runtime.py:189),
+    ``load_state_dict``.  Treat it as an optimizer step: move the epoch so that the registry refreshes EVERY packed copy with its
+    one batched launch instead of ~250 single-job launches trickling in layer by layer."""
+    if old_tag[3] == new_tag[3] and reg.epoch == WEIGHT_EPOCH[0] and old_tag[:3] != new_tag[:3]:
+        WEIGHT_EPOCH[0] += 1
+
+
 def _packed(weight: torch.Tensor, transpose: bool, slot: str, nbytes_fn, dtype, single, builder_name):
     """shared body of packed_weights / packed_weights_x3: cache ON the tensor object (so it dies with the parameter and can
     never be confused with another tensor that later reuses the same address), refreshed whenever the parameter's storage,
@@ -160,10 +169,13 @@ def _packed(weight: torch.Tensor, transpose: bool, slot: str, nbytes_fn, dtype, 
     if hit is not None and hit[0] == tag:
         return hit[1]
     reg = _registry(w.device)
-    if hit is not None and reg.refresh():
-        hit = cache.get(key)
-        if hit[0] == _weight_tag(w):
-            return hit[1]
+    if hit is not None:
+        _announce_rewrite(reg, hit[0], tag)
+        if reg.refresh():
+            hit = cache.get(key)
+            if hit[0] == _weight_tag(w):
+                return hit[1]
+        tag = _weight_tag(w)
     cout, cin, k, _ = w.shape
     lcin, lcout = (cout, cin) if transpose else (cin, cout)
     n = nbytes_fn(lcin, lcout, k)
@@ -504,6 +516,7 @@ class WgradSide:
         self.record_streams = os.environ.get("IRR_LANE_RECORD_STREAM", "0") != "0"
         self._inflight = collections.deque()    # (done marker on the lane, tensors its launch reads)
         self.on_launch = None                   # optional hook(weight, bias) once a routed gradient is complete (ddp: early buckets)
+        self.on_queue = None                    # optional hook(weight, bias) when a launch is queued (ddp: flush at a bucket's last one)
         # the ~210 partial-image folds of a step run as a few batched launches (ReduceBatch); IRR_LANE_BATCH_REDUCE=0: A/B
         self.batch = ReduceBatch() if os.environ.get("IRR_LANE_BATCH_REDUCE", "1") != "0" else None
         self._pending = []                      # (weight, bias) of launches whose fold has not been launched yet
@@ -513,6 +526,11 @@ class WgradSide:
         # held alive here and the backward nodes never touch a gradient slice again once its weight-gradient launch is issued).
         self.group = max(1, int(os.environ.get("IRR_LANE_GROUP", "4")))
         self._queued = []                       # (fn, tensors, params) not handed to the lane yet
+        # The routed gradients are complete only after flush() + join().  GradArena.sync() / FusedAdam.step() / TrainStep do
+        # that explicitly; for every other caller (the reference's own ``loss.backward(); optimizer.step()`` loop,
+        # runtime.py:188-189) the first launch of a backward pass registers join() as a FINAL CALLBACK of that pass: it runs on
+        # the thread that called backward(), on its current stream, once the whole graph has been executed.
+        self._join_queued = False
 
     def route(self, weight, bias):
         gw = self.views.get(id(weight))
@@ -566,6 +584,18 @@ class WgradSide:
             for p_ in pending:
                 self.on_launch(*p_)
 
+    def _end_of_backward(self):
+        self.join()
+
+    def _queue_join(self):
+        if self._join_queued:
+            return
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+            self._join_queued = True
+        except RuntimeError:                     # not inside a backward pass (direct calls in tests / tools): the caller joins
+            pass
+
     def launch(self, fn, tensors, params=(None, None), gw=None):
         """Run ``fn`` on the lane after everything enqueued so far on the current stream.  The tensors it reads are kept
         ALIVE (strong references) until the lane has passed the launch: (a) the caching allocator cannot recycle them, and
@@ -573,6 +603,7 @@ class WgradSide:
         only steals a gradient whose use_count is 1), nor handed to a consumer as its exclusive property -- whatever the
         model code around the node does with the same gradient tensor (``a = a + b`` feeding two nodes,
         models/pwcnet_irr*.py)."""
+        self._queue_join()
         if self.batch is not None and gw is not None:
             # a batch folds into each gradient at most once, and holds at most cap jobs: queued launches count
             if (self.batch.full_for(gw) or any(q[3] == gw.data_ptr() for q in self._queued)
@@ -583,12 +614,17 @@ class WgradSide:
             self._pending.append(params)
             if self.batch is None or not self.batch.n:
                 self.flush()
+            if self.on_queue is not None and params[0] is not None:
+                self.on_queue(*params)
             return
         self._queued.append((fn, tensors, params, gw.data_ptr() if gw is not None else 0))
         if len(self._queued) >= self.group:
             self._kick()
+        if self.on_queue is not None and params[0] is not None:
+            self.on_queue(*params)
 
     def join(self):
+        self._join_queued = False               # (also after a backward pass that raised before its final callbacks ran)
         self.flush()
         if self.inline:
             return
@@ -851,8 +887,13 @@ def _dense_column_packs(ws5, cin0: int, use_x3=(False,) * 5):
     if holder.get("tag") == tags:
         return holder["packs"]
     reg = _registry(ws5[0].device)
-    if "packs" in holder and reg.refresh() and holder.get("tag") == cur_tags():
-        return holder["packs"]
+    if "packs" in holder:
+        old = holder.get("tag")
+        if old is not None and old[-2] == tags[-2] and reg.epoch == WEIGHT_EPOCH[0] and old[:-2] != tags[:-2]:
+            WEIGHT_EPOCH[0] += 1                             # rewritten behind the caches' back (see _announce_rewrite)
+        if reg.refresh() and holder.get("tag") == cur_tags():
+            return holder["packs"]
+        tags = cur_tags()
     in0 = [448, 320, 192, 96, 32]                         # first buffer channel read by conv1..conv5
     row0 = {5: 0, 4: 32, 3: 96, 2: 192, 1: 320}           # row (= G channel) where conv i's gradient slice starts
     bounds = [(32, 96), (96, 192), (192, 320), (320, 448), (448, 448 + cin0)]

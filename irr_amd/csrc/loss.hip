@@ -2,8 +2,10 @@
 //   * target pyramid: adaptive_avg_pool2d to each level (losses.py:16-18) == s x s mean for the integer ratios that occur
 //   * flow term:  sum_p || avgpool(target)_p - flow_p ||_2                     (losses.py:8-10, 544-549)
 //   * occ  term:  per-sample sums of f1_score_bal_loss on sigmoid(logits)      (losses.py:39-48, 551-558)
-// Forward kernels reduce to a handful of floats with wave shuffles + one atomic per block; backward kernels are
-// pure elementwise.  The scalar algebra (level weights, flow/occ balancing) stays on the host side.
+// Forward kernels reduce in a FIXED order (round 4): every block stores its partial sum(s) in a caller-owned scratch array
+// (one slot per block) and one finishing block adds the slots in index order -- no atomics, so flow_loss / occ_loss (and the
+// balancing weights derived from them) are bit-reproducible run to run like the weight gradients.  Backward kernels are pure
+// elementwise.  The scalar algebra (level weights, flow/occ balancing) stays on the host side.
 #include "common.h"
 
 namespace {
@@ -53,9 +55,9 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float* __re
   out[i] = scale * (acc / (float)((y1 - y0) * (x1 - x0)));
 }
 
-// flow, tgt: (B,2,h,w) ; *out += weight * sum_p sqrt(du^2 + dv^2)
+// flow, tgt: (B,2,h,w) ; part[block] = weight * sum_p sqrt(du^2 + dv^2) over the block's pixels
 __global__ __launch_bounds__(256) void epe_fwd_kernel(const float* __restrict__ flow, const float* __restrict__ tgt,
-                                                     float* __restrict__ out, long hw, long flow_bs, long tgt_bs, float weight) {
+                                                     float* __restrict__ part, long hw, long flow_bs, long tgt_bs, float weight) {
   __shared__ float red[4];
   const int b = blockIdx.y;
   const float* f = flow + (long)b * flow_bs;
@@ -66,7 +68,17 @@ __global__ __launch_bounds__(256) void epe_fwd_kernel(const float* __restrict__ 
     s += sqrtf(du * du + dv * dv);
   }
   s = block_sum(s, red);
-  if (threadIdx.x == 0) unsafeAtomicAdd(out, weight * s);
+  if (threadIdx.x == 0) part[(long)b * gridDim.x + blockIdx.x] = weight * s;
+}
+
+// out[0] += part[0] + part[1] + ... + part[n-1], always added in the same order: thread t sums the slots t, t+256, ...,
+// then the fixed shuffle / LDS tree of block_sum
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) s += part[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] += s;
 }
 
 // gflow = gscale[0] * weight * (flow - tgt) / epe      (0 where epe == 0, as torch.norm's backward)
@@ -86,9 +98,9 @@ __global__ __launch_bounds__(256) void epe_bwd_kernel(const float* __restrict__ 
   g[hw + p] = k * dv;
 }
 
-// sums[b][0..3] += { -sum t log(s+eps), -sum (1-t) log(1-s+eps), sum t, sum s }   with s = sigmoid(logit)
+// part[b][bx][0..3] = { -sum t log(s+eps), -sum (1-t) log(1-s+eps), sum t, sum s } over the block's pixels, s = sigmoid(logit)
 __global__ __launch_bounds__(256) void f1_sums_kernel(const float* __restrict__ logit, const float* __restrict__ tgt,
-                                                     float* __restrict__ sums, long hw, long l_bs, long t_bs) {
+                                                     float* __restrict__ part, long hw, long l_bs, long t_bs) {
   __shared__ float red[4];
   const int b = blockIdx.y;
   const float* l = logit + (long)b * l_bs;
@@ -107,12 +119,20 @@ __global__ __launch_bounds__(256) void f1_sums_kernel(const float* __restrict__ 
   a1 = block_sum(a1, red);
   a2 = block_sum(a2, red);
   a3 = block_sum(a3, red);
-  if (threadIdx.x == 0) {
-    unsafeAtomicAdd(sums + b * 4 + 0, a0);
-    unsafeAtomicAdd(sums + b * 4 + 1, a1);
-    unsafeAtomicAdd(sums + b * 4 + 2, a2);
-    unsafeAtomicAdd(sums + b * 4 + 3, a3);
+  if (threadIdx.x == 0) *(float4*)(part + ((long)b * gridDim.x + blockIdx.x) * 4) = make_float4(a0, a1, a2, a3);
+}
+
+// sums[b][0..3] = part[b][0][.] + part[b][1][.] + ... (fixed order), one thread per sample
+__global__ __launch_bounds__(64) void f1_fold_kernel(const float* __restrict__ part, float* __restrict__ sums, int B, int nbx) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* p = (const float4*)part + (long)b * nbx;
+  for (int i = 0; i < nbx; ++i) {
+    const float4 v = p[i];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
   }
+  *(float4*)(sums + (long)b * 4) = a;
 }
 
 // loss_b = c * ( tp/D1 + fn/D2 ), D1 = st+sp+eps, D2 = 2N-st-sp+eps ; glogit = gscale[0]*weight * dloss/ds * s(1-s)
@@ -149,7 +169,7 @@ __device__ __forceinline__ int find_term(const LossTerms& T, int blk) {
   return i;
 }
 
-__global__ __launch_bounds__(256) void epe_multi_fwd_kernel(const LossTerms T, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void epe_multi_fwd_kernel(const LossTerms T, float* __restrict__ part) {
   __shared__ float red[4];
   const int ti = find_term(T, blockIdx.x);
   const IrrLossTerm& m = T.t[ti];
@@ -164,7 +184,7 @@ __global__ __launch_bounds__(256) void epe_multi_fwd_kernel(const LossTerms T, f
     s += sqrtf(du * du + dv * dv);
   }
   s = block_sum(s, red);
-  if (threadIdx.x == 0) unsafeAtomicAdd(out, m.weight * s);
+  if (threadIdx.x == 0) part[blockIdx.x] = m.weight * s;
 }
 
 __global__ __launch_bounds__(256) void epe_multi_bwd_kernel(const LossTerms T, const float* __restrict__ gscale) {
@@ -185,7 +205,7 @@ __global__ __launch_bounds__(256) void epe_multi_bwd_kernel(const LossTerms T, c
   g[hw + p] = k * dv;
 }
 
-__global__ __launch_bounds__(256) void f1_multi_sums_kernel(const LossTerms T) {
+__global__ __launch_bounds__(256) void f1_multi_sums_kernel(const LossTerms T, float* __restrict__ part) {
   __shared__ float red[4];
   const int ti = find_term(T, blockIdx.x);
   const IrrLossTerm& m = T.t[ti];
@@ -208,31 +228,45 @@ __global__ __launch_bounds__(256) void f1_multi_sums_kernel(const LossTerms T) {
   a1 = block_sum(a1, red);
   a2 = block_sum(a2, red);
   a3 = block_sum(a3, red);
-  if (threadIdx.x == 0) {
-    float* sums = m.aux + b * 4;
-    unsafeAtomicAdd(sums + 0, a0);
-    unsafeAtomicAdd(sums + 1, a1);
-    unsafeAtomicAdd(sums + 2, a2);
-    unsafeAtomicAdd(sums + 3, a3);
-  }
+  if (threadIdx.x == 0) *(float4*)(part + (long)blockIdx.x * 4) = make_float4(a0, a1, a2, a3);
 }
 
-// out[0] += sum over the terms of weight * ( sum_b tp/(st+sp+eps) + sum_b fn/((N-st)+(N-sp)+eps) ): one wave per term
-__global__ __launch_bounds__(64) void f1_multi_value_kernel(const LossTerms T, float* __restrict__ out) {
-  const IrrLossTerm& m = T.t[blockIdx.x];
-  const float eps = 1e-8f, n = (float)m.hw;
-  float s1 = 0.f, s2 = 0.f;
-  for (int b = threadIdx.x; b < m.B; b += 64) {
-    const float tp = m.aux[b * 4 + 0], fn = m.aux[b * 4 + 1], st = m.aux[b * 4 + 2], sp = m.aux[b * 4 + 3];
-    s1 += tp / (st + sp + eps);
-    s2 += fn / ((n - st) + (n - sp) + eps);
-  }
+// ONE block finishes all terms in a fixed order: wave w takes the terms w, w+4, ...; a lane folds the block partials of its
+// samples in index order into aux[b][0..3] (kept for the backward pass), the per-sample algebra
+// weight * ( sum_b tp/(st+sp+eps) + sum_b fn/((N-st)+(N-sp)+eps) ) is reduced by the fixed shuffle tree, and thread 0 adds
+// the term values to out[0] in term order
+__global__ __launch_bounds__(256) void f1_multi_value_kernel(const LossTerms T, const float* __restrict__ part,
+                                                            float* __restrict__ out) {
+  __shared__ float termval[IRR_LOSS_MAX_TERMS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int ti = wv; ti < T.n; ti += 4) {
+    const IrrLossTerm& m = T.t[ti];
+    const float eps = 1e-8f, n = (float)m.hw;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = lane; b < m.B; b += 64) {
+      const float4* p = (const float4*)part + (long)m.block0 + (long)b * m.nbx;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < m.nbx; ++i) {
+        const float4 v = p[i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+      *(float4*)(m.aux + (long)b * 4) = a;
+      s1 += a.x / (a.z + a.w + eps);
+      s2 += a.y / ((n - a.z) + (n - a.w) + eps);
+    }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s1 += __shfl_down(s1, o, 64);
-    s2 += __shfl_down(s2, o, 64);
+    for (int o = 32; o > 0; o >>= 1) {
+      s1 += __shfl_down(s1, o, 64);
+      s2 += __shfl_down(s2, o, 64);
+    }
+    if (lane == 0) termval[ti] = (s1 + s2) * m.weight;
   }
-  if (threadIdx.x == 0) unsafeAtomicAdd(out, (s1 + s2) * m.weight);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < T.n; ++i) s += termval[i];
+    out[0] += s;
+  }
 }
 
 __global__ __launch_bounds__(256) void f1_multi_bwd_kernel(const LossTerms T, const float* __restrict__ gscale) {
@@ -254,6 +288,12 @@ __global__ __launch_bounds__(256) void f1_multi_bwd_kernel(const LossTerms T, co
   m.grad[(long)b * m.grad_bs + p] = gscale[0] * m.weight * dls * s * (1.f - s);
 }
 
+// grid-stride blocks per sample of the forward reductions (= partial-sum slots per sample)
+static int reduce_blocks_per_sample(long hw) {
+  int bx = irr_cdiv(hw, 256 * 8);
+  return bx > 256 ? 256 : bx;
+}
+
 // lays the terms out over the blocks of one launch; mode 0: a few grid-stride blocks per sample (reductions), 1: one thread per pixel
 static long layout_terms(const IrrLossTerm* in, int n, int mode, LossTerms* T) {
   if (!in || n <= 0 || n > IRR_LOSS_MAX_TERMS) return -1;
@@ -261,8 +301,7 @@ static long layout_terms(const IrrLossTerm* in, int n, int mode, LossTerms* T) {
   for (int i = 0; i < n; ++i) {
     IrrLossTerm t = in[i];
     if (!t.pred || !t.tgt || t.B <= 0 || t.hw <= 0) return -1;
-    int nbx = mode == 0 ? irr_cdiv(t.hw, 256 * 8) : irr_cdiv(t.hw, 256);
-    if (mode == 0 && nbx > 256) nbx = 256;
+    const int nbx = mode == 0 ? reduce_blocks_per_sample(t.hw) : irr_cdiv(t.hw, 256);
     t.nbx = nbx;
     t.block0 = (int)blk;
     blk += (long)nbx * t.B;
@@ -290,13 +329,21 @@ extern "C" int irr_adaptive_avgpool_f32(const float* in, float* out, int BC, int
   return 0;
 }
 
+// partial-sum slots (floats) the forward reductions below need in `scratch`: one per block (EPE), four per block (F1)
+extern "C" long irr_loss_partial_blocks(int B, long HW) {
+  if (B <= 0 || HW <= 0) return IRR_EINVAL;
+  return (long)B * reduce_blocks_per_sample(HW);
+}
+
 extern "C" int irr_epe_sum_fwd_f32(const float* flow, const float* tgt, float* out, int B, int HW, long flow_bs,
-                                   long tgt_bs, float weight, void* stream) {
-  if (!flow || !tgt || !out || B <= 0 || HW <= 0 || B > 65535) return IRR_EINVAL;
-  int bx = irr_cdiv(HW, 256 * 8);
-  if (bx > 256) bx = 256;
-  hipLaunchKernelGGL(epe_fwd_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, flow, tgt, out, (long)HW, flow_bs,
+                                   long tgt_bs, float weight, float* scratch, long scratch_elems, void* stream) {
+  if (!flow || !tgt || !out || !scratch || B <= 0 || HW <= 0 || B > 65535) return IRR_EINVAL;
+  const int bx = reduce_blocks_per_sample(HW);
+  if (scratch_elems < (long)bx * B) return IRR_EINVAL;
+  hipLaunchKernelGGL(epe_fwd_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, flow, tgt, scratch, (long)HW, flow_bs,
                      tgt_bs, weight);
+  IRR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, (long)bx * B, out);
   IRR_LAUNCH_CHECK();
   return 0;
 }
@@ -311,11 +358,13 @@ extern "C" int irr_epe_sum_bwd_f32(const float* flow, const float* tgt, const fl
 }
 
 extern "C" int irr_f1bal_sums_f32(const float* logit, const float* tgt, float* sums, int B, int HW, long l_bs, long t_bs,
-                                  void* stream) {
-  if (!logit || !tgt || !sums || B <= 0 || HW <= 0 || B > 65535) return IRR_EINVAL;
-  int bx = irr_cdiv(HW, 256 * 8);
-  if (bx > 256) bx = 256;
-  hipLaunchKernelGGL(f1_sums_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, logit, tgt, sums, (long)HW, l_bs, t_bs);
+                                  float* scratch, long scratch_elems, void* stream) {
+  if (!logit || !tgt || !sums || !scratch || B <= 0 || HW <= 0 || B > 65535) return IRR_EINVAL;
+  const int bx = reduce_blocks_per_sample(HW);
+  if (scratch_elems < 4L * bx * B || ((size_t)scratch & 15) || ((size_t)sums & 15)) return IRR_EINVAL;
+  hipLaunchKernelGGL(f1_sums_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, logit, tgt, scratch, (long)HW, l_bs, t_bs);
+  IRR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(f1_fold_kernel, dim3(irr_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, scratch, sums, B, bx);
   IRR_LAUNCH_CHECK();
   return 0;
 }
@@ -357,11 +406,14 @@ extern "C" int irr_f1bal_bwd_f32(const float* logit, const float* tgt, const flo
 }
 
 // ---- multi-term entry points: `terms` is a HOST array of nterms IrrLossTerm records (include/irr_hip.h) ----
-extern "C" int irr_epe_sum_multi_fwd_f32(const void* terms, int nterms, float* out, void* stream) {
+extern "C" int irr_epe_sum_multi_fwd_f32(const void* terms, int nterms, float* out, float* scratch, long scratch_elems,
+                                         void* stream) {
   LossTerms T;
   const long nb = layout_terms((const IrrLossTerm*)terms, nterms, 0, &T);
-  if (nb <= 0 || !out) return IRR_EINVAL;
-  hipLaunchKernelGGL(epe_multi_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, T, out);
+  if (nb <= 0 || !out || !scratch || scratch_elems < nb) return IRR_EINVAL;
+  hipLaunchKernelGGL(epe_multi_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, T, scratch);
+  IRR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, nb, out);
   IRR_LAUNCH_CHECK();
   return 0;
 }
@@ -377,16 +429,17 @@ extern "C" int irr_epe_sum_multi_bwd_f32(const void* terms, int nterms, const fl
   return 0;
 }
 
-// per-sample sums of every term into its zeroed aux[B][4], then out[0] += sum over terms of weight * per-sample algebra
-extern "C" int irr_f1bal_multi_fwd_f32(const void* terms, int nterms, float* out, void* stream) {
+// per-sample sums of every term into its aux[B][4] (overwritten), then out[0] += sum over terms of weight * per-sample algebra
+extern "C" int irr_f1bal_multi_fwd_f32(const void* terms, int nterms, float* out, float* scratch, long scratch_elems,
+                                       void* stream) {
   LossTerms T;
   const long nb = layout_terms((const IrrLossTerm*)terms, nterms, 0, &T);
-  if (nb <= 0 || !out) return IRR_EINVAL;
+  if (nb <= 0 || !out || !scratch || scratch_elems < 4 * nb || ((size_t)scratch & 15)) return IRR_EINVAL;
   for (int i = 0; i < nterms; ++i)
-    if (!T.t[i].aux) return IRR_EINVAL;
-  hipLaunchKernelGGL(f1_multi_sums_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, T);
+    if (!T.t[i].aux || ((size_t)T.t[i].aux & 15)) return IRR_EINVAL;
+  hipLaunchKernelGGL(f1_multi_sums_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, T, scratch);
   IRR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(f1_multi_value_kernel, dim3((unsigned)nterms), dim3(64), 0, (hipStream_t)stream, T, out);
+  hipLaunchKernelGGL(f1_multi_value_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, T, (const float*)scratch, out);
   IRR_LAUNCH_CHECK();
   return 0;
 }

@@ -16,6 +16,8 @@ MI355X-side addition required by BASELINE.json.  Design:
 """
 from __future__ import annotations
 
+import time
+import weakref
 from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -66,6 +68,8 @@ class GradArena:
     decoders) and the 21 MB shared-decoder bucket under the backward of the feature pyramid; only the pyramid's own 4 MB
     are reduced after the last kernel of backward."""
 
+    MAX_CALIBRATION_ATTEMPTS = 3
+
     def __init__(self, named_params: Iterable[Tuple[str, torch.nn.Parameter]], group=None,
                  early_prefixes: Sequence[str] = EARLY_PREFIXES, late_prefixes: Sequence[str] = LATE_PREFIXES,
                  overlap: bool = True):
@@ -94,15 +98,23 @@ class GradArena:
                 off += n
             self.buckets.append((start, off))
             self._members.append(ids)
+        me = weakref.ref(self)
+        for _, p in self.order:                         # (irr_amd.harness: never build a second arena over these parameters)
+            p.__dict__["_irr_arena"] = me
         self._works = []
         self.overlap = overlap and dev.type == "cuda"
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
         self._side_lane = None
         self._hooks = []
         self._expected: Optional[dict] = None          # id(param) -> contributions per step (None: not calibrated yet)
+        self._expected_queued: Optional[List[int]] = None   # per bucket: weight-gradient launches QUEUED on the lane per step
         self.calibration_mismatch = False
+        self._calib_attempts = 0
+        self.broken: Optional[str] = None              # set by a late contribution: every later sync() raises until recalibrate()
         self._seen = {}
+        self._t0 = time.perf_counter()
         self.launch_log: List[Tuple[int, str]] = []    # (bucket, "backward" | "sync") of the last step -- tests / diagnostics
+        self.launch_times: List[float] = []            # ms since zero_grad() at which each entry of launch_log was enqueued
         self._reset()
         if self.world > 1:
             for _, p in self.order:
@@ -117,6 +129,9 @@ class GradArena:
         self._launched = [False] * len(self.buckets)
         self._in_sync = False
         self._late = False
+        self._queued = [0] * len(self.buckets)
+        self._t0 = time.perf_counter()
+        self.launch_times = []
         if self._expected is not None:
             self._remaining = [sum(1 for pid in ids if self._expected.get(pid, 0) > 0) for ids in self._members]
         else:
@@ -124,8 +139,14 @@ class GradArena:
         self.launch_log = []
 
     def recalibrate(self):
-        """forget the learned contribution counts (call when the model graph changes: other loss heads, frozen layers)"""
+        """forget the learned contribution counts (call when the model graph changes: other loss heads, frozen layers) -- on
+        EVERY rank before the same step: the next step is a calibration step (all buckets reduced at sync(), two extra small
+        all-reduces), and the ranks must run it together"""
         self._expected = None
+        self._expected_queued = None
+        self.calibration_mismatch = False
+        self._calib_attempts = 0
+        self.broken = None
         self._reset()
 
     def zero_grad(self):
@@ -145,17 +166,47 @@ class GradArena:
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
 
+    def _inside(self, t: torch.Tensor) -> bool:
+        return self.flat.data_ptr() <= t.data_ptr() < self.flat.data_ptr() + self.flat.numel() * 4
+
+    def adopt_grads(self):
+        """Make every ``param.grad`` a view of the arena again WITHOUT assuming who cleared it: a stock optimizer's
+        ``zero_grad()`` sets the gradients to None (torch's default, ``set_to_none=True``; the reference calls it once per step,
+        runtime.py:164) -- such a parameter gets its zeroed slice back; a gradient that still is the arena's view is kept as it is
+        (gradient accumulation over several backward passes); a foreign gradient tensor is copied into its slice.  Called by the
+        drop-in route (irr_amd.harness) at the start of every training forward pass."""
+        grads = [p.grad for _, p in self.order]
+        if all(g is None for g in grads):
+            self.flat.zero_()
+            self._reattach()
+            return
+        off = 0
+        with torch.no_grad():
+            for (_, p), g in zip(self.order, grads):
+                n = p.numel()
+                if g is None:
+                    self.flat[off:off + n].zero_()
+                    p.grad = self.flat[off:off + n].view_as(p)
+                elif not (self._inside(g) and g.data_ptr() == self.flat.data_ptr() + 4 * off):
+                    self.flat[off:off + n].copy_(g.reshape(-1))
+                    p.grad = self.flat[off:off + n].view_as(p)
+                off += n
+
     def _launch(self, bi: int):
         if self._launched[bi] or self.world == 1:
             return
         self._launched[bi] = True
         self.launch_log.append((bi, "sync" if self._in_sync else "backward"))
+        self.launch_times.append(round((time.perf_counter() - self._t0) * 1e3, 3))
         s, e = self.buckets[bi]
         if e == s:
             return
         chunk = self.flat[s:e]
         if self.overlap:
-            # the bucket's contributions were enqueued on the main stream (autograd) and / or on the weight-gradient lane
+            # the bucket's contributions were enqueued on the main stream (autograd) and / or on the weight-gradient lane.
+            # The lane's tail at this moment IS the bucket's last contribution: _on_queue() flushed the lane the moment the
+            # bucket's last weight-gradient launch of the step was queued, so the fold that completes the bucket is the last
+            # thing on the lane -- the all-reduce does not wait for later levels' launches that the lagging lane still holds.
             self._side.wait_stream(torch.cuda.current_stream())
             if self._side_lane is not None and self._side_lane.stream is not None:
                 self._side.wait_stream(self._side_lane.stream)
@@ -188,6 +239,18 @@ class GradArena:
         if bias is not None:
             self._contribution(id(bias))
 
+    def _on_queue(self, weight, bias):
+        """a weight-gradient launch for ``weight`` has just been QUEUED on the lane (its partial images are folded, and the
+        contribution reported through _on_lane, only when the lane's fold batch is flushed -- up to 40 launches later).  When it
+        is the bucket's last launch of the step, flush now: the bucket's all-reduce then waits for exactly that fold."""
+        bi = self._bucket_of.get(id(weight))
+        if bi is None:
+            return
+        self._queued[bi] += 1
+        if (self._expected_queued is not None and not self._launched[bi]
+                and self._queued[bi] == self._expected_queued[bi] and self._side_lane is not None):
+            self._side_lane.flush()
+
     def enable_async_wgrad(self):
         """Route every weight/bias gradient of the MFMA conv nodes straight into this arena on a second HIP stream
         (irr_amd.conv.WgradSide): the wgrad launches then overlap the data-gradient chain instead of sitting on
@@ -196,6 +259,7 @@ class GradArena:
         self._side_lane = conv.WgradSide({id(p): p.grad for _, p in self.order})
         if self.world > 1:
             self._side_lane.on_launch = self._on_lane
+            self._side_lane.on_queue = self._on_queue
         conv.SIDE = self._side_lane
         self.recalibrate()
 
@@ -206,6 +270,7 @@ class GradArena:
         self._side_lane = conv.WgradSide({id(p): p.grad for _, p in self.order}, inline=True)
         if self.world > 1:
             self._side_lane.on_launch = self._on_lane
+            self._side_lane.on_queue = self._on_queue
         conv.SIDE = self._side_lane
         self.recalibrate()
 
@@ -234,24 +299,34 @@ class GradArena:
             torch.cuda.current_stream().wait_stream(self._side)
         self.flat.mul_(1.0 / self.world)
         if self._late:
-            self._expected = None                       # (a caller that catches this continues in reduce-at-sync mode)
-            raise RuntimeError("a gradient contribution arrived after its bucket's all-reduce was started: the model graph "
-                               "differs from the calibrated one (the reduced gradients of this step are incomplete) -- call "
-                               "GradArena.recalibrate() before changing the graph")
-        if self._expected is None:
+            # The calibrated counts stay as they are (this rank keeps starting its buckets where the others do, so the collective
+            # sequences of all ranks still match) and the arena refuses to go on: the condition is rank-local knowledge, a rank
+            # that silently switched to reduce-at-sync mode would deadlock the others.
+            self.broken = ("a gradient contribution arrived after its bucket's all-reduce was started: the model graph differs "
+                           "from the calibrated one (the reduced gradients of that step were incomplete) -- call "
+                           "GradArena.recalibrate() on EVERY rank before the same step")
+        if self.broken is not None:
+            raise RuntimeError(self.broken)
+        if self._expected is None and self._calib_attempts < self.MAX_CALIBRATION_ATTEMPTS:
             # calibration step: every bucket was reduced here.  The learned counts decide WHEN each rank starts a bucket's
             # collective, so they must agree on every rank (ranks whose graphs differ would start the buckets in different
-            # orders and deadlock RCCL): compare them once; on a mismatch stay in reduce-at-sync mode.
-            counts = torch.tensor([self._seen[id(p)] for _, p in self.order], dtype=torch.int64, device=self.flat.device)
+            # orders and deadlock RCCL): compare them; on a mismatch this step stays the reduce-at-sync step it was and the next
+            # one is tried again (a first step may differ for transient reasons), MAX_CALIBRATION_ATTEMPTS times in all -- then the
+            # verdict is cached: reduce-at-sync mode without further comparison all-reduces / host syncs until recalibrate().
+            self._calib_attempts += 1
+            counts = torch.tensor([self._seen[id(p)] for _, p in self.order] + list(self._queued), dtype=torch.int64,
+                                  device=self.flat.device)
             lo, hi = counts.clone(), counts.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
             if bool((lo == hi).all()):
                 self._expected = dict(self._seen)
+                self._expected_queued = list(self._queued)
             else:
                 self.calibration_mismatch = True
                 import warnings
-                warnings.warn("GradArena: gradient-contribution counts differ between ranks -- buckets stay reduced at sync()")
+                warnings.warn("GradArena: gradient-contribution counts differ between ranks -- buckets stay reduced at sync()"
+                              + (" until recalibrate()" if self._calib_attempts >= self.MAX_CALIBRATION_ATTEMPTS else ""))
 
 
 def broadcast_params(module: torch.nn.Module, src: int = 0, group=None) -> None:

@@ -19,6 +19,8 @@ HEADER = os.path.join(os.path.dirname(_PKG), "include", "irr_hip.h")
 # IRR_HIP_LIB: load another build of the SAME ABI (ablation / trace builds of irr_amd.build with IRR_BUILD_TAG)
 LIB_PATH = os.environ.get("IRR_HIP_LIB") or os.path.join(_PKG, "lib", "libirr_hip.so")
 
+ABI_VERSION = 4          # irr_abi_version() of the library this binding was written against (csrc/misc.hip)
+
 _CTYPES = {
     "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
     "const int*": ctypes.c_void_p, "int*": ctypes.c_void_p,
@@ -60,6 +62,14 @@ class _Lib:
                             f"{LIB_PATH} is missing: the HIP extension is the product path and has no fallback. "
                             "Build it with `python -m irr_amd.build` (hipcc, gfx950).")
                     lib = ctypes.CDLL(LIB_PATH)
+                    lib.irr_abi_version.restype = ctypes.c_int
+                    got = lib.irr_abi_version()
+                    if got != ABI_VERSION:
+                        # argument types are taken from the HEADER in the tree: a library built from other sources would be
+                        # called with the wrong signatures (e.g. double vs float scalars) without any error
+                        raise RuntimeError(
+                            f"{LIB_PATH} has ABI version {got}, include/irr_hip.h / irr_amd.hip expect {ABI_VERSION}: the "
+                            "library was built from other sources -- rebuild it with `python -m irr_amd.build --force`")
                     for name, (ret, args) in self.protos.items():
                         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
                         fn.restype = ctypes.c_long if ret == "long" else ctypes.c_int

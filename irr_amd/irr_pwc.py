@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
+from . import harness as _harness
 from .modules import (ContextNetwork, FeatureExtractor, FlowEstimatorDense, OccContextNetwork, OccEstimatorDense,
                       OccUpsampleNetwork, RefineFlow, RefineOcc, WarpingLayer, conv, initialize_msra)
 
@@ -150,6 +151,7 @@ class PWCNet(nn.Module):
     def forward(self, input_dict):
         x1_raw, x2_raw = input_dict['input1'], input_dict['input2']
         B, _, H, W = x1_raw.shape
+        _harness.auto_install(self)            # no-op unless a foreign training loop drives the model (irr_amd/harness.py)
         div = self._div_flow
         dev = x1_raw.device
 

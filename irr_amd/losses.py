@@ -61,8 +61,9 @@ class _EpeSum(hip.Function):
         flow, tgt = _dense(flow), _dense(tgt)
         B, _, h, w = flow.shape
         out = torch.zeros(1, device=flow.device, dtype=torch.float32)
+        part = _partials([flow], 1)
         hip.call("irr_epe_sum_fwd_f32", hip.ptr(flow), hip.ptr(tgt), hip.ptr(out), B, h * w, hip.bs(flow), hip.bs(tgt),
-                 weight, hip.stream())
+                 weight, hip.ptr(part), part.numel(), hip.stream())
         ctx.weight = weight
         ctx.save_for_backward(flow, tgt)
         return out
@@ -86,9 +87,10 @@ class _F1BalLoss(hip.Function):
         _need_cuda(logit, tgt)
         logit, tgt = _dense(logit), _dense(tgt)
         B, _, h, w = logit.shape
-        sums = torch.zeros(B, 4, device=logit.device, dtype=torch.float32)
+        sums = torch.empty(B, 4, device=logit.device, dtype=torch.float32)
+        part = _partials([logit], 4)
         hip.call("irr_f1bal_sums_f32", hip.ptr(logit), hip.ptr(tgt), hip.ptr(sums), B, h * w, hip.bs(logit), hip.bs(tgt),
-                 hip.stream())
+                 hip.ptr(part), part.numel(), hip.stream())
         out = torch.empty(1, device=logit.device, dtype=torch.float32)
         # (tp/(st+sp+eps)).sum() + (fn/((n-st)+(n-sp)+eps)).sum(), times h*w*0.5 * weight: one launch instead of 15 torch ops
         hip.call("irr_f1bal_value_f32", hip.ptr(sums), hip.ptr(out), B, h * w, float(weight * h * w * 0.5), hip.stream())
@@ -115,6 +117,14 @@ class _Term(ctypes.Structure):
 
 
 MAX_TERMS = 32          # IRR_LOSS_MAX_TERMS
+
+
+def _partials(preds, per_block: int) -> torch.Tensor:
+    """scratch for the forward reductions: one slot (EPE) / four slots (F1) per block.  The blocks store their partial sums
+    there and one finishing block adds them in a fixed order (csrc/loss.hip): no atomics, bit-reproducible loss values."""
+    lib = hip.lib()
+    n = sum(int(lib.irr_loss_partial_blocks(p.shape[0], p.shape[2] * p.shape[3])) for p in preds)
+    return torch.empty(per_block * n, device=preds[0].device, dtype=torch.float32)
 
 
 def _paired_grads(preds):
@@ -165,7 +175,9 @@ class _MultiEpe(hip.Function):
         for i0 in range(0, n, MAX_TERMS):
             sl = slice(i0, i0 + MAX_TERMS)
             arr = _term_table(preds[sl], tgts[sl], weights[sl])
-            hip.call("irr_epe_sum_multi_fwd_f32", ctypes.addressof(arr), len(arr), hip.ptr(out), hip.stream())
+            part = _partials(preds[sl], 1)
+            hip.call("irr_epe_sum_multi_fwd_f32", ctypes.addressof(arr), len(arr), hip.ptr(out), hip.ptr(part), part.numel(),
+                     hip.stream())
         ctx.weights = weights
         ctx.n = n
         ctx.save_for_backward(*preds, *tgts)
@@ -195,13 +207,15 @@ class _MultiF1Bal(hip.Function):
         tgts = [_dense(t) for t in tensors[n:]]
         _need_cuda(*preds, *tgts)
         B = preds[0].shape[0]
-        sums = torch.zeros(n, B, 4, device=preds[0].device, dtype=torch.float32)
+        sums = torch.empty(n, B, 4, device=preds[0].device, dtype=torch.float32)
         out = torch.zeros(1, device=preds[0].device, dtype=torch.float32)
         scaled = tuple(w * p.shape[2] * p.shape[3] * 0.5 for w, p in zip(weights, preds))       # losses.py:553-556
         for i0 in range(0, n, MAX_TERMS):
             sl = slice(i0, i0 + MAX_TERMS)
             arr = _term_table(preds[sl], tgts[sl], scaled[sl], aux=[sums[i] for i in range(i0, min(n, i0 + MAX_TERMS))])
-            hip.call("irr_f1bal_multi_fwd_f32", ctypes.addressof(arr), len(arr), hip.ptr(out), hip.stream())
+            part = _partials(preds[sl], 4)
+            hip.call("irr_f1bal_multi_fwd_f32", ctypes.addressof(arr), len(arr), hip.ptr(out), hip.ptr(part), part.numel(),
+                     hip.stream())
         ctx.scaled = scaled
         ctx.n = n
         ctx.save_for_backward(sums, *preds, *tgts)

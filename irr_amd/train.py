@@ -2,7 +2,7 @@
 ``TrainingEpoch._step`` (runtime.py:131-194) + ``ModelAndLoss.forward`` (configuration.py:45-62) with
 Adam(lr=1e-4, weight_decay=4e-4) (scripts/IRR-PWC_flyingChairsOcc.sh:29-31):
 
-    zero_grad -> forward -> loss -> backward -> [grad all-reduce] -> NaN assert -> optimizer.step
+    [augmentation] -> zero_grad -> forward -> loss -> backward -> [grad all-reduce] -> NaN assert -> optimizer.step
 
 (the reference asserts between loss and backward; TrainStep(check_nan="before_backward") keeps that placement, the default
 asserts before the optimizer step from a pinned host copy of the loss -- same exception, weights never touched on NaN, no drain of
@@ -46,8 +46,11 @@ class TrainStep:
     """Holds model+loss+optimizer and runs reference-equivalent steps on device-resident batches."""
 
     def __init__(self, model_and_loss: ModelAndLoss, optimizer: torch.optim.Optimizer, training_key: str = "total_loss",
-                 grad_sync=None, check_nan=True):
-        """check_nan: True / "before_step" -- the reference's per-step assertion (runtime.py:182-183) evaluated BEFORE THE OPTIMIZER
+                 grad_sync=None, check_nan=True, augmentation=None):
+        """augmentation: optional callable(example_dict) -> example_dict applied under ``no_grad`` to the device-resident batch
+        before the forward pass, where the reference's ``_step`` runs its GPU augmentation (runtime.py:151-153), e.g.
+        ``irr_amd.augment.RandomAffineFlowOcc`` (augmentations.py:368-653).
+        check_nan: True / "before_step" -- the reference's per-step assertion (runtime.py:182-183) evaluated BEFORE THE OPTIMIZER
         STEP: the loss is copied to pinned host memory right after the forward pass, backward is enqueued, and the host reads the
         value (already there by then) before optimizer.step() -- same exception, no update of the weights on NaN, but no drain of
         the GPU pipeline between forward and backward.  "before_backward": the reference's exact placement (``.item()`` before
@@ -56,12 +59,16 @@ class TrainStep:
         self.optimizer = optimizer
         self.training_key = training_key
         self.grad_sync = grad_sync              # callable() run between backward and optimizer.step (data parallel)
+        self.augmentation = augmentation
         if check_nan not in (True, False, "before_step", "before_backward"):
             raise ValueError(check_nan)
         self.check_nan = "before_step" if check_nan is True else check_nan
         self._loss_host = None                  # pinned scalar for the deferred check
 
     def __call__(self, example_dict: Dict[str, torch.Tensor]):
+        if self.augmentation is not None:        # runtime.py:151-153
+            with torch.no_grad():
+                example_dict = self.augmentation(example_dict)
         for key, t in example_dict.items():      # runtime.py:158-162
             if "input" in key:
                 t.requires_grad_(True)
@@ -82,6 +89,10 @@ class TrainStep:
         training_loss.backward()
         if self.grad_sync is not None:
             self.grad_sync()
+        elif _conv.SIDE is not None:
+            # weight gradients routed past autograd (enable_async_wgrad / enable_direct_wgrad) are complete only after the lane's
+            # deferred folds have run and the lane is joined: without a grad_sync (= GradArena.sync) that happens here
+            _conv.SIDE.join()
         if copied is not None:                    # the value left the device long ago: this wait does not stall the pipeline
             copied.synchronize()
             assert not math.isnan(float(self._loss_host)), "training_loss is NaN"
@@ -135,7 +146,7 @@ class GraphedTrainStep:
         # (detached: a caller's tensor may already require grad -- the static copies must be leaves of their own)
         self.static_in = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in example_dict.items()}
         eager = TrainStep(self.step.model_and_loss, self.step.optimizer, self.step.training_key, self.step.grad_sync,
-                          check_nan=False)
+                          check_nan=False, augmentation=self.step.augmentation)
         snap = self.step.optimizer.snapshot()         # the warm-up steps below must not count as training steps
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(device=cur.device)

@@ -19,7 +19,7 @@ def test_library_exports_all_declared_symbols():
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in hip.prototypes():
         assert hasattr(lib, name), f"{name} declared in include/irr_hip.h but not exported"
-    assert lib.irr_abi_version() >= 1
+    assert lib.irr_abi_version() == hip.ABI_VERSION
 
 
 def test_argument_validation_without_gpu():
@@ -31,3 +31,35 @@ def test_argument_validation_without_gpu():
         assert "-22" in str(e)
     else:
         raise AssertionError("expected IRR_EINVAL")
+
+
+def test_binding_refuses_a_library_of_another_abi(monkeypatch):
+    """the argument types come from the header in the tree, so a stale library must be refused at load time."""
+    import pytest
+    fresh = hip._Lib()
+    monkeypatch.setattr(hip, "ABI_VERSION", hip.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        fresh.load()
+
+
+def test_build_is_keyed_on_content_not_on_mtime(tmp_path):
+    """objects newer than changed sources (the copy to the GPU box) must still be rebuilt; the stamp next to the
+    library names the sources it was LINKED from."""
+    from irr_amd import build as B
+    assert not B.stale(), "conftest builds the library"
+    assert B.built_hash() == B.source_hash()
+    objdir = os.path.join(os.path.dirname(hip.LIB_PATH), "obj")
+    stamp = os.path.join(objdir, "misc.o.hash")
+    good = open(stamp).read()
+    try:
+        with open(stamp, "w") as f:                 # as if misc.hip had other contents when misc.o was compiled
+            f.write("0" * 16)
+        os.utime(os.path.join(objdir, "misc.o"))    # ... and the object is NEWER than every source
+        t0 = os.path.getmtime(hip.LIB_PATH)
+        B.build(verbose=False)
+        assert open(stamp).read() == good, "the object was not recompiled although its content key differed"
+        assert os.path.getmtime(hip.LIB_PATH) > t0, "the library was not relinked"
+    finally:
+        if open(stamp).read() != good:
+            B.build(force=True, verbose=False)
+    assert B.built_hash() == B.source_hash()

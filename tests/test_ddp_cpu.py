@@ -1,6 +1,7 @@
 """world_size-2 gloo test (CPU) of the data-parallel pieces: batch sharding, gradient arena with bucketed
 all-reduce, and the loss-scalar reduction that keeps flow/occ balancing identical to a single process."""
 import os
+import time
 import types
 
 import pytest
@@ -29,6 +30,7 @@ class _LaneConv(torch.autograd.Function):
             bobj.grad += gy.sum(dim=(0, 2, 3))
         arena = arena_box[0]
         if arena is not None and arena.world > 1:
+            arena._on_queue(wobj, bobj)          # (the real lane reports "queued" first, "folded into the gradient" later)
             arena._on_lane(wobj, bobj)
         gx = torch.nn.grad.conv2d_input(x.shape, w, gy, padding=1) if ctx.needs_input_grad[0] else None
         return gx, None, None, None
@@ -43,9 +45,13 @@ class Toy(nn.Module):
         self.conv_1x1_1 = nn.Conv2d(4, 2, 1)
         self.arena_box = [None]
 
+        self.stall = 0.0                                                  # seconds this rank sleeps in the middle of backward
+
     def forward(self, x):
         f = torch.tanh(self.feature_pyramid_extractor(x))
         h = torch.tanh(_LaneConv.apply(f, self.body.weight, self.body.bias, self.arena_box))
+        if self.stall > 0 and h.requires_grad:
+            h.register_hook(lambda g, t=self.stall: (time.sleep(t), g)[1])
         h = torch.tanh(_LaneConv.apply(h, self.body.weight, self.body.bias, self.arena_box))
         return self.conv_1x1_1(h), self.occ_shuffle_upsample(h)
 
@@ -81,10 +87,13 @@ def _worker(rank, world, port, q):
     assert [n for n, _ in arena.order] == ["occ_shuffle_upsample.weight", "occ_shuffle_upsample.bias", "conv_1x1_1.weight",
                                            "conv_1x1_1.bias", "body.weight", "body.bias",
                                            "feature_pyramid_extractor.weight", "feature_pyramid_extractor.bias"]
-    full = _make_batch(4)
+    full = _make_batch(8)
     mine = ddp.shard_batch(full, rank, world)
     logs = []
-    for _ in range(3):                       # three rounds: calibration, then two with the all-reduces started in backward
+    for it in range(4):                      # calibration, then three rounds with the all-reduces started in backward;
+        # in the last one ONE rank stalls 200 ms in the middle of backward (between the two uses of the shared conv): the other
+        # ranks have started bucket 0 long before -- the collective ORDER is a property of the graph, not of the timing
+        model.stall = 0.2 if (it == 3 and rank == world - 1) else 0.0
         arena.zero_grad()
         ld = _loss(model, mine, ddp.reduce_losses())
         ld["total_loss"].backward()
@@ -93,7 +102,11 @@ def _worker(rank, world, port, q):
     # step 1 learns the contribution counts (body: 2 lane contributions per step) and reduces everything at sync();
     # afterwards every bucket starts its all-reduce the moment its last contribution is in, in finalisation order
     assert logs[0] == [(0, "sync"), (1, "sync"), (2, "sync")], logs
-    assert logs[1] == logs[2] == [(0, "backward"), (1, "backward"), (2, "backward")], logs
+    assert logs[1] == logs[2] == logs[3] == [(0, "backward"), (1, "backward"), (2, "backward")], logs
+    assert arena._expected_queued == [0, 2, 0], arena._expected_queued
+    assert len(arena.launch_times) == 3 and arena.launch_times == sorted(arena.launch_times)
+    if rank == world - 1:
+        assert arena.launch_times[1] >= 200.0, arena.launch_times          # bucket 1 completes after the stall
     exp = {n: arena._expected[id(p)] for n, p in model.named_parameters()}
     # (2 lane contributions; torch additionally runs the AccumulateGrad hook once for a parameter whose Function returned None)
     assert exp["body.weight"] in (2, 3) and exp["body.bias"] in (2, 3) and exp["conv_1x1_1.weight"] == 1, exp
@@ -102,20 +115,22 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_two_rank_gloo_matches_single_process():
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_gloo_matches_single_process(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 1000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + 13 * world) % 1000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=100) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
     res = [(r, torch.tensor(flat), loss) for r, flat, loss in res]
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    assert torch.allclose(res[0][1], res[1][1])                       # identical after all-reduce
+    for r in range(1, world):
+        assert torch.allclose(res[0][1], res[r][1])                   # identical after all-reduce
     # single process on the global batch: per-rank loss divides by the PER-RANK batch (losses.py:569-571),
     # so mean over ranks of grads == grads of (global loss / global batch) * ... check against that
     from irr_amd import ddp
@@ -123,7 +138,7 @@ def test_two_rank_gloo_matches_single_process():
     model = Toy()
     arena = ddp.GradArena(model.named_parameters())
     model.arena_box[0] = arena
-    full = _make_batch(4)
+    full = _make_batch(8)
     arena.zero_grad()
     ld = _loss(model, full, None)
     ld["total_loss"].backward()
@@ -174,6 +189,23 @@ def _failsafe_worker(rank, world, port, q):
     except RuntimeError as e:
         late = str(e)[:40]
     out["late"] = late
+    # (c) the rank that saw the late contribution stays refused (it keeps its calibrated schedule, so the collectives of the other
+    #     rank's next step still find their partners) until recalibrate() is called on every rank; then training goes on
+    arena.zero_grad()
+    _loss(model, mine, ddp.reduce_losses())["total_loss"].backward()
+    again = None
+    try:
+        arena.sync()
+    except RuntimeError as e:
+        again = str(e)[:40]
+    out["again"] = again
+    out["log_after_late"] = list(arena.launch_log)
+    arena.recalibrate()
+    for it in range(2):
+        arena.zero_grad()
+        _loss(model, mine, ddp.reduce_losses())["total_loss"].backward()
+        arena.sync()
+        out[f"relog{it}"] = list(arena.launch_log)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -196,6 +228,11 @@ def test_arena_is_fail_safe_when_ranks_disagree():
         assert res[r]["mismatch"] is True and res[r]["calibrated_after_mismatch"] is True, res
         assert res[r]["log0"] == res[r]["log1"] == [(0, "sync"), (1, "sync"), (2, "sync")], res
     assert res[0]["late"] is None and res[1]["late"] is not None and "contribution" in res[1]["late"], res
+    assert res[0]["again"] is None and res[1]["again"] == res[1]["late"], res
+    for r in (0, 1):
+        assert res[r]["log_after_late"] == [(0, "backward"), (1, "backward"), (2, "backward")], res
+        assert res[r]["relog0"] == [(0, "sync"), (1, "sync"), (2, "sync")], res
+        assert res[r]["relog1"] == [(0, "backward"), (1, "backward"), (2, "backward")], res
 
 
 def test_shard_batch():

@@ -75,3 +75,25 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0 and out["config"]["transport"] == "gloo"
     assert out["secondary"]["value"] > 0 and out["secondary"]["roofline"]["achieved"] > 0
     assert out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out
+
+
+def test_bench_eight_ranks_share_one_gpu_over_gloo():
+    """The driver's 8-GPU leg as far as ONE GPU allows: `bench.py --gpus 8` from a cold shell, eight ranks
+    sharing cuda:0 over gloo on a small shape -- launch_ranks, broadcast_params, contribution counting + MIN/MAX calibration over
+    8 ranks, the three buckets started inside backward on every later step, loss-scalar all-reduce, MAX-over-ranks timing with the
+    per-rank spread, rank-0 relay.  Only the RCCL transport itself is not exercised."""
+    import json
+    env = _env()
+    env["IRR_DDP_BACKEND"] = "gloo"
+    env["OMP_NUM_THREADS"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "2", "--batch", "1",
+                        "--height", "128", "--width", "192", "--no-secondary", "--no-cpu-baseline", "--prealloc-gb", "0"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 8 and out["value"] > 0 and out["config"]["transport"] == "gloo"
+    assert len(out["ranks"]["per_rank_ms_per_step"]) == 8 and max(out["ranks"]["per_rank_ms_per_step"]) == pytest.approx(out["ms_per_step"], rel=1e-3)
+    log = [tuple(e[:2]) for e in out["ranks"]["bucket_launches_last_step"]]
+    assert log == [(0, "backward"), (1, "backward"), (2, "backward")], out["ranks"]

@@ -93,6 +93,149 @@ def _three_steps(step, m, g):
     return losses, d3, d31, full
 
 
+def test_reference_training_loop_drops_in(golden_dir):
+    """The model under the REFERENCE's own loop, literally (runtime.py:158-189: ``optimizer.zero_grad()`` -- torch's default
+    sets the gradients to None --, forward, ``.item()`` NaN assertion before ``backward()``, stock ``torch.optim.Adam.step()``;
+    optimizer as configuration.py:488-573 builds it) and nothing of this package's training harness: no GradArena, no FusedAdam,
+    no TrainStep.  Three steps on three batches against the imported reference (same checker as below) -- and the model must
+    have given itself the gradient arena + weight-gradient lane (irr_amd/harness.py), with the packed weights refreshed by ONE
+    batched launch per step although nobody announces the optimizer step."""
+    import math
+    import irr_amd
+    from irr_amd import conv as C, harness
+    from irr_amd.train import ModelAndLoss
+    from oracle import irr_pwc_oracle as O
+    from train3_check import problems
+    g = np.load(os.path.join(golden_dir, "train3_B2_128x192.npz"))
+    assert C.SIDE is None, "a previous test left its lane installed"
+    results = {}
+    for auto in (True, False):
+        harness.set_enabled(auto)
+        try:
+            m = irr_amd.PWCNet(_args(2), mask_threshold=0.9999)
+            m.load_state_dict(O.synthetic_params(0), strict=True)
+            m = m.cuda().train()
+            mal = ModelAndLoss(_args(2), m, irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(_args(2))).train()
+            optimizer = torch.optim.Adam(mal.parameters(), lr=1e-4, weight_decay=4e-4)
+            launches = []
+
+            def step(example_dict):
+                for key, t in example_dict.items():
+                    t.requires_grad_("input" in key)
+                optimizer.zero_grad()
+                loss_dict, output_dict = mal(example_dict)
+                training_loss = loss_dict["total_loss"]
+                assert not math.isnan(training_loss.item())
+                C.LAUNCHES.clear()
+                training_loss.backward()
+                optimizer.step()
+                launches.append(dict(C.LAUNCHES))
+                return loss_dict, output_dict, 2
+
+            res = _three_steps(step, m, g)
+            bad = problems(g, *res)
+            assert bad == [], (auto, bad)
+            results[auto] = res
+            assert harness.installed(m) == auto
+            if auto:
+                assert C.SIDE is not None and C.SIDE.auto
+                # steps 2 and 3 repack through the batched launch (one per step), not weight by weight
+                C.LAUNCHES.clear()
+                step(_batch(2, 128, 192, 5))
+                assert C.LAUNCHES["pack_batch"] == 1 and C.LAUNCHES["pack_single"] <= 4, dict(C.LAUNCHES)
+                assert all(p.grad is not None and harness._STATE[m][1]._inside(p.grad) for p in m.parameters())
+        finally:
+            harness.uninstall(m)
+            harness.set_enabled(True)
+    assert C.SIDE is None
+
+
+def test_fused_adam_is_an_optimizer_with_lr_schedule():
+    """FusedAdam under the reference's scheduler (configuration.py:579-608 builds torch.optim.lr_scheduler.MultiStepLR on the
+    optimizer; scripts/IRR-PWC_flyingChairsOcc.sh:24-26: milestones [54, 72, 90], gamma 0.5): three steps with a milestone after
+    the FIRST against torch.optim.Adam + the same scheduler on the same kernels -- and against the unscheduled run, which must
+    differ (the check has teeth)."""
+    from irr_amd.train import TrainStep, make_adam
+    from torch.optim.lr_scheduler import MultiStepLR
+
+    def run(kind, scheduled):
+        m, mal, arena, opt, step = _setup(2, lane=(kind == "fused"))
+        try:
+            if kind == "torch":
+                opt = make_adam(m.parameters())
+                step = TrainStep(mal, opt)
+            assert isinstance(opt, torch.optim.Optimizer) and len(opt.param_groups) == 1
+            sched = MultiStepLR(opt, milestones=[1], gamma=0.5) if scheduled else None
+            p0 = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).double().clone()
+            lrs = []
+            for seed in (1234, 99, 7):
+                step(_batch(2, 128, 192, seed))
+                if sched is not None:
+                    sched.step()
+                lrs.append(opt.param_groups[0]["lr"])
+            torch.cuda.synchronize()
+            return (torch.cat([p.detach().reshape(-1) for p in m.parameters()]).double() - p0).cpu(), lrs
+        finally:
+            arena.disable_async_wgrad()
+
+    d_fused, lrs = run("fused", True)
+    assert lrs == [5e-5, 5e-5, 5e-5], lrs
+    d_torch, lrs_t = run("torch", True)
+    assert lrs_t == lrs
+    d_plain, _ = run("fused", False)
+    rel = float((d_fused - d_torch).norm() / d_torch.norm())
+    teeth = float((d_plain - d_torch).norm() / d_torch.norm())
+    print(f"3 scheduled steps: FusedAdam vs torch.optim.Adam update difference {rel:.2e}; unscheduled differs by {teeth:.2e}")
+    assert rel <= 2e-3 and teeth >= 0.2, (rel, teeth)
+
+
+def test_train_step_applies_augmentation_before_the_forward_pass():
+    """TrainStep(augmentation=...) == the reference's ``_step`` (runtime.py:151-153): the batch is augmented under no_grad before
+    the forward pass; the step then equals a plain step on the pre-augmented batch."""
+    from irr_amd.augment import RandomAffineFlowOcc
+    from irr_amd.train import TrainStep
+    b = _batch(2, 192, 256)
+    aug_args = types.SimpleNamespace(batch_size=2)
+    losses = []
+    for pre in (False, True):
+        m, mal, arena, opt, _ = _setup(2)
+        try:
+            aug = RandomAffineFlowOcc(aug_args, addnoise=False, crop=[128, 192]).cuda()
+            torch.manual_seed(11)
+            np.random.seed(11)
+            if pre:
+                with torch.no_grad():
+                    ex = aug({k: v.clone() for k, v in b.items()})
+                assert ex["input1"].shape[-2:] == (128, 192)
+                ld, _, bs = TrainStep(mal, opt, grad_sync=arena.sync)(ex)
+            else:
+                ld, _, bs = TrainStep(mal, opt, grad_sync=arena.sync, augmentation=aug)({k: v.clone() for k, v in b.items()})
+            torch.cuda.synchronize()
+            losses.append((float(ld["total_loss"].detach()), opt.param_flat.double().sum().item()))
+        finally:
+            arena.disable_async_wgrad()
+    assert losses[0][0] == pytest.approx(losses[1][0], rel=1e-5) and losses[0][1] == pytest.approx(losses[1][1], rel=1e-7), losses
+
+
+def test_step_without_grad_sync_still_steps_on_complete_gradients():
+    """with a lane installed but no grad_sync, TrainStep / FusedAdam.step must join the lane (deferred folds) themselves."""
+    from irr_amd.train import TrainStep
+    b = _batch(2, 128, 192)
+    flats = []
+    for explicit in (True, False):
+        m, mal, arena, opt, _ = _setup(2)
+        try:
+            step = TrainStep(mal, opt, grad_sync=arena.sync if explicit else None)
+            step({k: v.clone() for k, v in b.items()})
+            torch.cuda.synchronize()
+            flats.append((arena.flat.clone(), opt.param_flat.clone()))
+            assert arena._side_lane.batch.n == 0 and not arena._side_lane._queued
+        finally:
+            arena.disable_async_wgrad()
+    assert torch.allclose(flats[0][0], flats[1][0], rtol=1e-4, atol=1e-7)
+    assert torch.allclose(flats[0][1], flats[1][1], rtol=0, atol=1e-7)
+
+
 @pytest.mark.parametrize("mode", ["eager", "graphed", "torch_adam"])
 def test_three_optimizer_steps_vs_reference(golden_dir, mode, routing):
     """Three consecutive optimisation steps on three different batches against the imported reference
@@ -236,7 +379,13 @@ def _vs_chunked_oracle(B, H, W, chunk):
             d = float((p.grad.double().cpu() - r).norm())
             worst = max(worst, d / (float(r.norm()) + 1e-4 * tot_ref))
             assert d <= 2e-3 * float(r.norm()) + 1e-5 * tot_ref, (n, d, float(r.norm()))
-        print(f"worst per-parameter gradient difference vs oracle {worst:.2e} (relative, floor 1e-4 of the total norm)")
+        line = (f"{B}x{H}x{W}: worst per-parameter gradient difference vs oracle {worst:.3e} (||g - g_oracle|| / (||g_oracle|| + "
+                f"1e-4 ||all||)); total grad-L2 {tot:.6f} vs {tot_ref:.6f}; losses {got} vs {ref}")
+        print(line)
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        if os.path.isdir(out_dir):                      # kept under profiles/r4_parity_margins.txt
+            with open(os.path.join(out_dir, "parity_margins.txt"), "a") as f:
+                f.write(line + "\n")
         return routing
     finally:
         arena.disable_async_wgrad()
