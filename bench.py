@@ -396,6 +396,12 @@ def main():
         second = run(make_step, SECONDARY[0], SECONDARY[1], SECONDARY[2], SECONDARY_STEPS, 2, not a.no_kernel_timer)
 
     extra = {}
+    if world == 1 and not a.no_extra_legs and not a.no_kernel_timer:
+        # what the per-launch HIP events of the timed region cost (~1 000 event pairs per step): 5 more steps without them
+        nt = run(make_step, a.batch, a.height, a.width, 5, 0, False)
+        extra["without_kernel_timer"] = {"value": round(nt["value"], 3), "ms_per_step": round(nt["dt"] / 5 * 1e3, 3), "steps": 5,
+                                         "note": "same process, same step, KernelTimer off (the headline's timed region records two "
+                                                 "HIP events around every conv launch for the roofline object)"}
     if world == 1 and not a.no_extra_legs and a.harness == "own" and not a.no_async_wgrad and not a.no_kernel_timer:
         # (1) kernel quality without lane time-sharing: 3 steps with the weight gradients on the main stream, same process
         arena.disable_async_wgrad()

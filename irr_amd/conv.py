@@ -170,7 +170,8 @@ def _packed(weight: torch.Tensor, transpose: bool, slot: str, nbytes_fn, dtype, 
         return hit[1]
     reg = _registry(w.device)
     if hit is not None:
-        _announce_rewrite(reg, hit[0], tag)
+        if not weight.__dict__.get("_irr_derived", False):
+            _announce_rewrite(reg, hit[0], tag)
         if reg.refresh():
             hit = cache.get(key)
             if hit[0] == _weight_tag(w):
@@ -262,8 +263,9 @@ def _call_conv(args) -> None:
 
 def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, dil: int,
                  lrelu: bool, out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
-                 alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
-    """out = [res +] alpha * act(conv(x, weight) + bias)   (accumulate: out += ...)."""
+                 alpha: float = 1.0, accumulate: bool = False, real_cin: Optional[int] = None) -> torch.Tensor:
+    """out = [res +] alpha * act(conv(x, weight) + bias)   (accumulate: out += ...).
+    real_cin: the layer's true input-channel count when x / weight are zero-padded copies (KernelTimer prices algorithmic FLOPs)."""
     # (the LeakyReLU'-mask epilogue of the kernel is only used by conv_dgrad)
     B, cin, H, W = x.shape
     cout, cin_w, k, _ = weight.shape
@@ -301,7 +303,7 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     else:
         if variant is None:
             variant = hip.lib().irr_conv2d_fwd_variant(B, cout, oh, ow, k)
-        TIMER.wrap(variant, 2.0 * B * oh * ow * cout * cin * k * k, lambda: _call_conv(args))
+        TIMER.wrap(variant, 2.0 * B * oh * ow * cout * (real_cin or cin) * k * k, lambda: _call_conv(args))
     return out
 
 
@@ -333,7 +335,7 @@ S2_GATHER_MAX_CIN = 96   # stride-2 3x3 data gradients with at most this many re
 def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in_hw: Tuple[int, int],
                gx: Optional[torch.Tensor] = None, accumulate: bool = False,
                mask: Optional[torch.Tensor] = None, nmask: int = 0,
-               res: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+               res: Optional[torch.Tensor] = None, alpha: float = 1.0, real_cin: Optional[int] = None) -> torch.Tensor:
     """gx (+)= conv_transpose(gy, weight); gy must already carry the activation derivative.
     mask/nmask: afterwards gx[:, :nmask] *= LeakyReLU'(mask[:, :nmask]) in the same launch (mask = the saved
     activation that produced this conv's input), i.e. gx comes out as a PRE-activation gradient.
@@ -381,7 +383,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         else:
             if variant is None:
                 variant = hip.lib().irr_conv2d_fwd_variant(B, cin, H, W, k)
-            TIMER.wrap(variant, 2.0 * B * H * W * cout * cin * k * k, lambda: _call_conv(args), "dgrad")
+            TIMER.wrap(variant, 2.0 * B * H * W * cout * (real_cin or cin) * k * k, lambda: _call_conv(args), "dgrad")
     elif stride == 2 and k == 3 and dil == 1 and H == 2 * oh and W == 2 * ow and cout >= 2 and cin > S2_GATHER_MAX_CIN:
         # transposed stride-2 conv == stride-1 conv (flipped weights) of the zero-interleaved gradient
         z = torch.zeros(B, cout, H, W, device=gy.device, dtype=torch.float32)
@@ -503,9 +505,11 @@ class WgradSide:
     (or a whole coarse-level launch, which cannot fill 256 CUs) leaves idle.  Autograd then receives ``None`` for
     those parameters; GradArena.sync() joins the lane before the all-reduce / optimizer step."""
 
-    def __init__(self, views, inline: bool = False):
-        self.views = views                      # id(parameter) -> flat-arena view with the parameter's shape
-        dev = next(iter(views.values())).device
+    def __init__(self, params_and_views, inline: bool = False):
+        # id(parameter) -> (weak reference to the parameter, flat-arena view with its shape).  Looked up by id for speed and
+        # verified by identity: the id of a dead parameter can be reused by a parameter of ANOTHER model
+        self.views = {id(p_): (weakref.ref(p_), v_) for p_, v_ in params_and_views}
+        dev = next(iter(self.views.values()))[1].device
         # inline: no second stream -- the launches stay on the current stream, but still accumulate straight into the arena
         # (no per-use gradient tensors, no autograd accumulation adds, one batched fold): GradArena.enable_direct_wgrad()
         self.inline = inline
@@ -531,12 +535,18 @@ class WgradSide:
         # runtime.py:188-189) the first launch of a backward pass registers join() as a FINAL CALLBACK of that pass: it runs on
         # the thread that called backward(), on its current stream, once the whole graph has been executed.
         self._join_queued = False
+        # experiment switch (tools/graph_bisect.py): the inline lane keeps its operands alive until join(), as the asynchronous one does
+        self.hold = [] if (inline and os.environ.get("IRR_LANE_HOLD")) else None
+
+    def _view(self, p_):
+        hit = self.views.get(id(p_))
+        return hit[1] if (hit is not None and hit[0]() is p_) else None
 
     def route(self, weight, bias):
-        gw = self.views.get(id(weight))
+        gw = self._view(weight)
         if gw is None:
             return None
-        gb = self.views.get(id(bias)) if bias is not None else None
+        gb = self._view(bias) if bias is not None else None
         return gw, gb
 
     def _kick(self):
@@ -611,6 +621,8 @@ class WgradSide:
                 self.flush()
         if self.inline:
             fn()
+            if self.hold is not None:
+                self.hold += [t for t in tensors if t is not None]
             self._pending.append(params)
             if self.batch is None or not self.batch.n:
                 self.flush()
@@ -627,6 +639,8 @@ class WgradSide:
         self._join_queued = False               # (also after a backward pass that raised before its final callbacks ran)
         self.flush()
         if self.inline:
+            if self.hold is not None:
+                self.hold = []
             return
         torch.cuda.current_stream().wait_stream(self.stream)
         self._inflight.clear()                   # later work on the current stream is ordered after the lane
@@ -771,7 +785,7 @@ class _DenseEstimatorFn(hip.Function):
     GROW = (128, 128, 96, 64, 32)
 
     @staticmethod
-    def forward(ctx, nparts, base, *args):
+    def forward(ctx, nparts, base, nrelu, *args):
         # x arrives as `nparts` tensors (IRR-PWC: cost volume, projected features, flow / occlusion): they are copied straight
         # into their channel slices of the buffer, and backward returns the slices of the gradient buffer -- no torch.cat of the
         # decoder input in forward, no split of its gradient in backward
@@ -797,7 +811,7 @@ class _DenseEstimatorFn(hip.Function):
         else:
             out = conv_forward(buf[:, :ctot], ws[5], bs[5], 1, 1, False)
         ctx.save_for_backward(buf, *ws)
-        ctx.cfg = (cin0, E, has_base, tuple(widths))
+        ctx.cfg = (cin0, E, has_base, tuple(widths), int(nrelu))
         ctx.wobjs, ctx.bobjs = ws, bs
         return buf, out
 
@@ -805,9 +819,9 @@ class _DenseEstimatorFn(hip.Function):
     def backward(ctx, g_buf, g_out):
         buf = ctx.saved_tensors[0]
         ws = ctx.saved_tensors[1:]
-        cin0, E, has_base, widths = ctx.cfg
+        cin0, E, has_base, widths, nrelu = ctx.cfg
         nparts = len(widths)
-        need_x = any(ctx.needs_input_grad[2:2 + nparts])
+        need_x = any(ctx.needs_input_grad[3:3 + nparts])
         B, _, H, W = buf.shape
         ctot = 448 + cin0
         dev = buf.device
@@ -844,7 +858,11 @@ class _DenseEstimatorFn(hip.Function):
             last = k_ == 4
             if last and not need_x:
                 break
-            margs = (None if last else hip.ptr(buf[:, t0:t1]), 0 if last else hip.bs(buf), 0 if last else t1 - t0)
+            # (the input column: its first `nrelu` channels are LeakyReLU outputs whose producer wants the PRE-activation gradient
+            # -- the cost volume, models/IRR_PWC.py:94-95: the mask costs this MFMA-bound launch nothing, and the two HBM-bound
+            # cost-volume gradient kernels no longer read their 81-plane output)
+            nm = (nrelu if last else t1 - t0)
+            margs = (hip.ptr(buf[:, t0:t1]), hip.bs(buf), nm) if nm > 0 else (None, 0, 0)
             LAUNCHES["dense_column_x3" if use_x3[k_] else "dense_column_f32"] += 1
             if use_x3[k_]:
                 args = ("irr_conv2d_fwd_x3", hip.ptr(G), hip.ptr(packs[k_]), None, None, hip.ptr(G[:, t0:t1]), B, t0, H, W,
@@ -864,10 +882,10 @@ class _DenseEstimatorFn(hip.Function):
         # g_est is still being read by the asynchronous wgrad lane (conv_last): autograd gets its own copy, because
         # the engine may accumulate the other gradients of `base` into the returned tensor IN PLACE
         gbase = g_est.clone() if (has_base and ctx.needs_input_grad[1]) else None
-        out = [None, gbase]
+        out = [None, gbase, None]
         c0 = 448
         for i, wd in enumerate(widths):                       # per-part gradients = channel slices of G (plane-dense views)
-            out.append(G[:, c0:c0 + wd] if (need_x and ctx.needs_input_grad[2 + i]) else None)
+            out.append(G[:, c0:c0 + wd] if (need_x and ctx.needs_input_grad[3 + i]) else None)
             c0 += wd
         for i in range(6):
             out += [grads_w[i], grads_b[i]]
@@ -939,13 +957,18 @@ def _dense_column_packs(ws5, cin0: int, use_x3=(False,) * 5):
     return packs
 
 
-def dense_estimator(x, base, weights_and_biases):
+def dense_estimator(x, base, weights_and_biases, preact_grad_channels: int = 0):
     """(buf, out) -- see _DenseEstimatorFn.  x: the estimator's input, or a sequence of tensors whose channel concatenation
-    it is.  weights_and_biases = [w1, b1, ..., w5, b5, w_last, b_last]."""
+    it is.  weights_and_biases = [w1, b1, ..., w5, b5, w_last, b_last].
+    preact_grad_channels = n: the first n input channels are LeakyReLU(0.1) outputs and the gradient returned for them is the
+    PRE-activation gradient (multiplied by LeakyReLU' of the stored input) -- their producer must then not apply the derivative
+    again (functional.cost_volume(..., grad_is_preactivation=True))."""
     parts = tuple(x) if isinstance(x, (list, tuple)) else (x,)
     if not all(p_.is_cuda for p_ in parts):
         raise RuntimeError("irr_amd conv runs on the HIP device only (no CPU fallback)")
-    return _DenseEstimatorFn.apply(len(parts), base, *parts, *weights_and_biases)
+    if preact_grad_channels and preact_grad_channels != int(parts[0].shape[1]):
+        raise ValueError("preact_grad_channels must cover exactly the first input part")
+    return _DenseEstimatorFn.apply(len(parts), base, int(preact_grad_channels), *parts, *weights_and_biases)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -1048,6 +1071,9 @@ def _padded_cin(weight: torch.Tensor, cpad: int) -> torch.Tensor:
     if hit is not None and hit[0] == tag:
         return hit[1]
     wp = hit[1] if hit is not None else torch.zeros(w.shape[0], cpad, w.shape[2], w.shape[3], device=w.device, dtype=torch.float32)
+    # a DERIVED tensor: rewriting it here is a consequence of a parameter update that has been noticed already, not a new one
+    # (_announce_rewrite would move the weight epoch again and every later call would find its tag stale once more)
+    wp.__dict__["_irr_derived"] = True
     wp[:, :w.shape[1]].copy_(w)
     holder[cpad] = (tag, wp)
     return wp
@@ -1081,7 +1107,7 @@ class _OccUpsampleFn(hip.Function):
         x_in = torch.empty(B, cpad, H, W, device=occ_up.device, dtype=torch.float32)
         cat_channels_into(x_in, (occ_up,) + tuple(parts[1:]), zero_tail=cpad - cin)
         w_first = _padded_cin(w_init, cpad) if cpad > cin else w_init
-        x_init = conv_forward(x_in, w_first, b_init, 1, 1, True)
+        x_init = conv_forward(x_in, w_first, b_init, 1, 1, True, real_cin=cin)
         xs = [x_init]
         ts = []
         for _ in range(3):
@@ -1146,7 +1172,7 @@ class _OccUpsampleFn(hip.Function):
         gparts = [None] * nparts
         if any(ctx.needs_input_grad[2:2 + nparts]):
             w_first = _padded_cin(w_init, x_in.shape[1]) if x_in.shape[1] > cin else w_init
-            g_xin = conv_dgrad(gpre_init, w_first, 1, 1, hw_)
+            g_xin = conv_dgrad(gpre_init, w_first, 1, 1, hw_, real_cin=cin)
             c0 = 0
             for i, wd in enumerate(widths):
                 if ctx.needs_input_grad[2 + i]:

@@ -256,7 +256,7 @@ class GradArena:
         (irr_amd.conv.WgradSide): the wgrad launches then overlap the data-gradient chain instead of sitting on
         its critical path.  Autograd no longer sees those gradients; the lane reports each contribution instead."""
         from . import conv
-        self._side_lane = conv.WgradSide({id(p): p.grad for _, p in self.order})
+        self._side_lane = conv.WgradSide([(p, p.grad) for _, p in self.order])
         if self.world > 1:
             self._side_lane.on_launch = self._on_lane
             self._side_lane.on_queue = self._on_queue
@@ -267,7 +267,7 @@ class GradArena:
         """The same routing WITHOUT a second stream: the weight-gradient launches stay on the current stream but accumulate
         straight into this arena (no per-use gradient tensors, no autograd accumulation adds, batched folds)."""
         from . import conv
-        self._side_lane = conv.WgradSide({id(p): p.grad for _, p in self.order}, inline=True)
+        self._side_lane = conv.WgradSide([(p, p.grad) for _, p in self.order], inline=True)
         if self.world > 1:
             self._side_lane.on_launch = self._on_lane
             self._side_lane.on_queue = self._on_queue

@@ -47,7 +47,7 @@ def _need_cuda(*ts):
 # ----------------------------------------------------------------------------------------------
 class _CostVolume(hip.Function):
     @staticmethod
-    def forward(ctx, f1, f2, lrelu: bool):
+    def forward(ctx, f1, f2, lrelu: bool, premasked: bool = False):
         _need_cuda(f1, f2)
         f1, f2 = _pd(f1), _pd(f2)
         B, C, H, W = f1.shape
@@ -55,7 +55,9 @@ class _CostVolume(hip.Function):
         hip.call("irr_corr81_fwd_f32", hip.ptr(f1), hip.ptr(f2), hip.ptr(out), B, C, H, W,
                  hip.bs(f1), hip.bs(f2), hip.bs(out), int(lrelu), hip.stream())
         ctx.lrelu = lrelu
-        ctx.save_for_backward(f1, f2, out if lrelu else None)
+        # premasked: every consumer hands back the PRE-activation gradient (conv.dense_estimator(preact_grad_channels=81) applies
+        # LeakyReLU' in its data-gradient epilogue), so the 81-plane output is neither kept for nor read by the gradient kernels
+        ctx.save_for_backward(f1, f2, out if (lrelu and not premasked) else None)
         return out
 
     @staticmethod
@@ -68,14 +70,19 @@ class _CostVolume(hip.Function):
         hip.call("irr_corr81_bwd_f32", hip.ptr(f1), hip.ptr(f2), hip.ptr(gout), hip.ptr(out), hip.ptr(g1), hip.ptr(g2),
                  B, C, H, W, hip.bs(f1), hip.bs(f2), hip.bs(gout), hip.bs(out) if out is not None else 0,
                  hip.bs(g1) if g1 is not None else 0, hip.bs(g2) if g2 is not None else 0, hip.stream())
-        return g1, g2, None
+        return g1, g2, None, None
 
 
-def cost_volume(feat1: torch.Tensor, feat2: torch.Tensor, lrelu: bool = False) -> torch.Tensor:
-    """81-channel cost volume, optionally with the LeakyReLU(0.1) of models/IRR_PWC.py:94-95 fused."""
+def cost_volume(feat1: torch.Tensor, feat2: torch.Tensor, lrelu: bool = False, grad_is_preactivation: bool = False) -> torch.Tensor:
+    """81-channel cost volume, optionally with the LeakyReLU(0.1) of models/IRR_PWC.py:94-95 fused.
+    grad_is_preactivation (with lrelu): the caller guarantees that EVERY consumer returns the gradient already multiplied by
+    LeakyReLU'(out) (conv.dense_estimator(..., preact_grad_channels=81)); the backward kernels then skip the mask and never read
+    the 81-plane output (half of their HBM traffic at 96x112)."""
     if feat1.shape != feat2.shape:
         raise ValueError(f"feature maps must have equal shapes, got {tuple(feat1.shape)} vs {tuple(feat2.shape)}")
-    return _CostVolume.apply(feat1, feat2, lrelu)
+    if grad_is_preactivation and not lrelu:
+        raise ValueError("grad_is_preactivation only makes sense with the fused LeakyReLU")
+    return _CostVolume.apply(feat1, feat2, lrelu, bool(grad_is_preactivation))
 
 
 def compute_cost_volume(feat1, feat2, param_dict):

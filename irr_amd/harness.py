@@ -58,6 +58,12 @@ def uninstall(model) -> None:
         st[1].disable_async_wgrad()
 
 
+def _drop_lane(lane) -> None:
+    """the model died: its lane must not stay installed (it holds the model's gradient arena alive)"""
+    if _conv.SIDE is lane:
+        _conv.SIDE = None
+
+
 def auto_install(model: torch.nn.Module) -> None:
     """see the module docstring; cheap when already installed (one pass over the parameter list)"""
     if not _ENABLED or not model.training or not torch.is_grad_enabled():
@@ -65,8 +71,11 @@ def auto_install(model: torch.nn.Module) -> None:
     st = _STATE.get(model)
     side = _conv.SIDE
     mine = st[1]._side_lane if st is not None else None
-    if side is not None and side is not mine and not getattr(side, "auto", False):
-        return                                 # the caller installed its own lane (GradArena.enable_*_wgrad)
+    if side is not None and side is not mine:
+        if not getattr(side, "auto", False):
+            return                             # the caller installed its own lane (GradArena.enable_*_wgrad)
+        side.join()                            # another model's automatic lane: it must not stay installed while THIS model runs
+        _conv.SIDE = side = None
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         return
@@ -102,13 +111,10 @@ def auto_install(model: torch.nn.Module) -> None:
     if arena._side_lane is None:
         if capturing:
             return
-        if _conv.SIDE is not None:             # another model's automatic lane
-            _conv.SIDE.join()
         arena.enable_async_wgrad()             # (installs the lane as conv.SIDE)
         arena._side_lane.auto = True
+        weakref.finalize(model, _drop_lane, arena._side_lane)
     elif _conv.SIDE is not arena._side_lane:
-        if _conv.SIDE is not None:
-            _conv.SIDE.join()
         _conv.SIDE = arena._side_lane
     if not capturing:
         arena.adopt_grads()

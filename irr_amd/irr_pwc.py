@@ -176,7 +176,9 @@ class PWCNet(nn.Module):
                     flow = Fn.resize_bilinear_ac(flow, h, w)
                     occ = Fn.resize_bilinear_ac(occ, h, w)
                     xo_warp = warp_other(x, flow)
-                corr = Fn.cost_volume(x, xo_warp, lrelu=True)     # cost volume + LeakyReLU fused
+                # cost volume + LeakyReLU fused; its only consumers are the two estimators below, which hand back the gradient
+                # already multiplied by LeakyReLU' (PRE = 81 channels): the gradient kernels never read the 81-plane output
+                corr = Fn.cost_volume(x, xo_warp, lrelu=True, grad_is_preactivation=True)
 
                 x_1by1 = self.conv_1x1[l](x) if l != self.output_level else x
 
@@ -186,7 +188,7 @@ class PWCNet(nn.Module):
                 flow = flow * t_loc
 
                 # estimator + "est = flow + res" + cat([x_intm, est]) in one cat-free node (conv.dense_estimator)
-                ctx_in, flow_est = self.flow_estimators.forward_residual((corr, x_1by1, flow), flow)
+                ctx_in, flow_est = self.flow_estimators.forward_residual((corr, x_1by1, flow), flow, self.dim_corr)
                 flow_cont = self.context_networks(ctx_in, res=flow_est)
 
                 # The occlusion decoder + context network are independent of the flow branch until refine_occ: with
@@ -197,14 +199,14 @@ class PWCNet(nn.Module):
                     main = torch.cuda.current_stream()
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        ctx_in_o, occ_est = self.occ_estimators.forward_residual(occ_in, occ)
+                        ctx_in_o, occ_est = self.occ_estimators.forward_residual(occ_in, occ, self.dim_corr)
                         occ_cont = self.occ_context_networks(ctx_in_o, res=occ_est)
                     for t_ in occ_in:
                         t_.record_stream(side)
                     occ.record_stream(side)
                     pending_join = (main, side, occ_cont)
                 else:
-                    ctx_in_o, occ_est = self.occ_estimators.forward_residual(occ_in, occ)
+                    ctx_in_o, occ_est = self.occ_estimators.forward_residual(occ_in, occ, self.dim_corr)
                     occ_cont = self.occ_context_networks(ctx_in_o, res=occ_est)
                     pending_join = None
 

@@ -124,10 +124,10 @@ class _DenseEstimator(nn.Module):
         buf, out = C.dense_estimator(x, None, self._wb())
         return buf, out
 
-    def forward_residual(self, x, base):
+    def forward_residual(self, x, base, preact_grad_channels: int = 0):
         """Model fast path: returns (cat([x5, est]), est) with est = base + conv_last(x5), i.e. the input of
         the context network (models/IRR_PWC.py:110-114) without building it by concatenation."""
-        return C.dense_estimator(x, base, self._wb())
+        return C.dense_estimator(x, base, self._wb(), preact_grad_channels)
 
 
 class FlowEstimatorDense(_DenseEstimator):

@@ -11,6 +11,7 @@ the GPU pipeline between forward and backward)
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -124,7 +125,7 @@ class GraphedTrainStep:
         if getattr(step.optimizer, "capturable", False) is not True:
             raise ValueError("GraphedTrainStep needs an optimizer whose step count lives on the device (FusedAdam(capturable=True))")
         side = _conv.SIDE
-        if side is None or getattr(side, "inline", False):
+        if (side is None or getattr(side, "inline", False)) and not os.environ.get("IRR_GRAPH_ALLOW_NO_LANE"):
             # Measured in round 3 (tools/graph_step.py, LANE=none / LANE=direct): replays of a step captured WITHOUT the lane drift
             # or produce NaN -- with the lane, every tensor a weight-gradient launch reads stays alive until the join at the end of
             # backward; without it the capture-time allocator recycles them inside the graph and some reuse is not covered by the
@@ -158,7 +159,8 @@ class GraphedTrainStep:
         self.step.optimizer.restore(snap)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):            # (records the step; nothing executes until replay())
+        kw = {"stream": side} if os.environ.get("IRR_GRAPH_SAME_STREAM") else {}      # (experiment switch, tools/graph_bisect.py)
+        with torch.cuda.graph(self.graph, **kw):      # (records the step; nothing executes until replay())
             self.result = eager(self.static_in)
 
     def __call__(self, example_dict: Dict[str, torch.Tensor]):

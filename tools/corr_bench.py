@@ -10,6 +10,10 @@ for C, H, W in [(32, 96, 112), (32, 48, 56), (32, 24, 28)]:
         t = timeit(lambda: Fn.cost_volume(f1, f2, lrelu=True), iters=10)
     cv = Fn.cost_volume(f1, f2, lrelu=True); go = torch.randn_like(cv)
     tb = timeit(lambda: torch.autograd.grad(cv, (f1, f2), go, retain_graph=True), iters=10)
+    # round 4: the consumers hand back the pre-activation gradient, the gradient kernels do not read the 81-plane output
+    cvp = Fn.cost_volume(f1, f2, lrelu=True, grad_is_preactivation=True)
+    tp = timeit(lambda: torch.autograd.grad(cvp, (f1, f2), go, retain_graph=True), iters=10)
     by = B * H * W * 4 * (2 * C + 81) / 1e9
-    byb = B * H * W * 4 * (2 * C + 81 + 81 + 2 * C) / 1e9
-    print(f"corr C={C} {H}x{W}: fwd {t * 1e3:7.1f} us {by / t:5.2f} TB/s | bwd {tb * 1e3:7.1f} us {byb / tb:5.2f} TB/s", flush=True)
+    byb = B * H * W * 4 * (2 * C + 81 + 2 * C) / 1e9          # gout + f1 + f2 read, g1 + g2 written (both gradients)
+    print(f"corr C={C} {H}x{W}: fwd {t * 1e3:7.1f} us {by / t:5.2f} TB/s | bwd (both gradients) mask in the kernel {tb * 1e3:7.1f} us "
+          f"{byb / tb:5.2f} TB/s algorithmic | pre-masked gradient {tp * 1e3:7.1f} us {byb / tp:5.2f} TB/s algorithmic", flush=True)
