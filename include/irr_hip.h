@@ -84,6 +84,20 @@ int irr_warp_bwd_f32(const float* x, const float* flow, const float* gridx, cons
                      long x_bs, long flow_bs, long gout_bs, long gx_bs, long gflow_bs,
                      int height_im, int width_im, float div_flow, float mask_thr, int swap_halves, void* stream);
 
+/* The same gradients with the gradient w.r.t. x computed OWNER-COMPUTES (round 4): every pixel of gx is gathered by the thread
+ * that owns it from the output pixels whose bilinear targets include it (4-tap gather like the forward pass: no atomics, no zero
+ * fill), and the gradient w.r.t. the flow by a kernel with lanes along x.  Valid while every bilinear target stays within 8 pixels
+ * (per axis) of its output pixel; a SAMPLE that violates this is detected on the device and takes the atomic scatter of
+ * irr_warp_bwd_f32 inside the same call.  ws: caller-owned scratch of irr_warp_bwd_ws_elems(B, H, W) ints (any contents; only
+ * needed when gx != NULL). */
+long irr_warp_bwd_ws_elems(int B, int H, int W);
+int irr_warp_bwd_gather_f32(const float* x, const float* flow, const float* gridx, const float* gridy,
+                            const float* gout, float* gx, float* gflow,
+                            int B, int C, int H, int W,
+                            long x_bs, long flow_bs, long gout_bs, long gx_bs, long gflow_bs,
+                            int height_im, int width_im, float div_flow, float mask_thr, int swap_halves,
+                            int* ws, long ws_elems, void* stream);
+
 /* ---- bilinear resize, align_corners=True --------------------------------------------------------
  * upsample2d_as (models/pwc_modules.py:65-67).  out = alpha * resize(x).
  */

@@ -14,6 +14,8 @@
 
 namespace {
 
+#define GMAX_HOST 8     // == GMAX of the owner-computes gather below (samples with a larger margin take the atomic scatter)
+
 struct Taps {
   int x0, y0;
   float nw, ne, sw, se;     // weights (already zeroed for out-of-bounds taps? no: raw weights)
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
                                                       const float* __restrict__ gout, float* __restrict__ gx,
                                                       float* __restrict__ gflow, int C, int H, int W, long x_bs,
                                                       long flow_bs, long gout_bs, long gx_bs, long gflow_bs,
-                                                      float den_w, float den_h, float div_flow, float mask_thr, int xshift) {
+                                                      float den_w, float den_h, float div_flow, float mask_thr, int xshift,
+                                                      const int* __restrict__ gx_only_if) {
   const long plane = (long)H * W;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = lane & 15, r = lane >> 4;
@@ -156,7 +159,9 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
   const int bx = (b + xshift) % (int)gridDim.z;             // swap_halves: x (and its gradient) of the other batch half
   const float* xb = x + (long)bx * x_bs;
   const float* gb = gout + (long)b * gout_bs + pp;
-  float* gxb = gx ? gx + (long)bx * gx_bs : nullptr;
+  // gx_only_if (owner-computes route): the scatter only runs for the samples whose targets left the gather window
+  float* gxb = (gx && (!gx_only_if || gx_only_if[b] > GMAX_HOST)) ? gx + (long)bx * gx_bs : nullptr;
+  if (!gxb && !gflow) return;
   for (int ch = 0; ch < C; ++ch) {
     const float g = act ? gb[(long)ch * plane] : 0.f;
     if (gxb) {
@@ -184,6 +189,182 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     gf[pp] = gix * (0.5f * (float)(W - 1)) * (2.f / den_w / div_flow);
     gf[plane + pp] = giy * (0.5f * (float)(H - 1)) * (2.f / den_h / div_flow);
   }
+}
+
+
+// ---- owner-computes gradient w.r.t. x (round 4) ---------------------------------------------------------------------------
+// The scatter above is bound by the DEVICE-SCOPE atomic rate (~23 G/s: 1.2 ms at 96x112x64x32 for 90 us worth of HBM traffic).
+// Here every pixel s of gx is OWNED by one thread, which gathers what the output pixels scatter into it:
+//   1. warp_margin_kernel: per sample the largest distance M_b (in pixels, per axis) between an output pixel and any of its
+//      bilinear targets (one atomicMax per block);
+//   2. warp_gather_kernel: a block owns an 8 x 32 tile of gx.  It stages (x0, y0, four effective weights) of the output pixels
+//      within M_b of the tile in LDS; a thread scans the (2 M_b + 1)^2 candidates around its pixel for those whose targets
+//      include it, keeps up to four (offset, weight) pairs -- exactly the four of a locally translating flow -- and runs the
+//      channel loop as a 4-tap gather like the forward pass: plain loads, plain stores, no atomics, no zero fill.  Pixels with
+//      more than four contributors (compressive flows) take further rounds of the same loop (read-modify-write of their OWN
+//      pixel).  Samples with M_b > GMAX are zero-filled instead and
+//   3. warp_bwd_kernel (above) adds their gradient with the device-scope atomics.
+// All decisions are taken on the device: nothing synchronises.  (A first version accumulated with LDS atomics per owned tile:
+// 0.59 ms at 96x112x64x32 -- ds_add_f32 retires a few lanes per cycle -- against 1.23 ms of the device-scope scatter.)
+#define GMAX 8          // largest per-sample margin the gather window supports ((8 + 16) x (32 + 16) candidates in LDS)
+#define GK 4            // contributors per round
+
+struct GCand { int x0, y0; float nw, ne, sw, se; };
+
+__global__ __launch_bounds__(256) void warp_margin_kernel(const float* __restrict__ flow, const float* __restrict__ gridx,
+                                                         const float* __restrict__ gridy, int* __restrict__ margin, int H, int W,
+                                                         long flow_bs, float den_w, float den_h, float div_flow, float mask_thr) {
+  __shared__ int red[4];
+  const long plane = (long)H * W;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.z;
+  int m = 0;
+  if (p < plane) {
+    const int yy = (int)(p / W), xx = (int)(p - (long)yy * W);
+    const float* fl = flow + (long)b * flow_bs;
+    const Taps t = make_taps(fl[p], fl[plane + p], gridx[xx], gridy[yy], H, W, den_w, den_h, div_flow, mask_thr);
+    if (t.mask != 0.f) {
+      if (t.in_nw || t.in_sw) m = max(m, abs(t.x0 - xx));
+      if (t.in_ne || t.in_se) m = max(m, abs(t.x0 + 1 - xx));
+      if (t.in_nw || t.in_ne) m = max(m, abs(t.y0 - yy));
+      if (t.in_sw || t.in_se) m = max(m, abs(t.y0 + 1 - yy));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(red[0], red[1]), max(red[2], red[3]));
+    if (m > 0) atomicMax(margin + b, m);
+  }
+}
+
+__global__ __launch_bounds__(256) void warp_gather_kernel(const float* __restrict__ flow, const float* __restrict__ gridx,
+                                                         const float* __restrict__ gridy, const float* __restrict__ gout,
+                                                         float* __restrict__ gx, const int* __restrict__ margin, int C, int H,
+                                                         int W, long flow_bs, long gout_bs, long gx_bs, float den_w, float den_h,
+                                                         float div_flow, float mask_thr, int xshift) {
+  __shared__ GCand cand[(8 + 2 * GMAX) * (32 + 2 * GMAX)];
+  const long plane = (long)H * W;
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int nb = gridDim.z;
+  const int bs = blockIdx.z;                                           // the owned tile of gx belongs to sample bs
+  const int b = (bs - xshift + nb) % nb;                               // the output sample that scatters into sample bs
+  const int X0 = blockIdx.x * 32, Y0 = blockIdx.y * 8;
+  const int ox = X0 + c, oy = Y0 + r;
+  const bool own = ox < W && oy < H;
+  float* gdst = gx + (long)bs * gx_bs + (long)(own ? oy : 0) * W + (own ? ox : 0);
+  const int M = margin[b];                                             // (uniform)
+  if (M > GMAX) {                                                      // the atomic kernel handles this sample: zero fill
+    if (own)
+      for (int ch = 0; ch < C; ++ch) gdst[(long)ch * plane] = 0.f;
+    return;
+  }
+  // stage the candidates: output pixels [Y0 - M, Y0 + 7 + M] x [X0 - M, X0 + 31 + M]
+  const int RW = 32 + 2 * M, RH = 8 + 2 * M;
+  const float* fl = flow + (long)b * flow_bs;
+  for (int i = threadIdx.x; i < RW * RH; i += 256) {
+    const int ry = i / RW, rx = i - ry * RW;
+    const int yy = Y0 - M + ry, xx = X0 - M + rx;
+    GCand g;
+    g.x0 = g.y0 = -(1 << 30);
+    g.nw = g.ne = g.sw = g.se = 0.f;
+    if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+      const long pp = (long)yy * W + xx;
+      const Taps t = make_taps(fl[pp], fl[plane + pp], gridx[xx], gridy[yy], H, W, den_w, den_h, div_flow, mask_thr);
+      if (t.mask != 0.f) {
+        g.x0 = t.x0; g.y0 = t.y0;
+        g.nw = t.in_nw ? t.nw : 0.f; g.ne = t.in_ne ? t.ne : 0.f; g.sw = t.in_sw ? t.sw : 0.f; g.se = t.in_se ? t.se : 0.f;
+      }
+    }
+    cand[i] = g;
+  }
+  __syncthreads();
+  const float* gb = gout + (long)b * gout_bs;
+  const long self = (long)(own ? oy : 0) * W + (own ? ox : 0);
+  const int nwin = (2 * M + 1) * (2 * M + 1);
+  int resume = 0;                                                      // first window index not consumed yet
+  bool first = true;
+  for (;;) {
+    // collect up to GK contributors among the window entries >= resume (the window of pixel (r, c) starts at cand[r][c])
+    long off[GK];
+    float wt[GK];
+#pragma unroll
+    for (int k = 0; k < GK; ++k) { off[k] = self; wt[k] = 0.f; }
+    int cnt = 0, next = nwin;
+    if (own) {
+      int wi = 0;
+      for (int dy = 0; dy <= 2 * M; ++dy) {
+        for (int dx = 0; dx <= 2 * M; ++dx, ++wi) {
+          if (wi < resume) continue;
+          const GCand g = cand[(r + dy) * RW + c + dx];
+          const int ex = ox - g.x0, ey = oy - g.y0;                    // 0 or 1 when this pixel is one of the candidate's targets
+          if ((unsigned)ex > 1u || (unsigned)ey > 1u) continue;
+          const float w = ey ? (ex ? g.se : g.sw) : (ex ? g.ne : g.nw);
+          if (w == 0.f) continue;
+          if (cnt == GK) { next = min(next, wi); continue; }
+          const long po = (long)(oy - M + dy) * W + (ox - M + dx);
+          if (cnt == 0) { off[0] = po; wt[0] = w; }
+          else if (cnt == 1) { off[1] = po; wt[1] = w; }
+          else if (cnt == 2) { off[2] = po; wt[2] = w; }
+          else { off[3] = po; wt[3] = w; }
+          ++cnt;
+        }
+      }
+    }
+    const bool work = own && (first || cnt > 0);
+    if (work) {
+#pragma unroll 4
+      for (int ch = 0; ch < C; ++ch) {
+        const float* gc = gb + (long)ch * plane;
+        float v = gc[off[0]] * wt[0] + gc[off[1]] * wt[1] + gc[off[2]] * wt[2] + gc[off[3]] * wt[3];
+        if (!first) v += gdst[(long)ch * plane];
+        gdst[(long)ch * plane] = v;
+      }
+    }
+    first = false;
+    resume = next;
+    if (!__any(own && next < nwin)) break;
+  }
+}
+
+// gradient w.r.t. the flow alone (owner-computes route: the scatter kernel above spends its time in the 16 x 4 lane layout its
+// atomic merging needs -- 4 cache lines per load instruction).  Lanes run along x: gout and the four taps of x are read with
+// (nearly) coalesced loads, four channels in flight per thread.
+__global__ __launch_bounds__(256) void warp_gflow_kernel(const float* __restrict__ x, const float* __restrict__ flow,
+                                                        const float* __restrict__ gridx, const float* __restrict__ gridy,
+                                                        const float* __restrict__ gout, float* __restrict__ gflow, int C,
+                                                        int H, int W, long x_bs, long flow_bs, long gout_bs, long gflow_bs,
+                                                        float den_w, float den_h, float div_flow, float mask_thr, int xshift) {
+  const long plane = (long)H * W;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  const int b = blockIdx.z;
+  const int yy = (int)(p / W), xx = (int)(p - (long)yy * W);
+  const float* fl = flow + (long)b * flow_bs;
+  const Taps t = make_taps(fl[p], fl[plane + p], gridx[xx], gridy[yy], H, W, den_w, den_h, div_flow, mask_thr);
+  float* gf = gflow + (long)b * gflow_bs;
+  float gix = 0.f, giy = 0.f;
+  if (t.mask != 0.f) {
+    const int bx = (b + xshift) % (int)gridDim.z;
+    // clamped tap offsets: an out-of-image tap reads a valid address and is multiplied by 0
+    const long o_nw = t.in_nw ? (long)t.y0 * W + t.x0 : 0, o_ne = t.in_ne ? (long)t.y0 * W + t.x0 + 1 : 0;
+    const long o_sw = t.in_sw ? (long)(t.y0 + 1) * W + t.x0 : 0, o_se = t.in_se ? (long)(t.y0 + 1) * W + t.x0 + 1 : 0;
+    const float m_nw = t.in_nw ? 1.f : 0.f, m_ne = t.in_ne ? 1.f : 0.f, m_sw = t.in_sw ? 1.f : 0.f, m_se = t.in_se ? 1.f : 0.f;
+    const float* xb = x + (long)bx * x_bs;
+    const float* gb = gout + (long)b * gout_bs + p;
+#pragma unroll 4
+    for (int ch = 0; ch < C; ++ch) {
+      const float* xcp = xb + (long)ch * plane;
+      const float g = gb[(long)ch * plane];
+      const float a = xcp[o_nw] * m_nw, bq = xcp[o_ne] * m_ne, cq = xcp[o_sw] * m_sw, dq = xcp[o_se] * m_se;
+      gix += g * ((bq - a) * t.s + (dq - cq) * t.n);
+      giy += g * ((cq - a) * t.e + (dq - bq) * t.w);
+    }
+  }
+  gf[p] = gix * (0.5f * (float)(W - 1)) * (2.f / den_w / div_flow);
+  gf[plane + p] = giy * (0.5f * (float)(H - 1)) * (2.f / den_h / div_flow);
 }
 
 }  // namespace
@@ -226,7 +407,52 @@ extern "C" int irr_warp_bwd_f32(const float* x, const float* flow, const float* 
   dim3 grid(irr_cdiv(W, 32), irr_cdiv(H, 8), B);
   const float den_w = (float)(width_im - 1 > 1 ? width_im - 1 : 1), den_h = (float)(height_im - 1 > 1 ? height_im - 1 : 1);
   hipLaunchKernelGGL(warp_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, flow, gridx, gridy, gout, gx, gflow, C,
-                     H, W, x_bs, flow_bs, gout_bs, gx_bs, gflow_bs, den_w, den_h, div_flow, mask_thr, swap_halves ? B / 2 : 0);
+                     H, W, x_bs, flow_bs, gout_bs, gx_bs, gflow_bs, den_w, den_h, div_flow, mask_thr, swap_halves ? B / 2 : 0,
+                     (const int*)nullptr);
   IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+// workspace (ints) of irr_warp_bwd_gather_f32: one margin per sample
+extern "C" long irr_warp_bwd_ws_elems(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return IRR_EINVAL;
+  return (long)((B + 3) / 4 * 4);
+}
+
+// Same contract as irr_warp_bwd_f32; the gradient w.r.t. x is gathered per owned pixel (no atomics, no zero fill) for every
+// sample whose bilinear targets stay within GMAX = 8 pixels of their output pixel (per axis), and falls back to the atomic
+// scatter per SAMPLE otherwise (decided on the device).  ws: irr_warp_bwd_ws_elems(B, H, W) ints, any contents.
+extern "C" int irr_warp_bwd_gather_f32(const float* x, const float* flow, const float* gridx, const float* gridy,
+                                       const float* gout, float* gx, float* gflow, int B, int C, int H, int W, long x_bs,
+                                       long flow_bs, long gout_bs, long gx_bs, long gflow_bs, int height_im, int width_im,
+                                       float div_flow, float mask_thr, int swap_halves, int* ws, long ws_elems, void* stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !x || !flow || !gridx || !gridy || !gout || B > 65535) return IRR_EINVAL;
+  if (swap_halves && (B & 1)) return IRR_EINVAL;
+  if (!gx && !gflow) return 0;
+  const float den_w = (float)(width_im - 1 > 1 ? width_im - 1 : 1), den_h = (float)(height_im - 1 > 1 ? height_im - 1 : 1);
+  dim3 grid(irr_cdiv(W, 32), irr_cdiv(H, 8), B);
+  const long plane = (long)H * W;
+  if (gx) {
+    if (!ws || ws_elems < irr_warp_bwd_ws_elems(B, H, W)) return IRR_EINVAL;
+    IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(int) * (size_t)B, (hipStream_t)stream));
+    hipLaunchKernelGGL(warp_margin_kernel, dim3(irr_cdiv(plane, 256), 1, B), dim3(256), 0, (hipStream_t)stream, flow, gridx, gridy, ws,
+                       H, W, flow_bs, den_w, den_h, div_flow, mask_thr);
+    IRR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(warp_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, flow, gridx, gridy, gout, gx,
+                       (const int*)ws, C, H, W, flow_bs, gout_bs, gx_bs, den_w, den_h, div_flow, mask_thr,
+                       swap_halves ? B / 2 : 0);
+    IRR_LAUNCH_CHECK();
+    // samples whose targets left the gather window: the device-scope atomic scatter (exits at once for all the others)
+    hipLaunchKernelGGL(warp_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, flow, gridx, gridy, gout, gx, (float*)nullptr, C,
+                       H, W, x_bs, flow_bs, gout_bs, gx_bs, gflow_bs, den_w, den_h, div_flow, mask_thr, swap_halves ? B / 2 : 0,
+                       (const int*)ws);
+    IRR_LAUNCH_CHECK();
+  }
+  if (gflow) {
+    hipLaunchKernelGGL(warp_gflow_kernel, dim3(irr_cdiv(plane, 256), 1, B), dim3(256), 0, (hipStream_t)stream, x, flow, gridx, gridy,
+                       gout, gflow, C, H, W, x_bs, flow_bs, gout_bs, gflow_bs, den_w, den_h, div_flow, mask_thr,
+                       swap_halves ? B / 2 : 0);
+    IRR_LAUNCH_CHECK();
+  }
   return 0;
 }

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from . import hip
@@ -99,6 +101,9 @@ def compute_cost_volume(feat1, feat2, param_dict):
 # ----------------------------------------------------------------------------------------------
 # warp
 # ----------------------------------------------------------------------------------------------
+_WARP_BWD_ATOMIC = os.environ.get("IRR_WARP_BWD_ATOMIC", "0") != "0"      # A/B switch: the device-scope atomic scatter everywhere
+
+
 class _Warp(hip.Function):
     @staticmethod
     def forward(ctx, x, flow, height_im: int, width_im: int, div_flow: float, mask_thr: float, swap: bool = False):
@@ -122,10 +127,18 @@ class _Warp(hip.Function):
         gxg, gyg = _linspace_dev(W, x.device), _linspace_dev(H, x.device)
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gf = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
-        hip.call("irr_warp_bwd_f32", hip.ptr(x), hip.ptr(flow), hip.ptr(gxg), hip.ptr(gyg), hip.ptr(gout),
-                 hip.ptr(gx), hip.ptr(gf), B, C, H, W, hip.bs(x), hip.bs(flow), hip.bs(gout),
-                 hip.bs(gx) if gx is not None else 0, hip.bs(gf) if gf is not None else 0,
-                 height_im, width_im, div_flow, mask_thr, int(swap), hip.stream())
+        if not _WARP_BWD_ATOMIC:
+            # owner-computes gradient w.r.t. x (csrc/warp.hip): no device-scope atomics; per-sample fallback inside the call
+            ws = torch.empty(hip.lib().irr_warp_bwd_ws_elems(B, H, W), device=x.device, dtype=torch.int32) if gx is not None else None
+            hip.call("irr_warp_bwd_gather_f32", hip.ptr(x), hip.ptr(flow), hip.ptr(gxg), hip.ptr(gyg), hip.ptr(gout),
+                     hip.ptr(gx), hip.ptr(gf), B, C, H, W, hip.bs(x), hip.bs(flow), hip.bs(gout),
+                     hip.bs(gx) if gx is not None else 0, hip.bs(gf) if gf is not None else 0,
+                     height_im, width_im, div_flow, mask_thr, int(swap), hip.ptr(ws), ws.numel() if ws is not None else 0, hip.stream())
+        else:
+            hip.call("irr_warp_bwd_f32", hip.ptr(x), hip.ptr(flow), hip.ptr(gxg), hip.ptr(gyg), hip.ptr(gout),
+                     hip.ptr(gx), hip.ptr(gf), B, C, H, W, hip.bs(x), hip.bs(flow), hip.bs(gout),
+                     hip.bs(gx) if gx is not None else 0, hip.bs(gf) if gf is not None else 0,
+                     height_im, width_im, div_flow, mask_thr, int(swap), hip.stream())
         return gx, gf, None, None, None, None, None
 
 

@@ -120,6 +120,53 @@ def test_warp_full_size_properties():
     assert torch.allclose(2 * a, b, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(4, 32, 96, 112), (2, 35, 45, 70), (4, 3, 24, 28), (2, 2, 6, 7)])
+@pytest.mark.parametrize("swap", [False, True])
+def test_warp_gradient_owner_computes_equals_atomic_scatter(shape, swap):
+    """irr_warp_bwd_gather_f32 (every 8x32 tile of the image gradient gathered by its owning block, LDS accumulation, plain
+    stores) against the device-scope atomic scatter of irr_warp_bwd_f32 and against an fp64 autograd restatement of the sampler:
+    smooth flows (fast path everywhere), a batch in which ONE sample carries flows of +-40 px at that level (its targets leave the
+    gather window: that sample alone takes the atomic fallback, decided on the device), sizes that are not multiples of the tile,
+    C > 32 (two accumulator passes), and the swapped-halves form the model uses."""
+    import torch.nn.functional as F
+    from irr_amd import functional as Fn
+    B, C, H, W = shape
+    torch.manual_seed(4)
+    x = torch.randn(B, C, H, W, device="cuda")
+    go = torch.randn(B, C, H, W, device="cuda")
+    for wild in ("smooth", "rough", "wild"):
+        fl = torch.randn(B, 2, H, W, device="cuda") * 0.05 * 1.5              # (flow is in div_flow * full-resolution px)
+        if wild == "rough":
+            # independent uniform flows of +-6 px per pixel at this level: every gather window up to the largest is used, and
+            # many pixels have more than four contributors (further rounds of the owner's loop)
+            fl = (torch.rand(B, 2, H, W, device="cuda") * 2 - 1) * 0.05 * 4 * 6.0
+        if wild == "wild":
+            fl[1] = torch.randn(2, H, W, device="cuda") * 0.05 * 160.0        # ~ +-40 px at a quarter-resolution level
+        res = {}
+        for atomic in (True, False):
+            Fn._WARP_BWD_ATOMIC = atomic
+            try:
+                xr, fr = x.clone().requires_grad_(True), fl.clone().requires_grad_(True)
+                Fn.warp(xr, fr, 4 * H, 4 * W, 0.05, 0.9999, swap).backward(go)
+                res[atomic] = (xr.grad.clone(), fr.grad.clone())
+            finally:
+                Fn._WARP_BWD_ATOMIC = False
+        fscale = res[True][1].abs().max().item()                                 # (flow gradient: a lanes-along-x kernel of its own)
+        assert (res[True][1] - res[False][1]).abs().max().item() <= 2e-5 * fscale + 1e-6, (wild, shape)
+        scale = res[True][0].abs().max().item()
+        assert (res[True][0] - res[False][0]).abs().max().item() <= 2e-6 * scale + 1e-6, (wild, shape)
+        # fp64 restatement: bilinear zero-padded sampling, align_corners=True (models/pwc_modules.py:119-133)
+        xd = x.double().requires_grad_(True)
+        src = torch.roll(xd, B // 2, 0) if swap else xd                      # sample b reads x[(b + B/2) % B]
+        gxb = torch.linspace(-1, 1, W, device="cuda", dtype=torch.float64).view(1, 1, W).expand(B, H, W)
+        gyb = torch.linspace(-1, 1, H, device="cuda", dtype=torch.float64).view(1, H, 1).expand(B, H, W)
+        grid = torch.stack([gxb + fl[:, 0].double() * 2 / max(4 * W - 1, 1) / 0.05, gyb + fl[:, 1].double() * 2 / max(4 * H - 1, 1) / 0.05], 3)
+        with torch.no_grad():
+            m = Fn.warp(torch.ones(B, 1, H, W, device="cuda"), fl, 4 * H, 4 * W, 0.05, 0.9999)
+        (F.grid_sample(src, grid, align_corners=True) * m.double()).backward(go.double())
+        assert (xd.grad - res[False][0].double()).abs().max().item() <= 1e-5 * scale + 1e-6, (wild, shape)
+
+
 def test_cost_volume_full_size_properties():
     """level-4 shape at bs8: centre channel equals the channel-mean of f1*f2; shifted input shifts channels."""
     from irr_amd import functional as Fn

@@ -48,6 +48,9 @@ def run(graph):
 
 
 le, ge, pe = run(False)
+if os.environ.get("CONTROL"):                  # eager vs eager: what two runs of the SAME configuration differ by (atomics + Adam)
+    lc, gc, pc = run(False)
+    print(f"LANE={lane} {B}x{H}x{W}: parameters after {N} steps, eager vs eager (control): {(pc - pe).norm().item() / pe.norm().item():.3e}")
 lg, gg, pg = run(True)
 d = (pg - pe).norm().item() / pe.norm().item()
 print(f"LANE={lane} HOLD={os.environ.get('IRR_LANE_HOLD', '0')} SAME_STREAM={os.environ.get('IRR_GRAPH_SAME_STREAM', '0')} "

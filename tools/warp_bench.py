@@ -13,4 +13,9 @@ for C in (32, 3):
         tb = timeit(lambda: torch.autograd.grad(y, (x, fl), go, retain_graph=True), iters=10)
         tx = timeit(lambda: torch.autograd.grad(y, (x,), go, retain_graph=True), iters=10)
         tf = timeit(lambda: torch.autograd.grad(y, (fl,), go, retain_graph=True), iters=10)
-        print(f"warp backward C={C:2d} 96x112x64, flow noise {amp}: both {tb*1e3:7.1f} us, image gradient only {tx*1e3:7.1f} us, flow gradient only {tf*1e3:7.1f} us")
+        Fn._WARP_BWD_ATOMIC = True                      # round 3's route: device-scope atomic scatter
+        ta = timeit(lambda: torch.autograd.grad(y, (x, fl), go, retain_graph=True), iters=10)
+        tax = timeit(lambda: torch.autograd.grad(y, (x,), go, retain_graph=True), iters=10)
+        Fn._WARP_BWD_ATOMIC = False
+        print(f"warp backward C={C:2d} 96x112x64, flow noise {amp}: both {tb*1e3:7.1f} us, image gradient only {tx*1e3:7.1f} us, flow gradient "
+              f"only {tf*1e3:7.1f} us | atomic scatter (IRR_WARP_BWD_ATOMIC=1): both {ta*1e3:7.1f} us, image gradient only {tax*1e3:7.1f} us")
