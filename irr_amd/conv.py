@@ -535,8 +535,6 @@ class WgradSide:
         # runtime.py:188-189) the first launch of a backward pass registers join() as a FINAL CALLBACK of that pass: it runs on
         # the thread that called backward(), on its current stream, once the whole graph has been executed.
         self._join_queued = False
-        # experiment switch (tools/graph_bisect.py): the inline lane keeps its operands alive until join(), as the asynchronous one does
-        self.hold = [] if (inline and os.environ.get("IRR_LANE_HOLD")) else None
 
     def _view(self, p_):
         hit = self.views.get(id(p_))
@@ -621,8 +619,6 @@ class WgradSide:
                 self.flush()
         if self.inline:
             fn()
-            if self.hold is not None:
-                self.hold += [t for t in tensors if t is not None]
             self._pending.append(params)
             if self.batch is None or not self.batch.n:
                 self.flush()
@@ -639,8 +635,6 @@ class WgradSide:
         self._join_queued = False               # (also after a backward pass that raised before its final callbacks ran)
         self.flush()
         if self.inline:
-            if self.hold is not None:
-                self.hold = []
             return
         torch.cuda.current_stream().wait_stream(self.stream)
         self._inflight.clear()                   # later work on the current stream is ordered after the lane

@@ -38,3 +38,25 @@ __device__ __forceinline__ unsigned irr_xcd_order(unsigned lin, unsigned total) 
   const unsigned per = total >> 3, rem = total & 7u, r = lin & 7u, q = lin >> 3;
   return r * per + (r < rem ? r : rem) + q;
 }
+
+// Zero fill of a caller-owned buffer on `stream` as a KERNEL, not hipMemsetAsync (round 4).  Under stream capture a memset becomes a
+// graph memset node, and replays of such graphs were observed to corrupt data (profiles/r4_graph_bisect.txt): a step captured
+// without the asynchronous weight-gradient lane -- where the caching allocator recycles blocks inside the capture, so the zero-filled
+// buffer is usually memory that an earlier kernel of the same graph has just read -- drifted by ~1e-2 over ten replays with the
+// memset in the warp backward and is exact with this kernel in its place.  (IRR_ZERO_MEMSET=1: hipMemsetAsync again, A/B.)
+__global__ __launch_bounds__(256) static void irr_zero_kernel(uint32_t* __restrict__ p, size_t n16, size_t nbytes) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  if (i < n16) ((u4*)p)[i] = u4{0u, 0u, 0u, 0u};
+  if (i == 0)
+    for (size_t k = n16 * 16; k < nbytes; ++k) ((unsigned char*)p)[k] = 0;
+}
+
+static inline hipError_t irr_zero_async(void* ptr, size_t nbytes, hipStream_t st) {
+  if (nbytes == 0) return hipSuccess;
+  if (IRR_ENV_FLAG("IRR_ZERO_MEMSET") || ((uintptr_t)ptr & 15)) return hipMemsetAsync(ptr, 0, nbytes, st);
+  const size_t n16 = nbytes / 16;
+  const size_t blocks = n16 ? (n16 + 255) / 256 : 1;
+  hipLaunchKernelGGL(irr_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)ptr, n16, nbytes);
+  return hipGetLastError();
+}

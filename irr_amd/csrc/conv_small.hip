@@ -758,7 +758,7 @@ extern "C" int irr_conv2d_smallco_wgrad_f32(const float* x, const float* gy, flo
   if ((k != 1 && k != 3) || dil < 1 || B > 65535 || Cin > 65535) return IRR_EINVAL;
   const long n = (long)Cout * Cin * k * k;
   hipStream_t st = (hipStream_t)stream;
-  IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, st));
+  IRR_HIP_TRY(irr_zero_async(ws, sizeof(float) * (size_t)n, st));
   const long hw = (long)H * W;
   // enough blocks to fill the chip, at least 4 pixels per thread
   long chunks = (2048 + (long)Cin * B - 1) / ((long)Cin * B);
@@ -816,7 +816,7 @@ extern "C" int irr_conv2d_smallci_wgrad_f32(const float* x, const float* gy, flo
     return IRR_EINVAL;
   const long n = (long)Cout * Cin * 9;
   hipStream_t st = (hipStream_t)stream;
-  IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, st));
+  IRR_HIP_TRY(irr_zero_async(ws, sizeof(float) * (size_t)n, st));
   const long ohw = (long)OH * OW;
   long ppb = 256 * 32;                                       // 32 pixels per thread amortise the block reduction
   while (ppb > 256 * 4 && irr_cdiv(ohw, ppb) * irr_cdiv(Cout, 4) * B < 1024) ppb /= 2;

@@ -695,7 +695,7 @@ extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
   WgArgs a;
   const long n = (long)Cout * Cin * k * k;
   const bool atomic = IRR_ENV_FLAG("IRR_WGRAD_ATOMIC");           // A/B switch: the earlier atomic flush into one image
-  if (atomic) IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)n, (hipStream_t)stream));
+  if (atomic) IRR_HIP_TRY(irr_zero_async(ws, sizeof(float) * (size_t)n, (hipStream_t)stream));
   a.x = x; a.gy = gy; a.gw = ws; a.n = atomic ? 0 : n; a.gbias = gbias; a.alpha = alpha;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW;
   a.stride = stride; a.dil = dil; a.pad = ((k - 1) * dil) / 2;

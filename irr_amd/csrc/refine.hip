@@ -133,10 +133,10 @@ extern "C" int irr_refine_tail_bwd_f32(const float* f, const float* v, const flo
   if (gv) {
     const long plane = (long)H * W;
     if (gv_bs == (long)C * plane) {
-      IRR_HIP_TRY(hipMemsetAsync(gv, 0, sizeof(float) * (size_t)B * C * plane, (hipStream_t)stream));
+      IRR_HIP_TRY(irr_zero_async(gv, sizeof(float) * (size_t)B * C * plane, (hipStream_t)stream));
     } else {
       for (int b = 0; b < B; ++b)
-        IRR_HIP_TRY(hipMemsetAsync(gv + (long)b * gv_bs, 0, sizeof(float) * (size_t)C * plane, (hipStream_t)stream));
+        IRR_HIP_TRY(irr_zero_async(gv + (long)b * gv_bs, sizeof(float) * (size_t)C * plane, (hipStream_t)stream));
     }
   }
   dim3 grid(irr_cdiv((long)H * W, 256), 1, B);

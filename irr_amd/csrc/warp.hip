@@ -398,10 +398,10 @@ extern "C" int irr_warp_bwd_f32(const float* x, const float* flow, const float* 
   if (gx) {
     // gx is a scatter target: zero exactly the region this call owns (dense when gx_bs == C*plane)
     if (gx_bs == (long)C * plane) {
-      IRR_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)B * C * plane, (hipStream_t)stream));
+      IRR_HIP_TRY(irr_zero_async(gx, sizeof(float) * (size_t)B * C * plane, (hipStream_t)stream));
     } else {
       for (int b = 0; b < B; ++b)
-        IRR_HIP_TRY(hipMemsetAsync(gx + (long)b * gx_bs, 0, sizeof(float) * (size_t)C * plane, (hipStream_t)stream));
+        IRR_HIP_TRY(irr_zero_async(gx + (long)b * gx_bs, sizeof(float) * (size_t)C * plane, (hipStream_t)stream));
     }
   }
   dim3 grid(irr_cdiv(W, 32), irr_cdiv(H, 8), B);
@@ -434,7 +434,7 @@ extern "C" int irr_warp_bwd_gather_f32(const float* x, const float* flow, const 
   const long plane = (long)H * W;
   if (gx) {
     if (!ws || ws_elems < irr_warp_bwd_ws_elems(B, H, W)) return IRR_EINVAL;
-    IRR_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(int) * (size_t)B, (hipStream_t)stream));
+    IRR_HIP_TRY(irr_zero_async(ws, sizeof(int) * (size_t)B, (hipStream_t)stream));
     hipLaunchKernelGGL(warp_margin_kernel, dim3(irr_cdiv(plane, 256), 1, B), dim3(256), 0, (hipStream_t)stream, flow, gridx, gridy, ws,
                        H, W, flow_bs, den_w, den_h, div_flow, mask_thr);
     IRR_LAUNCH_CHECK();

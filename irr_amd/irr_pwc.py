@@ -80,6 +80,9 @@ def _split_halves(t: torch.Tensor):
     return t[:b], t[b:]
 
 
+_CORR_PREMASK = os.environ.get("IRR_CORR_NO_PREMASK") is None     # A/B switch: the cost-volume gradient kernels apply LeakyReLU' themselves
+
+
 class PWCNet(nn.Module):
     def __init__(self, args, div_flow=0.05, mask_threshold: float = 1.0):
         super().__init__()
@@ -178,7 +181,7 @@ class PWCNet(nn.Module):
                     xo_warp = warp_other(x, flow)
                 # cost volume + LeakyReLU fused; its only consumers are the two estimators below, which hand back the gradient
                 # already multiplied by LeakyReLU' (PRE = 81 channels): the gradient kernels never read the 81-plane output
-                corr = Fn.cost_volume(x, xo_warp, lrelu=True, grad_is_preactivation=True)
+                corr = Fn.cost_volume(x, xo_warp, lrelu=True, grad_is_preactivation=_CORR_PREMASK)
 
                 x_1by1 = self.conv_1x1[l](x) if l != self.output_level else x
 
@@ -188,7 +191,7 @@ class PWCNet(nn.Module):
                 flow = flow * t_loc
 
                 # estimator + "est = flow + res" + cat([x_intm, est]) in one cat-free node (conv.dense_estimator)
-                ctx_in, flow_est = self.flow_estimators.forward_residual((corr, x_1by1, flow), flow, self.dim_corr)
+                ctx_in, flow_est = self.flow_estimators.forward_residual((corr, x_1by1, flow), flow, self.dim_corr if _CORR_PREMASK else 0)
                 flow_cont = self.context_networks(ctx_in, res=flow_est)
 
                 # The occlusion decoder + context network are independent of the flow branch until refine_occ: with
@@ -199,14 +202,14 @@ class PWCNet(nn.Module):
                     main = torch.cuda.current_stream()
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        ctx_in_o, occ_est = self.occ_estimators.forward_residual(occ_in, occ, self.dim_corr)
+                        ctx_in_o, occ_est = self.occ_estimators.forward_residual(occ_in, occ, self.dim_corr if _CORR_PREMASK else 0)
                         occ_cont = self.occ_context_networks(ctx_in_o, res=occ_est)
                     for t_ in occ_in:
                         t_.record_stream(side)
                     occ.record_stream(side)
                     pending_join = (main, side, occ_cont)
                 else:
-                    ctx_in_o, occ_est = self.occ_estimators.forward_residual(occ_in, occ, self.dim_corr)
+                    ctx_in_o, occ_est = self.occ_estimators.forward_residual(occ_in, occ, self.dim_corr if _CORR_PREMASK else 0)
                     occ_cont = self.occ_context_networks(ctx_in_o, res=occ_est)
                     pending_join = None
 

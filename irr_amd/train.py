@@ -11,7 +11,6 @@ the GPU pipeline between forward and backward)
 from __future__ import annotations
 
 import math
-import os
 from typing import Dict, Optional
 
 import torch
@@ -112,6 +111,12 @@ class GraphedTrainStep:
     its step count on the device (``FusedAdam(capturable=True)``); nothing inside the step reads device data on the host --
     the reference's per-step NaN assertion (runtime.py:182-183) is evaluated on the captured loss right after the replay.
     Data-parallel runs (world > 1) use the eager ``TrainStep``: the gradient all-reduce is not captured.
+    Any weight-gradient routing works (asynchronous lane, same-stream ``enable_direct_wgrad``, plain autograd).  Round 3 had found
+    replays captured WITHOUT the lane drifting (~1e-2 over ten steps) or producing NaN and refused them; round 4 traced it to
+    ``hipMemsetAsync`` inside the capture (the zero fill of the warp backward's scatter target): as a graph memset node it was not
+    ordered against the kernel that had just read the recycled allocation -- the lane merely kept every tensor alive until the end
+    of backward, so nothing was recycled.  The library now zero-fills with a kernel (csrc/common.h: irr_zero_async;
+    profiles/r4_graph_bisect.txt), and tests/test_train_gpu.py replays all three routings against eager steps.
 
     The optimizer's hyper-parameters (lr, betas, eps, weight decay) are kernel ARGUMENTS of the captured launch: after changing
     one of them (the reference trains with MultiStepLR, scripts/IRR-PWC_flyingChairsOcc.sh) the next call re-captures
@@ -124,13 +129,6 @@ class GraphedTrainStep:
                              "(use TrainStep with GradArena.sync)")
         if getattr(step.optimizer, "capturable", False) is not True:
             raise ValueError("GraphedTrainStep needs an optimizer whose step count lives on the device (FusedAdam(capturable=True))")
-        side = _conv.SIDE
-        if (side is None or getattr(side, "inline", False)) and not os.environ.get("IRR_GRAPH_ALLOW_NO_LANE"):
-            # Measured in round 3 (tools/graph_step.py, LANE=none / LANE=direct): replays of a step captured WITHOUT the lane drift
-            # or produce NaN -- with the lane, every tensor a weight-gradient launch reads stays alive until the join at the end of
-            # backward; without it the capture-time allocator recycles them inside the graph and some reuse is not covered by the
-            # captured order.  Until that is understood the graphed step is only offered in the configuration the tests pin.
-            raise ValueError("GraphedTrainStep needs the asynchronous weight-gradient lane (GradArena.enable_async_wgrad())")
         if warmup < 2:
             # step 1 builds the packed weights one by one, step 2 builds the job table of the batched pack launch (a pageable
             # host-to-device copy): neither may happen inside the capture
@@ -159,8 +157,7 @@ class GraphedTrainStep:
         self.step.optimizer.restore(snap)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        kw = {"stream": side} if os.environ.get("IRR_GRAPH_SAME_STREAM") else {}      # (experiment switch, tools/graph_bisect.py)
-        with torch.cuda.graph(self.graph, **kw):      # (records the step; nothing executes until replay())
+        with torch.cuda.graph(self.graph):            # (records the step; nothing executes until replay())
             self.result = eager(self.static_in)
 
     def __call__(self, example_dict: Dict[str, torch.Tensor]):

@@ -164,7 +164,8 @@ def test_warp_gradient_owner_computes_equals_atomic_scatter(shape, swap):
         with torch.no_grad():
             m = Fn.warp(torch.ones(B, 1, H, W, device="cuda"), fl, 4 * H, 4 * W, 0.05, 0.9999)
         (F.grid_sample(src, grid, align_corners=True) * m.double()).backward(go.double())
-        assert (xd.grad - res[False][0].double()).abs().max().item() <= 1e-5 * scale + 1e-6, (wild, shape)
+        # (sampling coordinates of +-40 px carry an fp32 rounding of ~1e-5 px into the bilinear weights)
+        assert (xd.grad - res[False][0].double()).abs().max().item() <= (1e-5 if wild == "smooth" else 1e-4) * scale + 1e-6, (wild, shape)
 
 
 def test_cost_volume_full_size_properties():

@@ -1,7 +1,11 @@
 """Root-causing the drift / NaN of hipGraph replays captured WITHOUT the asynchronous weight-gradient lane.
 Runs the SAME N steps (same batches) eagerly and as replays for one configuration and prints the parameter difference:
 
-    LANE=none|direct|async  [IRR_LANE_HOLD=1] [IRR_GRAPH_SAME_STREAM=1]  python tools/graph_bisect.py [B H W]
+    LANE=none|direct|async [CONTROL=1] [IRR_WARP_BWD_ATOMIC=1] [IRR_ZERO_MEMSET=1]  python tools/graph_bisect.py [B H W]
+
+CONTROL=1 also runs the eager steps twice (what two runs of the SAME configuration differ by: atomics + Adam's sign amplification).
+Result (profiles/r4_graph_bisect.txt): the drift needs BOTH the atomic warp backward (IRR_WARP_BWD_ATOMIC=1) and its zero fill as
+hipMemsetAsync (IRR_ZERO_MEMSET=1) -- a graph memset node is not ordered against the kernels around it.
 """
 import os
 import sys
@@ -10,7 +14,6 @@ import types
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("IRR_GRAPH_ALLOW_NO_LANE", "1")
 import bench  # noqa: E402
 import irr_amd  # noqa: E402
 from irr_amd import ddp  # noqa: E402
@@ -53,7 +56,7 @@ if os.environ.get("CONTROL"):                  # eager vs eager: what two runs o
     print(f"LANE={lane} {B}x{H}x{W}: parameters after {N} steps, eager vs eager (control): {(pc - pe).norm().item() / pe.norm().item():.3e}")
 lg, gg, pg = run(True)
 d = (pg - pe).norm().item() / pe.norm().item()
-print(f"LANE={lane} HOLD={os.environ.get('IRR_LANE_HOLD', '0')} SAME_STREAM={os.environ.get('IRR_GRAPH_SAME_STREAM', '0')} "
+print(f"LANE={lane} WARP_BWD_ATOMIC={os.environ.get('IRR_WARP_BWD_ATOMIC', '0')} ZERO_MEMSET={os.environ.get('IRR_ZERO_MEMSET', '0')} "
       f"{B}x{H}x{W}: parameters after {N} steps, replay vs eager: {d:.3e}")
 print("  eager  losses", [f"{v:.5f}" for v in le], "grad norms", [f"{v:.4f}" for v in ge])
 print("  replay losses", [f"{v:.5f}" for v in lg], "grad norms", [f"{v:.4f}" for v in gg], flush=True)
