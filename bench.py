@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick-cpu-baseline", action="store_true", help="one CPU leg (batch 2) instead of three")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--timer-every", type=int, default=4,
+                    help="per-launch HIP events (roofline object) on every N-th step of the timed region, starting with its first "
+                         "(an event pair per launch costs ~8 us of kernel overlap: 1.6 %% of a step when every step is instrumented)")
     ap.add_argument("--no-async-wgrad", action="store_true", help="keep weight gradients on the main stream")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 448x1024 leg after the headline timing")
     ap.add_argument("--harness", choices=["own", "reference"], default="own",
@@ -284,6 +287,8 @@ def main():
         t0 = time.perf_counter()
         for i in range(steps):
             mark()
+            if timer is not None:
+                timer.begin_step(i % max(1, a.timer_every) == 0)
             ld, _, _ = step(batches[(warmup + i) % NBATCHES])
         mark()
         barrier()
@@ -312,7 +317,7 @@ def main():
             spread = {"per_rank_ms_per_step": [round(t / steps * 1e3, 3) for t in per_rank]}
         res = {"dt": dt, "value": batch_pairs * world * steps / dt, "routing": routing, "spread": spread,
                "loss": {k: float(v.detach()) for k, v in ld.items()},
-               "roofline": roofline(timer, steps, height, width, batch_pairs) if (timer is not None and rank == 0) else None}
+               "roofline": roofline(timer, timer.steps, height, width, batch_pairs) if (timer is not None and rank == 0) else None}
         del batches, step
         return res
 
@@ -334,6 +339,9 @@ def main():
                 "launches": st["calls"], "avg_launch_us": round(st["seconds"] / st["calls"] * 1e6, 2),
                 "flop_per_launch": st["flops"] / st["calls"],
                 "concurrent_lanes": 1 if a.no_async_wgrad else 2,
+                "timed_steps": steps,
+                "timing": f"HIP events on the launch stream around every conv launch of {steps} steps of the timed region (every "
+                          f"{max(1, a.timer_every)}-th step, starting with the first)",
                 "note": ("durations include time-sharing the chip with the asynchronous weight-gradient lane "
                          "(second HIP stream) during backward; 'exclusive' = the forward-pass launches of the same "
                          "kernel, which run alone") if not a.no_async_wgrad else "single stream",

@@ -86,8 +86,8 @@ int irr_warp_bwd_f32(const float* x, const float* flow, const float* gridx, cons
 
 /* The same gradients with the gradient w.r.t. x computed OWNER-COMPUTES (round 4): every pixel of gx is gathered by the thread
  * that owns it from the output pixels whose bilinear targets include it (4-tap gather like the forward pass: no atomics, no zero
- * fill), and the gradient w.r.t. the flow by a kernel with lanes along x.  Valid while every bilinear target stays within 8 pixels
- * (per axis) of its output pixel; a SAMPLE that violates this is detected on the device and takes the atomic scatter of
+ * fill), and the gradient w.r.t. the flow by a kernel with lanes along x.  Valid while every bilinear target stays within 16 pixels
+ * (per axis) of its output pixel and no pixel of gx has more than 24 contributors; a SAMPLE that violates this is detected on the device and takes the atomic scatter of
  * irr_warp_bwd_f32 inside the same call.  ws: caller-owned scratch of irr_warp_bwd_ws_elems(B, H, W) ints (any contents; only
  * needed when gx != NULL). */
 long irr_warp_bwd_ws_elems(int B, int H, int W);
@@ -278,6 +278,12 @@ int irr_conv2d_smallci_wgrad_f32(const float* x, const float* gy, float* gw, flo
 int irr_conv2d_smallco_dgrad_f32(const float* gy, const float* w, float* gx, const float* mask,
                                  int B, int Cin, int H, int W, int Cout, int dil,
                                  long gy_bs, long gx_bs, long mask_bs, int nmask, int accumulate, void* stream);
+/* Both forms of the same data gradient from one pass (Cout = 1, dilation 1, W % 4 == 0, batch strides multiples of 4; IRR_EINVAL
+ * otherwise): gx_raw = conv_transpose(gy, w) and gx = gx_raw * LeakyReLU'(mask) over all Cin channels.  OccUpsampleNetwork's backward
+ * (models/irr_modules.py:54-55: x = x_init + res_end_conv(x); out_convs(x)) needs the gradient of that sum raw (skip) and masked. */
+int irr_conv2d_smallco_dgrad_dual_f32(const float* gy, const float* w, float* gx, float* gx_raw, const float* mask,
+                                      int B, int Cin, int H, int W, int Cout,
+                                      long gy_bs, long gx_bs, long raw_bs, long mask_bs, void* stream);
 
 
 /* gpre = gy * (y>0 ? 1 : 0.1) (if lrelu) ; gbias[co] += sum gpre (gbias nullable, accumulated).

@@ -528,11 +528,15 @@ __global__ __launch_bounds__(256) void conv_smallco_dgrad_kernel(const float* __
 // Quad version (dilation 1, W % 4 == 0): a thread owns four adjacent pixels, keeps their 3 x 6 gy neighbourhood in
 // registers and streams over the channels in batches of four: the read-modify-write operands of a batch (16-B buffer
 // loads, out-of-range voffset for channels past the end) are all in flight before the first store.
-template <int NC>
+// DUAL: the value BEFORE the LeakyReLU' mask is stored as well (gx_raw, same shape): OccUpsampleNetwork's backward needs the
+// gradient of x2 = x_init + e both raw (the skip into x_init) and masked by e (into res_end_conv) -- one pass instead of this
+// launch + an elementwise pass over two 32-channel full-resolution maps.
+template <int NC, bool DUAL = false>
 __global__ __launch_bounds__(256) void conv_smallco_dgrad4_kernel(const float* __restrict__ gy, const float* __restrict__ w,
                                                                  float* __restrict__ gx, const float* __restrict__ mask, int Cin,
                                                                  int H, int W, long gy_bs, long gx_bs, long mask_bs, int nmask,
-                                                                 int accumulate, int ci_per_block) {
+                                                                 int accumulate, int ci_per_block, float* __restrict__ gx_raw = nullptr,
+                                                                 long raw_bs = 0) {
   constexpr int U = 4;
   const long hw = (long)H * W;
   const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -553,6 +557,8 @@ __global__ __launch_bounds__(256) void conv_smallco_dgrad4_kernel(const float* _
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(gx + (long)b * gx_bs), (short)0, (int)SOOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t mr =
       __builtin_amdgcn_make_buffer_rsrc((void*)(mask ? mask + (long)b * mask_bs : gx), (short)0, (int)SOOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? gx_raw + (long)b * raw_bs : gx), (short)0, (int)SOOB, 0x00020000);
   const uint32_t vp = qok ? (uint32_t)(p * 4) : SOOB;
   const uint32_t hw4 = (uint32_t)(hw * 4);
   const int nm = mask ? nmask : 0;
@@ -580,6 +586,9 @@ __global__ __launch_bounds__(256) void conv_smallco_dgrad4_kernel(const float* _
             for (int i = 0; i < 4; ++i) v[i] = fmaf(ww, gp[c][2 - a][i + 2 - t], v[i]);
           }
       }
+      if (DUAL)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), rr,
+                                               (int)(ci + u < c1 ? vp : SOOB), (int)((uint32_t)(ci + u) * hw4), 0);
       if (ci + u < nm) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] *= irr_lrelu_grad(mk[u][i]);
@@ -697,6 +706,27 @@ extern "C" int irr_conv2d_smallco_dgrad_f32(const float* gy, const float* w, flo
   else
     hipLaunchKernelGGL((conv_smallco_dgrad_kernel<2>), grid, dim3(256), 0, st, gy, w, gx, mask, Cin, H, W, dil, gy_bs, gx_bs, mask_bs,
                        nmask, accumulate, cpb);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+// gx = LeakyReLU'(mask) * conv_transpose(gy, w) and gx_raw = conv_transpose(gy, w) from ONE pass (Cout = 1, dilation 1, W % 4 == 0,
+// batch strides multiples of 4: the quad kernel); IRR_EINVAL otherwise -- the caller then runs irr_conv2d_smallco_dgrad_f32 +
+// irr_lrelu_bwd_bias_f32.
+extern "C" int irr_conv2d_smallco_dgrad_dual_f32(const float* gy, const float* w, float* gx, float* gx_raw, const float* mask, int B,
+                                                 int Cin, int H, int W, int Cout, long gy_bs, long gx_bs, long raw_bs, long mask_bs,
+                                                 void* stream) {
+  if (!gy || !w || !gx || !gx_raw || !mask || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout != 1 || B > 65535) return IRR_EINVAL;
+  if ((W & 3) || ((gy_bs | gx_bs | raw_bs | mask_bs) & 3)) return IRR_EINVAL;
+  const long hw = (long)H * W;
+  const int qblocks = irr_cdiv(hw / 4, 256);
+  int split4 = (int)((2048 + (long)qblocks * B - 1) / ((long)qblocks * B));
+  if (split4 < 1) split4 = 1;
+  if (split4 > Cin) split4 = Cin;
+  const int cpb4 = ((Cin + split4 - 1) / split4 + 3) / 4 * 4;
+  dim3 grid4(qblocks, irr_cdiv(Cin, cpb4), B);
+  hipLaunchKernelGGL((conv_smallco_dgrad4_kernel<1, true>), grid4, dim3(256), 0, (hipStream_t)stream, gy, w, gx, mask, Cin, H, W, gy_bs,
+                     gx_bs, mask_bs, Cin, 0, cpb4, gx_raw, raw_bs);
   IRR_LAUNCH_CHECK();
   return 0;
 }

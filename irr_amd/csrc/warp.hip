@@ -14,8 +14,6 @@
 
 namespace {
 
-#define GMAX_HOST 8     // == GMAX of the owner-computes gather below (samples with a larger margin take the atomic scatter)
-
 struct Taps {
   int x0, y0;
   float nw, ne, sw, se;     // weights (already zeroed for out-of-bounds taps? no: raw weights)
@@ -66,6 +64,19 @@ __device__ __forceinline__ Taps make_taps(float fu, float fv, float gxb, float g
   return t;
 }
 
+// (owner-computes backward, see below)
+#define GMAX 16         // largest per-sample margin the gather handles
+#define GK 4            // contributors per round of the channel loop
+#define GKMAX 24        // list slots per owned pixel (a pixel has 4 contributors on average)
+#define GMS 32          // margin slots per sample (the sample's margin is their maximum)
+
+__device__ __forceinline__ int sample_margin(const int* __restrict__ margin, int b) {
+  int m = 0;
+#pragma unroll
+  for (int k = 0; k < GMS; ++k) m = max(m, margin[b * GMS + k]);
+  return m;
+}
+
 __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ flow,
                                                       const float* __restrict__ gridx, const float* __restrict__ gridy,
                                                       float* __restrict__ out, int C, int H, int W, long x_bs,
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
                                                       float* __restrict__ gflow, int C, int H, int W, long x_bs,
                                                       long flow_bs, long gout_bs, long gx_bs, long gflow_bs,
                                                       float den_w, float den_h, float div_flow, float mask_thr, int xshift,
-                                                      const int* __restrict__ gx_only_if) {
+                                                      const int* __restrict__ gx_only_if, const int* __restrict__ gx_flags) {
   const long plane = (long)H * W;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = lane & 15, r = lane >> 4;
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
   const float* xb = x + (long)bx * x_bs;
   const float* gb = gout + (long)b * gout_bs + pp;
   // gx_only_if (owner-computes route): the scatter only runs for the samples whose targets left the gather window
-  float* gxb = (gx && (!gx_only_if || gx_only_if[b] > GMAX_HOST)) ? gx + (long)bx * gx_bs : nullptr;
+  float* gxb = (gx && (!gx_only_if || gx_flags[b] != 0 || sample_margin(gx_only_if, b) > GMAX)) ? gx + (long)bx * gx_bs : nullptr;
   if (!gxb && !gflow) return;
   for (int ch = 0; ch < C; ++ch) {
     const float g = act ? gb[(long)ch * plane] : 0.f;
@@ -196,21 +207,19 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
 // The scatter above is bound by the DEVICE-SCOPE atomic rate (~23 G/s: 1.2 ms at 96x112x64x32 for 90 us worth of HBM traffic).
 // Here every pixel s of gx is OWNED by one thread, which gathers what the output pixels scatter into it:
 //   1. warp_margin_kernel: per sample the largest distance M_b (in pixels, per axis) between an output pixel and any of its
-//      bilinear targets (one atomicMax per block);
-//   2. warp_gather_kernel: a block owns an 8 x 32 tile of gx.  It stages (x0, y0, four effective weights) of the output pixels
-//      within M_b of the tile in LDS; a thread scans the (2 M_b + 1)^2 candidates around its pixel for those whose targets
-//      include it, keeps up to four (offset, weight) pairs -- exactly the four of a locally translating flow -- and runs the
-//      channel loop as a 4-tap gather like the forward pass: plain loads, plain stores, no atomics, no zero fill.  Pixels with
-//      more than four contributors (compressive flows) take further rounds of the same loop (read-modify-write of their OWN
-//      pixel).  Samples with M_b > GMAX are zero-filled instead and
-//   3. warp_bwd_kernel (above) adds their gradient with the device-scope atomics.
-// All decisions are taken on the device: nothing synchronises.  (A first version accumulated with LDS atomics per owned tile:
-// 0.59 ms at 96x112x64x32 -- ds_add_f32 retires a few lanes per cycle -- against 1.23 ms of the device-scope scatter.)
-#define GMAX 8          // largest per-sample margin the gather window supports ((8 + 16) x (32 + 16) candidates in LDS)
-#define GK 4            // contributors per round
-
-struct GCand { int x0, y0; float nw, ne, sw, se; };
-
+//      bilinear targets;
+//   2. warp_gather_kernel: a block owns an 8 x 32 tile of gx.  BINNING, once per block (not per channel): the threads walk the
+//      output pixels within M_b of the tile, compute their taps (same arithmetic as everywhere else) and append, for each of the
+//      four targets that lies in the tile, (offset of the output pixel, weight) to that target's list in LDS (an LDS integer
+//      atomic hands out the slot: <= GKMAX entries per pixel).  GATHER: a thread takes its pixel's list four entries at a time
+//      and runs the channel loop as a 4-tap gather like the forward pass -- plain loads and stores, no atomics on data, no zero
+//      fill; lists longer than four (compressive flows) take further rounds (read-modify-write of the OWN pixel).
+//      A sample with M_b > GMAX is left alone; a pixel with more than GKMAX contributors flags its SAMPLE; then
+//   3. warp_zero_flagged_kernel + warp_bwd_kernel (above): the flagged samples are zero-filled and take the device-scope atomic
+//      scatter.
+// All decisions are taken on the device: nothing synchronises.  (History of this round, 96x112x64x32, smooth flow: device-scope
+// scatter 1.23 ms; LDS float atomics per owned tile 0.59 ms -- ds_add_f32 retires a few lanes per cycle; per-pixel window scan
+// 0.05 ms, but (2 M + 1)^2 tests per pixel made it 0.76 ms on the noisy flows of a freshly initialised network.)
 __global__ __launch_bounds__(256) void warp_margin_kernel(const float* __restrict__ flow, const float* __restrict__ gridx,
                                                          const float* __restrict__ gridy, int* __restrict__ margin, int H, int W,
                                                          long flow_bs, float den_w, float den_h, float div_flow, float mask_thr) {
@@ -236,97 +245,103 @@ __global__ __launch_bounds__(256) void warp_margin_kernel(const float* __restric
   __syncthreads();
   if (threadIdx.x == 0) {
     m = max(max(red[0], red[1]), max(red[2], red[3]));
-    if (m > 0) atomicMax(margin + b, m);
+    // (hundreds of blocks per sample: GMS slots per sample spread the same-address atomics -- 53 -> 17 us at 192x224x64)
+    if (m > 0) atomicMax(margin + b * GMS + (blockIdx.x % GMS), m);
   }
 }
 
+// flags[b] (the second half of the workspace): 1 = some pixel of sample b overflowed its list -> the atomic route redoes the sample
 __global__ __launch_bounds__(256) void warp_gather_kernel(const float* __restrict__ flow, const float* __restrict__ gridx,
                                                          const float* __restrict__ gridy, const float* __restrict__ gout,
-                                                         float* __restrict__ gx, const int* __restrict__ margin, int C, int H,
-                                                         int W, long flow_bs, long gout_bs, long gx_bs, float den_w, float den_h,
-                                                         float div_flow, float mask_thr, int xshift) {
-  __shared__ GCand cand[(8 + 2 * GMAX) * (32 + 2 * GMAX)];
+                                                         float* __restrict__ gx, const int* __restrict__ margin,
+                                                         int* __restrict__ flags, int C, int H, int W, long flow_bs, long gout_bs,
+                                                         long gx_bs, float den_w, float den_h, float div_flow, float mask_thr,
+                                                         int xshift) {
+  __shared__ int cnt[256];
+  __shared__ int loff[GKMAX][256];
+  __shared__ float lwt[GKMAX][256];
   const long plane = (long)H * W;
   const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
   const int nb = gridDim.z;
   const int bs = blockIdx.z;                                           // the owned tile of gx belongs to sample bs
   const int b = (bs - xshift + nb) % nb;                               // the output sample that scatters into sample bs
+  const int M = sample_margin(margin, b);                              // (uniform)
+  if (M > GMAX) return;                                                // the atomic route handles this sample
   const int X0 = blockIdx.x * 32, Y0 = blockIdx.y * 8;
   const int ox = X0 + c, oy = Y0 + r;
   const bool own = ox < W && oy < H;
-  float* gdst = gx + (long)bs * gx_bs + (long)(own ? oy : 0) * W + (own ? ox : 0);
-  const int M = margin[b];                                             // (uniform)
-  if (M > GMAX) {                                                      // the atomic kernel handles this sample: zero fill
-    if (own)
-      for (int ch = 0; ch < C; ++ch) gdst[(long)ch * plane] = 0.f;
-    return;
-  }
-  // stage the candidates: output pixels [Y0 - M, Y0 + 7 + M] x [X0 - M, X0 + 31 + M]
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  // ---- binning: output pixels [Y0 - M, Y0 + 7 + M] x [X0 - M, X0 + 31 + M] ----
   const int RW = 32 + 2 * M, RH = 8 + 2 * M;
   const float* fl = flow + (long)b * flow_bs;
   for (int i = threadIdx.x; i < RW * RH; i += 256) {
     const int ry = i / RW, rx = i - ry * RW;
     const int yy = Y0 - M + ry, xx = X0 - M + rx;
-    GCand g;
-    g.x0 = g.y0 = -(1 << 30);
-    g.nw = g.ne = g.sw = g.se = 0.f;
-    if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
-      const long pp = (long)yy * W + xx;
-      const Taps t = make_taps(fl[pp], fl[plane + pp], gridx[xx], gridy[yy], H, W, den_w, den_h, div_flow, mask_thr);
-      if (t.mask != 0.f) {
-        g.x0 = t.x0; g.y0 = t.y0;
-        g.nw = t.in_nw ? t.nw : 0.f; g.ne = t.in_ne ? t.ne : 0.f; g.sw = t.in_sw ? t.sw : 0.f; g.se = t.in_se ? t.se : 0.f;
+    if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+    const long pp = (long)yy * W + xx;
+    const Taps t = make_taps(fl[pp], fl[plane + pp], gridx[xx], gridy[yy], H, W, den_w, den_h, div_flow, mask_thr);
+    if (t.mask == 0.f) continue;
+    const int lx = t.x0 - X0, ly = t.y0 - Y0;                          // nw target relative to the owned tile
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int tx = lx + (k & 1), ty = ly + (k >> 1);
+      const float w = k == 0 ? (t.in_nw ? t.nw : 0.f) : k == 1 ? (t.in_ne ? t.ne : 0.f) : k == 2 ? (t.in_sw ? t.sw : 0.f) : (t.in_se ? t.se : 0.f);
+      if (w == 0.f || (unsigned)tx >= 32u || (unsigned)ty >= 8u) continue;
+      const int ti = ty * 32 + tx;
+      const int slot = atomicAdd(&cnt[ti], 1);
+      if (slot < GKMAX) {
+        loff[slot][ti] = (int)pp;
+        lwt[slot][ti] = w;
       }
     }
-    cand[i] = g;
   }
   __syncthreads();
+  const int n_all = cnt[threadIdx.x];
+  if (__syncthreads_or(n_all > GKMAX)) {                               // (block-uniform) the atomic route redoes this sample
+    if (threadIdx.x == 0) atomicOr(flags + b, 1);
+    return;
+  }
+  if (!own) return;
+  const int n = n_all;
   const float* gb = gout + (long)b * gout_bs;
-  const long self = (long)(own ? oy : 0) * W + (own ? ox : 0);
-  const int nwin = (2 * M + 1) * (2 * M + 1);
-  int resume = 0;                                                      // first window index not consumed yet
-  bool first = true;
-  for (;;) {
-    // collect up to GK contributors among the window entries >= resume (the window of pixel (r, c) starts at cand[r][c])
-    long off[GK];
+  const int self = oy * W + ox;
+  float* gdst = gx + (long)bs * gx_bs + self;
+  // ---- gather: GK list entries per round ----
+  for (int k0 = 0; k0 == 0 || k0 < n; k0 += GK) {
+    int off[GK];
     float wt[GK];
 #pragma unroll
-    for (int k = 0; k < GK; ++k) { off[k] = self; wt[k] = 0.f; }
-    int cnt = 0, next = nwin;
-    if (own) {
-      int wi = 0;
-      for (int dy = 0; dy <= 2 * M; ++dy) {
-        for (int dx = 0; dx <= 2 * M; ++dx, ++wi) {
-          if (wi < resume) continue;
-          const GCand g = cand[(r + dy) * RW + c + dx];
-          const int ex = ox - g.x0, ey = oy - g.y0;                    // 0 or 1 when this pixel is one of the candidate's targets
-          if ((unsigned)ex > 1u || (unsigned)ey > 1u) continue;
-          const float w = ey ? (ex ? g.se : g.sw) : (ex ? g.ne : g.nw);
-          if (w == 0.f) continue;
-          if (cnt == GK) { next = min(next, wi); continue; }
-          const long po = (long)(oy - M + dy) * W + (ox - M + dx);
-          if (cnt == 0) { off[0] = po; wt[0] = w; }
-          else if (cnt == 1) { off[1] = po; wt[1] = w; }
-          else if (cnt == 2) { off[2] = po; wt[2] = w; }
-          else { off[3] = po; wt[3] = w; }
-          ++cnt;
-        }
-      }
+    for (int k = 0; k < GK; ++k) {
+      const bool ok = k0 + k < n;
+      off[k] = ok ? loff[k0 + k][threadIdx.x] : self;
+      wt[k] = ok ? lwt[k0 + k][threadIdx.x] : 0.f;
     }
-    const bool work = own && (first || cnt > 0);
-    if (work) {
+    if (k0 == 0) {
 #pragma unroll 4
       for (int ch = 0; ch < C; ++ch) {
         const float* gc = gb + (long)ch * plane;
-        float v = gc[off[0]] * wt[0] + gc[off[1]] * wt[1] + gc[off[2]] * wt[2] + gc[off[3]] * wt[3];
-        if (!first) v += gdst[(long)ch * plane];
-        gdst[(long)ch * plane] = v;
+        gdst[(long)ch * plane] = gc[off[0]] * wt[0] + gc[off[1]] * wt[1] + gc[off[2]] * wt[2] + gc[off[3]] * wt[3];
+      }
+    } else {
+#pragma unroll 4
+      for (int ch = 0; ch < C; ++ch) {
+        const float* gc = gb + (long)ch * plane;
+        gdst[(long)ch * plane] += gc[off[0]] * wt[0] + gc[off[1]] * wt[1] + gc[off[2]] * wt[2] + gc[off[3]] * wt[3];
       }
     }
-    first = false;
-    resume = next;
-    if (!__any(own && next < nwin)) break;
   }
+}
+
+// zero fill of the samples that take the atomic route (margin beyond the gather window, or a list overflow)
+__global__ __launch_bounds__(256) void warp_zero_flagged_kernel(float* __restrict__ gx, const int* __restrict__ margin,
+                                                               const int* __restrict__ flags, long n_per_sample, long gx_bs,
+                                                               int xshift) {
+  const int nb = gridDim.z, bs = blockIdx.z;
+  const int b = (bs - xshift + nb) % nb;
+  if (sample_margin(margin, b) <= GMAX && flags[b] == 0) return;
+  float* g = gx + (long)bs * gx_bs;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_sample; i += (long)gridDim.x * blockDim.x) g[i] = 0.f;
 }
 
 // gradient w.r.t. the flow alone (owner-computes route: the scatter kernel above spends its time in the 16 x 4 lane layout its
@@ -408,20 +423,20 @@ extern "C" int irr_warp_bwd_f32(const float* x, const float* flow, const float* 
   const float den_w = (float)(width_im - 1 > 1 ? width_im - 1 : 1), den_h = (float)(height_im - 1 > 1 ? height_im - 1 : 1);
   hipLaunchKernelGGL(warp_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, flow, gridx, gridy, gout, gx, gflow, C,
                      H, W, x_bs, flow_bs, gout_bs, gx_bs, gflow_bs, den_w, den_h, div_flow, mask_thr, swap_halves ? B / 2 : 0,
-                     (const int*)nullptr);
+                     (const int*)nullptr, (const int*)nullptr);
   IRR_LAUNCH_CHECK();
   return 0;
 }
 
-// workspace (ints) of irr_warp_bwd_gather_f32: one margin per sample
+// workspace (ints) of irr_warp_bwd_gather_f32: one margin and one overflow flag per sample
 extern "C" long irr_warp_bwd_ws_elems(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return IRR_EINVAL;
-  return (long)((B + 3) / 4 * 4);
+  return (long)B * 32 + ((B + 3) / 4 * 4);                   // GMS margin slots per sample + one overflow flag per sample
 }
 
 // Same contract as irr_warp_bwd_f32; the gradient w.r.t. x is gathered per owned pixel (no atomics, no zero fill) for every
-// sample whose bilinear targets stay within GMAX = 8 pixels of their output pixel (per axis), and falls back to the atomic
-// scatter per SAMPLE otherwise (decided on the device).  ws: irr_warp_bwd_ws_elems(B, H, W) ints, any contents.
+// sample whose bilinear targets stay within GMAX = 16 pixels of their output pixel (per axis) and whose pixels have at most 24
+// contributors each, and falls back to the atomic scatter per SAMPLE otherwise (decided on the device).  ws: irr_warp_bwd_ws_elems(B, H, W) ints, any contents.
 extern "C" int irr_warp_bwd_gather_f32(const float* x, const float* flow, const float* gridx, const float* gridy,
                                        const float* gout, float* gx, float* gflow, int B, int C, int H, int W, long x_bs,
                                        long flow_bs, long gout_bs, long gx_bs, long gflow_bs, int height_im, int width_im,
@@ -434,18 +449,27 @@ extern "C" int irr_warp_bwd_gather_f32(const float* x, const float* flow, const 
   const long plane = (long)H * W;
   if (gx) {
     if (!ws || ws_elems < irr_warp_bwd_ws_elems(B, H, W)) return IRR_EINVAL;
-    IRR_HIP_TRY(irr_zero_async(ws, sizeof(int) * (size_t)B, (hipStream_t)stream));
+    const int BP = (B + 3) / 4 * 4;
+    int* flags = ws + (long)B * GMS;
+    IRR_HIP_TRY(irr_zero_async(ws, sizeof(int) * ((size_t)B * GMS + BP), (hipStream_t)stream));
     hipLaunchKernelGGL(warp_margin_kernel, dim3(irr_cdiv(plane, 256), 1, B), dim3(256), 0, (hipStream_t)stream, flow, gridx, gridy, ws,
                        H, W, flow_bs, den_w, den_h, div_flow, mask_thr);
     IRR_LAUNCH_CHECK();
     hipLaunchKernelGGL(warp_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, flow, gridx, gridy, gout, gx,
-                       (const int*)ws, C, H, W, flow_bs, gout_bs, gx_bs, den_w, den_h, div_flow, mask_thr,
+                       (const int*)ws, flags, C, H, W, flow_bs, gout_bs, gx_bs, den_w, den_h, div_flow, mask_thr,
                        swap_halves ? B / 2 : 0);
     IRR_LAUNCH_CHECK();
-    // samples whose targets left the gather window: the device-scope atomic scatter (exits at once for all the others)
+    // samples whose targets left the gather window or overflowed a list: zero fill + the device-scope atomic scatter (both exit at
+    // once for all the other samples)
+    const long nps = (long)C * plane;
+    int zb = irr_cdiv(nps, 256 * 8);
+    if (zb > 1024) zb = 1024;
+    hipLaunchKernelGGL(warp_zero_flagged_kernel, dim3(zb, 1, B), dim3(256), 0, (hipStream_t)stream, gx, (const int*)ws,
+                       (const int*)flags, nps, gx_bs, swap_halves ? B / 2 : 0);
+    IRR_LAUNCH_CHECK();
     hipLaunchKernelGGL(warp_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, flow, gridx, gridy, gout, gx, (float*)nullptr, C,
                        H, W, x_bs, flow_bs, gout_bs, gx_bs, gflow_bs, den_w, den_h, div_flow, mask_thr, swap_halves ? B / 2 : 0,
-                       (const int*)ws);
+                       (const int*)ws, (const int*)flags);
     IRR_LAUNCH_CHECK();
   }
   if (gflow) {

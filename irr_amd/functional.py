@@ -102,6 +102,7 @@ def compute_cost_volume(feat1, feat2, param_dict):
 # warp
 # ----------------------------------------------------------------------------------------------
 _WARP_BWD_ATOMIC = os.environ.get("IRR_WARP_BWD_ATOMIC", "0") != "0"      # A/B switch: the device-scope atomic scatter everywhere
+_WARP_GATHER_MIN_C = int(os.environ.get("IRR_WARP_GATHER_MIN_C", "8"))     # fewer channels: atomic scatter (see _Warp.backward)
 
 
 class _Warp(hip.Function):
@@ -127,8 +128,11 @@ class _Warp(hip.Function):
         gxg, gyg = _linspace_dev(W, x.device), _linspace_dev(H, x.device)
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gf = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
-        if not _WARP_BWD_ATOMIC:
-            # owner-computes gradient w.r.t. x (csrc/warp.hip): no device-scope atomics; per-sample fallback inside the call
+        # Owner-computes gradient w.r.t. x (csrc/warp.hip: no device-scope atomics; per-sample fallback inside the call) for the
+        # feature warps.  Its per-tile binning is paid once per block whatever C is, so the 2- and 3-channel warps (flow, image)
+        # keep the one-pass atomic scatter: measured per dispatch in a BASELINE step (noisy flows of a fresh network), 384x448 x 64:
+        # C = 3 / 2 gather route 0.68 / 0.58 ms vs atomic 0.49 / 0.33 ms; 192x224 C = 16: 0.39 vs 0.68 ms; 96x112 C = 32: 0.25 vs 0.40.
+        if not _WARP_BWD_ATOMIC and (gx is None or C >= _WARP_GATHER_MIN_C):
             ws = torch.empty(hip.lib().irr_warp_bwd_ws_elems(B, H, W), device=x.device, dtype=torch.int32) if gx is not None else None
             hip.call("irr_warp_bwd_gather_f32", hip.ptr(x), hip.ptr(flow), hip.ptr(gxg), hip.ptr(gyg), hip.ptr(gout),
                      hip.ptr(gx), hip.ptr(gf), B, C, H, W, hip.bs(x), hip.bs(flow), hip.bs(gout),

@@ -134,23 +134,32 @@ def test_warp_gradient_owner_computes_equals_atomic_scatter(shape, swap):
     torch.manual_seed(4)
     x = torch.randn(B, C, H, W, device="cuda")
     go = torch.randn(B, C, H, W, device="cuda")
-    for wild in ("smooth", "rough", "wild"):
+    for wild in ("smooth", "rough", "collapse", "wild"):
         fl = torch.randn(B, 2, H, W, device="cuda") * 0.05 * 1.5              # (flow is in div_flow * full-resolution px)
         if wild == "rough":
             # independent uniform flows of +-6 px per pixel at this level: every gather window up to the largest is used, and
             # many pixels have more than four contributors (further rounds of the owner's loop)
             fl = (torch.rand(B, 2, H, W, device="cuda") * 2 - 1) * 0.05 * 4 * 6.0
+        if wild == "collapse" and H >= 24:
+            # sample 0: a 12 x 12 block whose pixels all sample (nearly) the same point -- 144 contributors to one pixel of the
+            # gradient, more than a list holds: the sample is flagged on the device and redone by the atomic route
+            ys, xs = torch.meshgrid(torch.arange(12, device="cuda"), torch.arange(12, device="cuda"), indexing="ij")
+            sx, sy = (W - 1) / (4 * W - 1) / 0.05, (H - 1) / (4 * H - 1) / 0.05          # flow units -> pixels at this level
+            fl[0, 0, 6:18, 6:18] = (5.3 - xs.float()) / sx
+            fl[0, 1, 6:18, 6:18] = (5.6 - ys.float()) / sy
         if wild == "wild":
             fl[1] = torch.randn(2, H, W, device="cuda") * 0.05 * 160.0        # ~ +-40 px at a quarter-resolution level
         res = {}
         for atomic in (True, False):
             Fn._WARP_BWD_ATOMIC = atomic
+            old_min_c, Fn._WARP_GATHER_MIN_C = Fn._WARP_GATHER_MIN_C, 1      # (the model routes C < 8 to the atomic scatter)
             try:
                 xr, fr = x.clone().requires_grad_(True), fl.clone().requires_grad_(True)
                 Fn.warp(xr, fr, 4 * H, 4 * W, 0.05, 0.9999, swap).backward(go)
                 res[atomic] = (xr.grad.clone(), fr.grad.clone())
             finally:
                 Fn._WARP_BWD_ATOMIC = False
+                Fn._WARP_GATHER_MIN_C = old_min_c
         fscale = res[True][1].abs().max().item()                                 # (flow gradient: a lanes-along-x kernel of its own)
         assert (res[True][1] - res[False][1]).abs().max().item() <= 2e-5 * fscale + 1e-6, (wild, shape)
         scale = res[True][0].abs().max().item()

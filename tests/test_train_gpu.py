@@ -312,32 +312,34 @@ def test_graphed_step_without_the_lane_matches_eager(lane):
     """hipGraph replays of a step captured WITHOUT the asynchronous weight-gradient lane (round 3 refused them: they drifted by ~1e-2
     over ten steps).  Root cause (profiles/r4_graph_bisect.txt): a hipMemsetAsync inside the capture -- the zero fill of the warp
     backward's scatter target -- is not ordered against the kernels around it as a graph memset node, and without the lane the
-    allocator recycles the memory it fills inside the same graph.  The library zero-fills with a kernel now.  Eight steps on three
-    batches at 4 x 384x448 (kernels long enough for the race to have bitten: the unfixed tree lands at >= 5e-3 here), replayed vs
-    eager, with the ATOMIC warp backward forced on (the path that had the memset); two eager runs of one configuration differ by
-    ~1e-4 (atomics + Adam)."""
+    allocator recycles the memory it fills inside the same graph.  The library zero-fills with a kernel now.  Ten steps on three
+    batches at the BASELINE shape 32 x 384x448 -- the race only bit there (7e-3 ... 8e-3 with IRR_ZERO_MEMSET=1, 5e-5 at
+    4 x 384x448) --, replayed vs eager, with the ATOMIC warp backward forced on (the path that had the memset); two eager runs of
+    one configuration differ by ~1e-4 (atomics + Adam)."""
     from irr_amd import functional as Fn
     from irr_amd.train import GraphedTrainStep
-    batches = [_batch(4, 384, 448, 100 + i) for i in range(3)]
+    batches = [_batch(32, 384, 448, 100 + i) for i in range(3)]
     Fn._WARP_BWD_ATOMIC = True
     try:
         finals = {}
         for graphed in (False, True):
-            m, mal, arena, opt, step = _setup(4, lane=False, capturable=graphed)
+            m, mal, arena, opt, step = _setup(32, lane=False, capturable=graphed)
             if lane == "direct":
                 arena.enable_direct_wgrad()
             try:
                 if graphed:
                     step = GraphedTrainStep(step)
-                for i in range(8):
+                for i in range(10):
                     ld, _, _ = step({k: v.clone() for k, v in batches[i % 3].items()})
                 torch.cuda.synchronize()
                 assert torch.isfinite(ld["total_loss"]).item()
                 finals[graphed] = (opt.param_flat.double().clone(), float(ld["total_loss"].detach()))
             finally:
                 arena.disable_async_wgrad()
+                del m, mal, arena, opt, step
+                torch.cuda.empty_cache()
         d = float((finals[True][0] - finals[False][0]).norm() / finals[False][0].norm())
-        print(f"lane={lane}: parameters after 8 steps, replay vs eager {d:.2e}; losses {finals[True][1]:.4f} / {finals[False][1]:.4f}")
+        print(f"lane={lane}: parameters after 10 steps, replay vs eager {d:.2e}; losses {finals[True][1]:.4f} / {finals[False][1]:.4f}")
         assert d <= 1e-3 and abs(finals[True][1] - finals[False][1]) <= 2e-2 * abs(finals[False][1]), (d, finals[True][1], finals[False][1])
     finally:
         Fn._WARP_BWD_ATOMIC = False
@@ -378,7 +380,7 @@ def test_train_step_B1_448x1024_vs_reference(golden_dir):
         arena.disable_async_wgrad()
 
 
-def _vs_chunked_oracle(B, H, W, chunk):
+def _vs_chunked_oracle(B, H, W, chunk, tol):
     from oracle import irr_pwc_oracle as O
     torch.set_num_threads(min(16, os.cpu_count() or 16))
     batch = O.synthetic_batch(B, H, W, 1234)
@@ -409,7 +411,8 @@ def _vs_chunked_oracle(B, H, W, chunk):
             r = P[n].grad.double()
             d = float((p.grad.double().cpu() - r).norm())
             worst = max(worst, d / (float(r.norm()) + 1e-4 * tot_ref))
-            assert d <= 2e-3 * float(r.norm()) + 1e-5 * tot_ref, (n, d, float(r.norm()))
+            # tol = 2 x the worst value observed in round 4 (profiles/r4_parity_margins.txt); round 3 allowed 2e-3
+            assert d <= tol * (float(r.norm()) + 1e-4 * tot_ref), (n, d, float(r.norm()))
         line = (f"{B}x{H}x{W}: worst per-parameter gradient difference vs oracle {worst:.3e} (||g - g_oracle|| / (||g_oracle|| + "
                 f"1e-4 ||all||)); total grad-L2 {tot:.6f} vs {tot_ref:.6f}; losses {got} vs {ref}")
         print(line)
@@ -427,14 +430,14 @@ def test_bench_shape_bs32_384x448_backward_vs_oracle():
     buffer-range-clamp branches of the weight-gradient kernels), default routing, asynchronous lane: losses (2e-5) and EVERY
     parameter gradient against the oracle run on the host in chunks of 8 pairs (oracle.train_grads_chunked == the whole-batch
     step, tests/test_oracle_golden.py)."""
-    routing = _vs_chunked_oracle(32, 384, 448, 8)
+    routing = _vs_chunked_oracle(32, 384, 448, 8, tol=3e-4)
     for fam in ("fwd_x3", "fwd_x3s", "dgrad_x3", "dense_column_x3", "wgrad_x3", "wgrad_x3_dil"):
         assert routing.get(fam, 0) > 0, (fam, routing)
 
 
 def test_config4_share_bs8_448x1024_backward_vs_oracle():
     """The per-GPU workload of BASELINE configs[4] (448x1024, 8 pairs): losses and every parameter gradient vs the oracle."""
-    _vs_chunked_oracle(8, 448, 1024, 2)
+    _vs_chunked_oracle(8, 448, 1024, 2, tol=8e-4)
 
 
 def test_async_wgrad_lane_is_race_free_at_4x384x448():
