@@ -1,0 +1,201 @@
+"""The weight-gradient lane of the conv() blocks (irr_amd.conv): weight / bias gradients accumulate straight into the flat gradient
+arena -- on a second HIP stream (asynchronous lane) or on the current one (inline) -- and the folds of the kernels' partial images are
+batched.  Installed by irr_amd.ddp.GradArena.enable_async_wgrad / enable_direct_wgrad (or by irr_amd.harness for a foreign training
+loop) as ``irr_amd.conv.SIDE``."""
+from __future__ import annotations
+
+import collections
+import ctypes
+import os
+import weakref
+from typing import Optional
+
+import torch
+
+from . import hip
+from .conv_pack import LAUNCHES
+
+
+class ReduceBatch:
+    """Fold jobs of weight-gradient launches whose partial images have not been added to their gradients yet
+    (include/irr_hip.h, "deferred fold"): the MFMA weight-gradient launchers append a job here instead of running their own
+    10-20 us fold kernel, and ``run()`` folds all of them with ONE launch.  Holds the scratch tensors alive until then."""
+
+    def __init__(self):
+        lib = hip.lib()
+        self.jb = lib.irr_wgrad_job_bytes()
+        self.cap = lib.irr_wgrad_reduce_batch_max()
+        self.buf = ctypes.create_string_buffer(self.jb * self.cap)
+        self.n = 0
+        self.keep = []                   # scratch (and gradient) tensors of the pending jobs
+        self.targets = set()             # data_ptr of the gradients with a pending job: a batch folds into each at most once
+
+    def begin(self):
+        hip.lib().irr_wgrad_defer_begin(ctypes.addressof(self.buf) + self.n * self.jb, self.cap - self.n)
+
+    def end(self, ws: torch.Tensor, gw: torch.Tensor):
+        got = hip.lib().irr_wgrad_defer_end()
+        if got:
+            self.n += got
+            self.keep += [ws, gw]
+            self.targets.add(gw.data_ptr())
+
+    def full_for(self, gw: torch.Tensor) -> bool:
+        return self.n >= self.cap - 1 or gw.data_ptr() in self.targets
+
+    def run(self):
+        """launch the fold of every pending job on the current stream; returns the tensors that must outlive it"""
+        keep = self.keep
+        if self.n:
+            with hip.device_of(keep[0]):
+                hip.call("irr_wgrad_reduce_batch", ctypes.addressof(self.buf), self.n, hip.stream())
+            LAUNCHES["wgrad_reduce_batch"] += 1
+        self.n, self.keep, self.targets = 0, [], set()
+        return keep
+
+
+
+class WgradSide:
+    """Asynchronous weight-gradient lane (training harness opt-in, see irr_amd.ddp.GradArena.enable_async_wgrad).
+
+    dgrad and wgrad of a layer are independent once the pre-activation gradient exists, and only dgrad is on the
+    critical path of backward.  With this object installed, every weight/bias gradient is accumulated straight into
+    the flat gradient arena on a SECOND HIP stream: the wgrad kernels fill the SIMDs that the tail of a dgrad launch
+    (or a whole coarse-level launch, which cannot fill 256 CUs) leaves idle.  Autograd then receives ``None`` for
+    those parameters; GradArena.sync() joins the lane before the all-reduce / optimizer step."""
+
+    def __init__(self, params_and_views, inline: bool = False):
+        # id(parameter) -> (weak reference to the parameter, flat-arena view with its shape).  Looked up by id for speed and
+        # verified by identity: the id of a dead parameter can be reused by a parameter of ANOTHER model
+        self.views = {id(p_): (weakref.ref(p_), v_) for p_, v_ in params_and_views}
+        dev = next(iter(self.views.values()))[1].device
+        # inline: no second stream -- the launches stay on the current stream, but still accumulate straight into the arena
+        # (no per-use gradient tensors, no autograd accumulation adds, one batched fold): GradArena.enable_direct_wgrad()
+        self.inline = inline
+        self.stream = None if inline else torch.cuda.Stream(device=dev)
+        # The references in _inflight are dropped only after the lane has passed the launch (marker) or after the current stream
+        # has joined the lane, so the caching allocator can never hand the memory out early; Tensor.record_stream on top of that
+        # makes the allocator record one (system-scope) event on the lane per freed tensor -- 500 per step (A/B switch: 1 = on)
+        self.record_streams = os.environ.get("IRR_LANE_RECORD_STREAM", "0") != "0"
+        self._inflight = collections.deque()    # (done marker on the lane, tensors its launch reads)
+        self.on_launch = None                   # optional hook(weight, bias) once a routed gradient is complete (ddp: early buckets)
+        self.on_queue = None                    # optional hook(weight, bias) when a launch is queued (ddp: flush at a bucket's last one)
+        # the ~210 partial-image folds of a step run as a few batched launches (ReduceBatch); IRR_LANE_BATCH_REDUCE=0: A/B
+        self.batch = ReduceBatch() if os.environ.get("IRR_LANE_BATCH_REDUCE", "1") != "0" else None
+        self._pending = []                      # (weight, bias) of launches whose fold has not been launched yet
+        # Launches are handed to the lane in GROUPS: one event on the main stream + one wait on the lane per group instead of per
+        # launch (~500 per step; every record / wait is a barrier packet in its queue).  Waiting for a LATER point of the main
+        # stream than necessary is always safe -- nothing on the main stream writes what a queued launch reads (the tensors are
+        # held alive here and the backward nodes never touch a gradient slice again once its weight-gradient launch is issued).
+        self.group = max(1, int(os.environ.get("IRR_LANE_GROUP", "4")))
+        self._queued = []                       # (fn, tensors, params) not handed to the lane yet
+        # The routed gradients are complete only after flush() + join().  GradArena.sync() / FusedAdam.step() / TrainStep do
+        # that explicitly; for every other caller (the reference's own ``loss.backward(); optimizer.step()`` loop,
+        # runtime.py:188-189) the first launch of a backward pass registers join() as a FINAL CALLBACK of that pass: it runs on
+        # the thread that called backward(), on its current stream, once the whole graph has been executed.
+        self._join_queued = False
+
+    def _view(self, p_):
+        hit = self.views.get(id(p_))
+        return hit[1] if (hit is not None and hit[0]() is p_) else None
+
+    def route(self, weight, bias):
+        gw = self._view(weight)
+        if gw is None:
+            return None
+        gb = self._view(bias) if bias is not None else None
+        return gw, gb
+
+    def _kick(self):
+        """hand the queued launches to the lane: after everything enqueued so far on the current stream"""
+        if not self._queued:
+            return
+        queued, self._queued = self._queued, []
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.stream.wait_event(ev)
+        keep = []
+        with torch.cuda.stream(self.stream):
+            for fn, tensors, params, _ in queued:
+                fn()
+                keep += [t for t in tensors if t is not None]
+                self._pending.append(params)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        if self.record_streams:
+            for t in keep:
+                t.record_stream(self.stream)
+        self._inflight.append((done, keep))
+        if not torch.cuda.is_current_stream_capturing():      # (an event recorded inside a capture cannot be queried)
+            while self._inflight and self._inflight[0][0].query():
+                self._inflight.popleft()
+        if self.batch is None or not self.batch.n:
+            self.flush(kick=False)                             # nothing deferred: the gradients are complete already
+
+    def flush(self, kick: bool = True):
+        """fold every pending partial image (one launch on the lane) and report the gradients that are complete now"""
+        if kick and not self.inline:
+            self._kick()
+        if self.batch is not None and self.batch.n:
+            if self.inline:
+                self.batch.run()                               # (same stream: the allocator orders any reuse after the fold)
+            else:
+                with torch.cuda.stream(self.stream):
+                    keep = self.batch.run()
+                    done = torch.cuda.Event()
+                    done.record(self.stream)
+                self._inflight.append((done, keep))
+        pending, self._pending = self._pending, []
+        if self.on_launch is not None:
+            for p_ in pending:
+                self.on_launch(*p_)
+
+    def _end_of_backward(self):
+        self.join()
+
+    def _queue_join(self):
+        if self._join_queued:
+            return
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+            self._join_queued = True
+        except RuntimeError:                     # not inside a backward pass (direct calls in tests / tools): the caller joins
+            pass
+
+    def launch(self, fn, tensors, params=(None, None), gw=None):
+        """Run ``fn`` on the lane after everything enqueued so far on the current stream.  The tensors it reads are kept
+        ALIVE (strong references) until the lane has passed the launch: (a) the caching allocator cannot recycle them, and
+        (b) a tensor with a second owner is never accumulated into IN PLACE by the autograd engine (InputBuffer::accumulate
+        only steals a gradient whose use_count is 1), nor handed to a consumer as its exclusive property -- whatever the
+        model code around the node does with the same gradient tensor (``a = a + b`` feeding two nodes,
+        models/pwcnet_irr*.py)."""
+        self._queue_join()
+        if self.batch is not None and gw is not None:
+            # a batch folds into each gradient at most once, and holds at most cap jobs: queued launches count
+            if (self.batch.full_for(gw) or any(q[3] == gw.data_ptr() for q in self._queued)
+                    or self.batch.n + len(self._queued) >= self.batch.cap - 1):
+                self.flush()
+        if self.inline:
+            fn()
+            self._pending.append(params)
+            if self.batch is None or not self.batch.n:
+                self.flush()
+            if self.on_queue is not None and params[0] is not None:
+                self.on_queue(*params)
+            return
+        self._queued.append((fn, tensors, params, gw.data_ptr() if gw is not None else 0))
+        if len(self._queued) >= self.group:
+            self._kick()
+        if self.on_queue is not None and params[0] is not None:
+            self.on_queue(*params)
+
+    def join(self):
+        self._join_queued = False               # (also after a backward pass that raised before its final callbacks ran)
+        self.flush()
+        if self.inline:
+            return
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self._inflight.clear()                   # later work on the current stream is ordered after the lane
+
+

@@ -1,0 +1,493 @@
+"""Autograd nodes over the conv primitives of irr_amd.conv: one conv() block, the whole DenseNet estimator, a sequential chain of
+conv() blocks and the OccUpsampleNetwork, each as ONE node whose backward uses the epilogue features of the data-gradient launches
+(skip adds, 0.1 x, LeakyReLU', accumulate) instead of elementwise passes, and routes weight gradients to the lane when one is
+installed (``irr_amd.conv.SIDE``)."""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+from . import conv as _c
+from . import hip
+from .conv import _call_conv, conv_dgrad, conv_forward, conv_forward_skip, conv_wgrad, x3_code
+from .conv_pack import LAUNCHES, _dense_column_packs, _padded_cin
+
+
+def wgrad_param(x, gy, weight, bias, stride: int, dil: int, want_bias: bool = True, alpha: float = 1.0,
+                acc=None):
+    """Weight (+bias) gradient of one conv use.  Returns (gw, gb) tensors for autograd -- or (None, None) when the
+    result was accumulated asynchronously into the gradient arena (SIDE lane).  ``acc`` = optional (gw, gb) pair to
+    accumulate into (shared weights used several times inside one autograd node)."""
+    routed = _c.SIDE.route(weight, bias) if _c.SIDE is not None else None
+    if routed is not None:
+        gwv, gbv = routed
+        _c.SIDE.launch(lambda: conv_wgrad(x, gy, weight.shape, stride, dil, gw=gwv, gbias=gbv if want_bias else None,
+                                       alpha=alpha, defer=_c.SIDE.batch), (x, gy),
+                    (weight, bias if (want_bias and gbv is not None) else None), gw=gwv)
+        return None, None
+    if acc is not None:
+        gw, gb = acc
+    else:
+        gw = None
+        gb = torch.zeros(weight.shape[0], device=x.device, dtype=torch.float32) if (want_bias and bias is not None) else None
+    gw = conv_wgrad(x, gy, weight.shape, stride, dil, gw=gw, gbias=gb if want_bias else None, alpha=alpha)
+    return gw, gb
+
+
+def lrelu_bwd_bias(gy: torch.Tensor, y: Optional[torch.Tensor], lrelu: bool, gpre: Optional[torch.Tensor],
+                   gbias: Optional[torch.Tensor]) -> None:
+    """gpre = gy * LeakyReLU'(y) (y = the activated output); gbias += sum over (b, h, w) of gpre."""
+    B, C, H, W = gy.shape
+    hip.call("irr_lrelu_bwd_bias_f32", hip.ptr(gy), hip.ptr(y) if lrelu else None, hip.ptr(gpre), hip.ptr(gbias),
+             B, C, H * W, hip.bs(gy), hip.bs(y) if lrelu else 0, hip.bs(gpre) if gpre is not None else 0,
+             int(lrelu), hip.stream())
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd: one conv() block
+# ----------------------------------------------------------------------------------------------
+class _ConvBlock(hip.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride: int, dil: int, lrelu: bool, res, alpha: float):
+        if not x.is_cuda:
+            raise RuntimeError("irr_amd conv runs on the HIP device only (no CPU fallback)")
+        x = x if _planes_dense(x) else x.contiguous()
+        if res is not None and not _planes_dense(res):
+            res = res.contiguous()
+        if res is None and alpha == 1.0:
+            y = conv_forward(x, weight, bias, stride, dil, lrelu)
+            act = y
+        else:
+            # keep the activated conv output for the LeakyReLU derivative
+            act = conv_forward(x, weight, bias, stride, dil, lrelu)
+            y = act * alpha if res is None else torch.add(res, act, alpha=alpha)
+        ctx.cfg = (stride, dil, lrelu, alpha, res is not None)
+        ctx.save_for_backward(x, weight, act if lrelu else None)
+        ctx.has_bias = bias is not None
+        ctx.weight_obj = weight            # the Parameter object that carries the packed-weight cache
+        ctx.bias_obj = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, act = ctx.saved_tensors
+        stride, dil, lrelu, alpha, has_res = ctx.cfg
+        gy = gy if _planes_dense(gy) else gy.contiguous()
+        # gy is also read by the asynchronous wgrad lane: hand autograd its own copy, because the engine may
+        # accumulate further gradients of `res` into the returned tensor IN PLACE on the main stream
+        gres = gy.clone() if (has_res and ctx.needs_input_grad[6]) else None
+        g = gy if alpha == 1.0 else gy * alpha
+        cout = weight.shape[0]
+        gb = torch.zeros(cout, device=gy.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        want_w = ctx.needs_input_grad[1]
+        bias_in_wgrad = gb is not None and want_w and not lrelu      # no elementwise pass needed at all
+        if lrelu or (gb is not None and not bias_in_wgrad):
+            gpre = torch.empty_like(g) if lrelu else None
+            lrelu_bwd_bias(g, act, lrelu, gpre, gb)                  # mask and bias gradient in one HBM pass
+            if lrelu:
+                g = gpre
+        gx = conv_dgrad(g, ctx.weight_obj, stride, dil, x.shape[2:]) if ctx.needs_input_grad[0] else None
+        gw = None
+        if want_w:
+            if bias_in_wgrad:
+                gw, gb = wgrad_param(x, g, ctx.weight_obj, ctx.bias_obj, stride, dil, want_bias=True)
+            else:
+                gw, _ = wgrad_param(x, g, ctx.weight_obj, None, stride, dil, want_bias=False)
+        return gx, gw, gb, None, None, None, gres, None
+
+
+class _CatPart(ctypes.Structure):
+    """IrrCatPart of include/irr_hip.h"""
+    _fields_ = [("src", ctypes.c_void_p), ("src_bs", ctypes.c_long), ("channels", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+CAT_MAX_PARTS = 8            # IRR_CAT_MAX_PARTS
+
+
+def cat_channels_into(dst: torch.Tensor, parts, zero_tail: int = 0) -> None:
+    """dst[:, :sum(channels)] = cat(parts, dim=1) (+ ``zero_tail`` zero channels behind them) in ONE launch
+    (irr_cat_channels_f32) -- dst is a channel-slice view of the consumer's buffer.  Parts whose planes are not dense are made
+    contiguous first."""
+    B, _, H, W = dst.shape
+    srcs = [p_ if _planes_dense(p_) else p_.contiguous() for p_ in parts]
+    recs = [(hip.ptr(p_), p_.stride(0), int(p_.shape[1])) for p_ in srcs]
+    if zero_tail > 0:
+        recs.append((None, 0, int(zero_tail)))
+    c0 = 0
+    for i in range(0, len(recs), CAT_MAX_PARTS):
+        chunk = recs[i:i + CAT_MAX_PARTS]
+        arr = (_CatPart * len(chunk))(*[_CatPart(s_, bs_, ch_, 0) for s_, bs_, ch_ in chunk])
+        view = dst[:, c0:]
+        hip.call("irr_cat_channels_f32", hip.ptr(view), dst.stride(0), ctypes.addressof(arr), len(chunk), B, H * W, hip.stream())
+        c0 += sum(ch_ for _, _, ch_ in chunk)
+
+
+def _planes_dense(t: torch.Tensor) -> bool:
+    b, c, h, w = t.shape
+    sb, sc, sh, sw = t.stride()
+    return (sw == 1 or w == 1) and (sh == w or h == 1) and (sc == h * w or c == 1)
+
+
+def conv_block(x, weight, bias, stride: int = 1, dil: int = 1, lrelu: bool = True, res=None, alpha: float = 1.0):
+    """[res +] alpha * LeakyReLU?(conv2d(x, weight, bias, stride, 'same' padding, dil))."""
+    return _ConvBlock.apply(x, weight, bias, int(stride), int(dil), bool(lrelu), res, float(alpha))
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd: the whole DenseNet estimator (FlowEstimatorDense / OccEstimatorDense) as ONE node
+# ----------------------------------------------------------------------------------------------
+class _DenseEstimatorFn(hip.Function):
+    """conv1..conv5 (+LeakyReLU, outputs PREPENDED) and conv_last of models/pwc_modules.py:153-170 / 190-207
+    on ONE preallocated NCHW buffer: every conv reads a channel suffix and writes the slice in front of it,
+    so there is no torch.cat; the backward walks the same buffer layout with a gradient buffer G in which
+    data-gradients are accumulated in place (``accumulate`` epilogue of the MFMA kernel).
+
+    Buffer layout (channels): [c5 32 | c4 64 | c3 96 | c2 128 | c1 128 | x Cin0 | est E]   (est only if base given)
+    Returns (buf, out): out = conv_last(x5) (+ base when given; then also stored in the est slot so the
+    context network can consume ``buf`` directly as cat([x5, est]), models/IRR_PWC.py:113-114)."""
+
+    GROW = (128, 128, 96, 64, 32)
+
+    @staticmethod
+    def forward(ctx, nparts, base, nrelu, *args):
+        # x arrives as `nparts` tensors (IRR-PWC: cost volume, projected features, flow / occlusion): they are copied straight
+        # into their channel slices of the buffer, and backward returns the slices of the gradient buffer -- no torch.cat of the
+        # decoder input in forward, no split of its gradient in backward
+        parts, wb = args[:nparts], args[nparts:]
+        ws, bs = wb[0::2], wb[1::2]
+        B, _, H, W = parts[0].shape
+        widths = [int(p_.shape[1]) for p_ in parts]
+        cin0 = sum(widths)
+        E = ws[5].shape[0]
+        ctot = 448 + cin0
+        has_base = base is not None
+        buf = torch.empty(B, ctot + (E if has_base else 0), H, W, device=parts[0].device, dtype=torch.float32)
+        cat_channels_into(buf[:, 448:], parts)
+        off = 448
+        for i in range(5):
+            co = _DenseEstimatorFn.GROW[i]
+            conv_forward(buf[:, off:ctot], ws[i], bs[i], 1, 1, True, out=buf[:, off - co:off])
+            off -= co
+        if has_base:
+            base_c = base if _planes_dense(base) else base.contiguous()
+            out = conv_forward(buf[:, :ctot], ws[5], bs[5], 1, 1, False, res=base_c, alpha=1.0)
+            buf[:, ctot:].copy_(out)
+        else:
+            out = conv_forward(buf[:, :ctot], ws[5], bs[5], 1, 1, False)
+        ctx.save_for_backward(buf, *ws)
+        ctx.cfg = (cin0, E, has_base, tuple(widths), int(nrelu))
+        ctx.wobjs, ctx.bobjs = ws, bs
+        return buf, out
+
+    @staticmethod
+    def backward(ctx, g_buf, g_out):
+        buf = ctx.saved_tensors[0]
+        ws = ctx.saved_tensors[1:]
+        cin0, E, has_base, widths, nrelu = ctx.cfg
+        nparts = len(widths)
+        need_x = any(ctx.needs_input_grad[3:3 + nparts])
+        B, _, H, W = buf.shape
+        ctot = 448 + cin0
+        dev = buf.device
+        # G: gradient w.r.t. every channel of buf.  g_buf is produced exclusively for this node (the context
+        # network's first conv), so it is updated in place.
+        if g_buf is None:
+            G = torch.zeros_like(buf)
+        else:
+            G = g_buf if (g_buf.is_contiguous() and g_buf.shape == buf.shape) else g_buf.contiguous()
+        g_est = None
+        if g_out is not None:
+            g_est = g_out if _planes_dense(g_out) else g_out.contiguous()
+        if has_base:
+            g_est = G[:, ctot:] + g_est if g_est is not None else G[:, ctot:].clone()
+        grads_w = [None] * 6
+        grads_b = [None] * 6
+        # conv_last first: its data gradient touches every channel (K is tiny, the launch is memory-bound) and its
+        # epilogue turns the c5 slice into a pre-activation gradient.  Then the buffer is back-propagated COLUMN-WISE:
+        # for each slice T = c4, c3, c2, c1, x (in that order) ONE launch sums the contributions of all later layers,
+        # reading their concatenated pre-activation gradients G[:, :t0] (contiguous by construction) against a
+        # combined packed weight matrix, accumulates into G[:, T] once and applies LeakyReLU'(buf[:, T]) in the same
+        # epilogue.  Versus layer-by-layer accumulation this replaces up to five small-K read-modify-write launches
+        # per slice by a single large-K one.  Bias gradients ride on the wgrad launches.
+        if g_est is not None:
+            grads_w[5], grads_b[5] = wgrad_param(buf[:, :ctot], g_est, ctx.wobjs[5], ctx.bobjs[5], 1, 1)
+            conv_dgrad(g_est, ws[5], 1, 1, (H, W), gx=G[:, :ctot], accumulate=True, mask=buf[:, :ctot], nmask=32)
+        else:
+            lrelu_bwd_bias(G[:, :32], buf[:, :32], True, G[:, :32], None)
+        use_x3 = [bool(x3_code(B, t0, H, W, t1 - t0, 3, 1, 1)) for (t0, t1) in ((32, 96), (96, 192), (192, 320), (320, 448), (448, ctot))]
+        packs = _dense_column_packs(ctx.wobjs[:5], cin0, tuple(use_x3))
+        grads_w[4], grads_b[4] = wgrad_param(buf[:, 32:ctot], G[:, :32], ctx.wobjs[4], ctx.bobjs[4], 1, 1)   # conv5
+        bounds = [(32, 96), (96, 192), (192, 320), (320, 448), (448, ctot)]
+        for k_, (t0, t1) in enumerate(bounds):
+            last = k_ == 4
+            if last and not need_x:
+                break
+            # (the input column: its first `nrelu` channels are LeakyReLU outputs whose producer wants the PRE-activation gradient
+            # -- the cost volume, models/IRR_PWC.py:94-95: the mask costs this MFMA-bound launch nothing, and the two HBM-bound
+            # cost-volume gradient kernels no longer read their 81-plane output)
+            nm = (nrelu if last else t1 - t0)
+            margs = (hip.ptr(buf[:, t0:t1]), hip.bs(buf), nm) if nm > 0 else (None, 0, 0)
+            LAUNCHES["dense_column_x3" if use_x3[k_] else "dense_column_f32"] += 1
+            if use_x3[k_]:
+                args = ("irr_conv2d_fwd_x3", hip.ptr(G), hip.ptr(packs[k_]), None, None, hip.ptr(G[:, t0:t1]), B, t0, H, W,
+                        t1 - t0, 1, hip.bs(G), hip.bs(G), 0, 0, 1.0, 1, *margs, hip.stream())
+                variant = 100000 + x3_code(B, t0, H, W, t1 - t0, 3, 1, 1)
+            else:
+                args = ("irr_conv2d_fwd_f32", hip.ptr(G), hip.ptr(packs[k_]), None, None, hip.ptr(G[:, t0:t1]), B, t0, H, W,
+                        t1 - t0, H, W, 3, 1, 1, hip.bs(G), hip.bs(G), 0, 0, 1.0, 1, *margs, hip.stream())
+                variant = hip.lib().irr_conv2d_fwd_variant(B, t1 - t0, H, W, 3)
+            if _c.TIMER is None:
+                _call_conv(args)
+            else:
+                _c.TIMER.wrap(variant, 2.0 * B * H * W * t0 * (t1 - t0) * 9, lambda: _call_conv(args), "dgrad")
+            if not last:                                   # G[:, t0:t1] is now the pre-activation gradient of conv(4-k_)
+                i = 3 - k_
+                grads_w[i], grads_b[i] = wgrad_param(buf[:, t1:ctot], G[:, t0:t1], ctx.wobjs[i], ctx.bobjs[i], 1, 1)
+        # g_est is still being read by the asynchronous wgrad lane (conv_last): autograd gets its own copy, because
+        # the engine may accumulate the other gradients of `base` into the returned tensor IN PLACE
+        gbase = g_est.clone() if (has_base and ctx.needs_input_grad[1]) else None
+        out = [None, gbase, None]
+        c0 = 448
+        for i, wd in enumerate(widths):                       # per-part gradients = channel slices of G (plane-dense views)
+            out.append(G[:, c0:c0 + wd] if (need_x and ctx.needs_input_grad[3 + i]) else None)
+            c0 += wd
+        for i in range(6):
+            out += [grads_w[i], grads_b[i]]
+        return tuple(out)
+
+
+
+def dense_estimator(x, base, weights_and_biases, preact_grad_channels: int = 0):
+    """(buf, out) -- see _DenseEstimatorFn.  x: the estimator's input, or a sequence of tensors whose channel concatenation
+    it is.  weights_and_biases = [w1, b1, ..., w5, b5, w_last, b_last].
+    preact_grad_channels = n: the first n input channels are LeakyReLU(0.1) outputs and the gradient returned for them is the
+    PRE-activation gradient (multiplied by LeakyReLU' of the stored input) -- their producer must then not apply the derivative
+    again (functional.cost_volume(..., grad_is_preactivation=True))."""
+    parts = tuple(x) if isinstance(x, (list, tuple)) else (x,)
+    if not all(p_.is_cuda for p_ in parts):
+        raise RuntimeError("irr_amd conv runs on the HIP device only (no CPU fallback)")
+    if preact_grad_channels and preact_grad_channels != int(parts[0].shape[1]):
+        raise ValueError("preact_grad_channels must cover exactly the first input part")
+    return _DenseEstimatorFn.apply(len(parts), base, int(preact_grad_channels), *parts, *weights_and_biases)
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd: a sequential chain of conv() blocks as ONE node
+# ----------------------------------------------------------------------------------------------
+class _ConvChainFn(hip.Function):
+    """y = [res +] conv_n(... conv_1(x)) for the purely sequential sub-networks (ContextNetwork /
+    OccContextNetwork, models/pwc_modules.py:210-243; the 7-conv stacks of RefineFlow / RefineOcc,
+    models/irr_modules.py:71-79,115-123; the (stride-2, stride-1) pairs of FeatureExtractor,
+    models/pwc_modules.py:91-96).
+
+    Backward walks the chain with no elementwise pass over the activations: the data-gradient launch of
+    layer i multiplies its result by LeakyReLU'(a_{i-1}) in its epilogue, so it directly yields the
+    pre-activation gradient layer i-1 needs, and every bias gradient comes out of the wgrad launch."""
+
+    @staticmethod
+    def forward(ctx, x, res, cfg, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        x = x if _planes_dense(x) else x.contiguous()
+        acts = []
+        cur = x
+        n = len(ws)
+        for i in range(n):
+            stride, dil, lrelu = cfg[i]
+            last = i == n - 1
+            if last and res is not None:
+                res_c = res if _planes_dense(res) else res.contiguous()
+                if lrelu:
+                    a = conv_forward(cur, ws[i], bs[i], stride, dil, True)      # keep the activation for its mask
+                    acts.append(a)
+                    cur = torch.add(res_c, a)
+                else:
+                    cur = conv_forward(cur, ws[i], bs[i], stride, dil, False, res=res_c)
+                    acts.append(None)
+            else:
+                cur = conv_forward(cur, ws[i], bs[i], stride, dil, lrelu)
+                acts.append(cur)
+        ctx.cfg = cfg
+        ctx.has_res = res is not None
+        ctx.weight_objs = ws
+        ctx.bias_objs = bs
+        ctx.save_for_backward(x, *[a for a in acts[:-1]], *( [acts[-1]] if cfg[-1][2] else [] ))
+        return cur
+
+    @staticmethod
+    def backward(ctx, gy):
+        cfg = ctx.cfg
+        n = len(cfg)
+        saved = ctx.saved_tensors
+        x = saved[0]
+        acts = list(saved[1:n])                               # a_0 .. a_{n-2}
+        a_last = saved[n] if cfg[-1][2] else None
+        ws = ctx.weight_objs
+        gy = gy if _planes_dense(gy) else gy.contiguous()
+        # (copy: gy may still be read by the asynchronous wgrad lane while autograd accumulates into gres in place)
+        gres = gy.clone() if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        dev = gy.device
+        g = gy
+        if cfg[-1][2]:                                        # activation on the chain output: one pass on a small tensor
+            gpre = torch.empty_like(gy)
+            lrelu_bwd_bias(gy, a_last, True, gpre, None)
+            g = gpre
+        grads = [None] * (2 * n)
+        for i in range(n - 1, -1, -1):
+            stride, dil, _ = cfg[i]
+            inp = acts[i - 1] if i > 0 else x
+            grads[2 * i], grads[2 * i + 1] = wgrad_param(inp, g, ws[i], ctx.bias_objs[i], stride, dil)
+            if i > 0:
+                prev_lrelu = cfg[i - 1][2]
+                g = conv_dgrad(g, ws[i], stride, dil, inp.shape[2:], mask=inp if prev_lrelu else None,
+                               nmask=inp.shape[1] if prev_lrelu else 0)
+            elif ctx.needs_input_grad[0]:
+                g = conv_dgrad(g, ws[i], stride, dil, inp.shape[2:])
+            else:
+                g = None
+        return (g, gres, None) + tuple(grads)
+
+
+def conv_chain(x, layers, res=None):
+    """layers: sequence of modules exposing .weight, .bias, .stride, .dilation, .is_relu (modules.ConvBlock)."""
+    if not x.is_cuda:
+        raise RuntimeError("irr_amd conv runs on the HIP device only (no CPU fallback)")
+    cfg = tuple((int(l.stride), int(l.dilation), bool(l.is_relu)) for l in layers)
+    wb = []
+    for l in layers:
+        wb += [l.weight, l.bias]
+    return _ConvChainFn.apply(x, res, cfg, *wb)
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd: OccUpsampleNetwork (models/irr_modules.py:30-56) as ONE node
+# ----------------------------------------------------------------------------------------------
+
+class _OccUpsampleFn(hip.Function):
+    """x_in -> init_conv -> 3 x [x += 0.1 * res_convs(x)] (shared weights) -> x_init + res_end_conv(x) -> out_convs + occ.
+
+    The network runs on 32-channel maps at 1/2 and full resolution (41 % of all conv activation traffic,
+    SURVEY.md Appendix A (iv)), so elementwise passes are expensive here.  The backward therefore uses the
+    epilogue features of the MFMA data-gradient launch for every skip connection and activation:
+    ``g_x = g_y + dgrad(...)`` (res), ``0.1 *`` (alpha), ``*= LeakyReLU'(t)`` (mask) and ``+=`` (accumulate);
+    bias gradients come from the wgrad launches.
+
+    The input arrives as its parts (nearest-x2 occlusion map first, then the guide tensors of models/IRR_PWC.py:166-167): they
+    are copied straight into the channel slices of ONE buffer (no torch.cat of the 10-channel guide and again of the 11-channel
+    input at full resolution).  When the bf16x3 streaming kernel accepts the problem with 16 input channels, that buffer gets
+    16 channels (five of them zero) and init_conv runs there with zero-padded weights -- forward and data gradient: the 11 -> 32
+    layer at 384x448 was the largest launch left on the fp32-MFMA kernels (1.35 ms at 52 TFLOP/s; the streaming kernel is bound by
+    writing the 32-channel map).  The weight gradient reads the 11 real channels of the same buffer."""
+
+    @staticmethod
+    def forward(ctx, nparts, mul_const, *args):
+        parts = args[:nparts]
+        w_init, b_init, w_r0, b_r0, w_r1, b_r1, w_end, b_end, w_out, b_out = args[nparts:]
+        occ_up = parts[0] if _planes_dense(parts[0]) else parts[0].contiguous()
+        B, _, H, W = occ_up.shape
+        widths = tuple(int(p_.shape[1]) for p_ in parts)
+        cin = sum(widths)
+        cpad = 16 if (cin < 16 and x3_code(B, 16, H, W, w_init.shape[0], 3, 1, 1)) else cin
+        x_in = torch.empty(B, cpad, H, W, device=occ_up.device, dtype=torch.float32)
+        cat_channels_into(x_in, (occ_up,) + tuple(parts[1:]), zero_tail=cpad - cin)
+        w_first = _padded_cin(w_init, cpad) if cpad > cin else w_init
+        x_init = conv_forward(x_in, w_first, b_init, 1, 1, True, real_cin=cin)
+        xs = [x_init]
+        ts = []
+        for _ in range(3):
+            t = conv_forward(xs[-1], w_r0, b_r0, 1, 1, True)
+            ts.append(t)
+            xs.append(conv_forward(t, w_r1, b_r1, 1, 1, False, res=xs[-1], alpha=mul_const))
+        e, x2 = conv_forward_skip(xs[-1], w_end, b_end, True, x_init)
+        o = conv_forward(x2, w_out, b_out, 1, 1, True)
+        out = torch.add(o, occ_up)
+        ctx.mul_const = mul_const
+        ctx.widths = widths
+        ctx.wobjs = (w_init, w_r0, w_r1, w_end, w_out)
+        ctx.bobjs = (b_init, b_r0, b_r1, b_end, b_out)
+        ctx.save_for_backward(x_in, xs[0], xs[1], xs[2], xs[3], ts[0], ts[1], ts[2], e, x2, o)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x_in, x0, x1, x2r, x3, t1, t2, t3, e, x2, o = ctx.saved_tensors
+        w_init, w_r0, w_r1, w_end, w_out = ctx.wobjs
+        b_init, b_r0, b_r1, b_end, b_out = ctx.bobjs
+        mc = ctx.mul_const
+        widths = ctx.widths
+        nparts = len(widths)
+        cin = sum(widths)
+        dev = g_out.device
+        hw_ = x0.shape[2:]
+        g_out = g_out if _planes_dense(g_out) else g_out.contiguous()
+        z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)
+        # out = occ_up + lrelu(conv_out(x2))
+        gpre_o = torch.empty_like(g_out)
+        gb_out = z(w_out.shape[0])
+        lrelu_bwd_bias(g_out, o, True, gpre_o, gb_out)                       # 1-channel tensor
+        gw_out, _ = wgrad_param(x2, gpre_o, w_out, None, 1, 1, want_bias=False)
+        # x2 = x_init + e, e = lrelu(conv_end(x3)): the gradient of x2 is needed raw (g_x2: the skip into x_init) and multiplied by
+        # LeakyReLU'(e) (gpre_e: into res_end_conv).  Both come out of the out_convs data-gradient launch where its quad kernel
+        # applies (one pass less over two 32-channel full-resolution maps); the bias gradient then rides on the wgrad launch.
+        B_, _, H_, W_ = x2.shape
+        dual = (w_out.shape[0] == 1 and W_ % 4 == 0 and not os.environ.get("IRR_OCCUP_NO_DUAL_DGRAD"))       # (A/B switch)
+        if dual:
+            g_x2 = torch.empty(B_, w_out.shape[1], H_, W_, device=dev, dtype=torch.float32)
+            gpre_e = torch.empty_like(g_x2)
+            LAUNCHES["dgrad_smallco"] += 1
+            hip.call("irr_conv2d_smallco_dgrad_dual_f32", hip.ptr(gpre_o), hip.ptr(w_out.detach().contiguous()), hip.ptr(gpre_e),
+                     hip.ptr(g_x2), hip.ptr(e), B_, w_out.shape[1], H_, W_, 1, hip.bs(gpre_o), hip.bs(gpre_e), hip.bs(g_x2), hip.bs(e),
+                     hip.stream())
+            gw_end, gb_end = wgrad_param(x3, gpre_e, w_end, b_end, 1, 1, want_bias=True)
+        else:
+            g_x2 = conv_dgrad(gpre_o, w_out, 1, 1, hw_)                      # (B,32,H,W); also the gradient of x_init via the skip
+            gpre_e = torch.empty_like(g_x2)
+            gb_end = z(w_end.shape[0])
+            lrelu_bwd_bias(g_x2, e, True, gpre_e, gb_end)
+            gw_end, _ = wgrad_param(x3, gpre_e, w_end, None, 1, 1, want_bias=False)
+        g_x = conv_dgrad(gpre_e, w_end, 1, 1, hw_)                           # gradient w.r.t. x3
+        # three residual blocks with shared weights: x_i = x_{i-1} + mc * conv_r1(t_i), t_i = lrelu(conv_r0(x_{i-1}))
+        routed = _c.SIDE is not None and _c.SIDE.route(w_r0, b_r0) is not None
+        acc_r0 = None if routed else (torch.zeros_like(w_r0), z(w_r0.shape[0]))
+        acc_r1 = None if routed else (torch.zeros_like(w_r1), z(w_r1.shape[0]))
+        xs = [x0, x1, x2r]
+        ts = [t1, t2, t3]
+        for i in (2, 1, 0):
+            wgrad_param(ts[i], g_x, w_r1, b_r1, 1, 1, alpha=mc, acc=acc_r1)
+            gpre_t = conv_dgrad(g_x, w_r1, 1, 1, hw_, mask=ts[i], nmask=ts[i].shape[1], alpha=mc)
+            wgrad_param(xs[i], gpre_t, w_r0, b_r0, 1, 1, acc=acc_r0)
+            if i > 0:
+                g_x = conv_dgrad(gpre_t, w_r0, 1, 1, hw_, res=g_x)                # skip + branch in one launch
+            else:
+                # x_0 = x_init: add the x2 skip gradient (accumulate into g_x2) and apply init_conv's LeakyReLU'
+                conv_dgrad(gpre_t, w_r0, 1, 1, hw_, gx=g_x2, accumulate=True, res=g_x, mask=x0, nmask=x0.shape[1])
+        gw_r0, gb_r0 = acc_r0 if acc_r0 is not None else (None, None)
+        gw_r1, gb_r1 = acc_r1 if acc_r1 is not None else (None, None)
+        gpre_init = g_x2
+        x_real = x_in[:, :cin] if x_in.shape[1] > cin else x_in
+        gw_init, gb_init = wgrad_param(x_real, gpre_init, w_init, b_init, 1, 1)
+        gparts = [None] * nparts
+        if any(ctx.needs_input_grad[2:2 + nparts]):
+            w_first = _padded_cin(w_init, x_in.shape[1]) if x_in.shape[1] > cin else w_init
+            g_xin = conv_dgrad(gpre_init, w_first, 1, 1, hw_, real_cin=cin)
+            c0 = 0
+            for i, wd in enumerate(widths):
+                if ctx.needs_input_grad[2 + i]:
+                    gparts[i] = g_xin[:, c0:c0 + wd]
+                c0 += wd
+        if ctx.needs_input_grad[2]:                           # occ_up: channel 0 of the input AND the final skip
+            gparts[0] = g_out + gparts[0] if gparts[0] is not None else g_out
+        return (None, None, *gparts, gw_init, gb_init, gw_r0, gb_r0, gw_r1, gb_r1, gw_end, gb_end, gw_out, gb_out)
+
+
+def occ_upsample_net(occ_up, guide, mod):
+    """mod: modules.OccUpsampleNetwork.  occ_up = nearest-x2 occlusion map, guide = the guide tensor or the sequence of tensors
+    whose channel concatenation it is; the network's input is cat([occ_up, guide])."""
+    parts = (occ_up,) + (tuple(guide) if isinstance(guide, (list, tuple)) else (guide,))
+    if not all(p_.is_cuda for p_ in parts):
+        raise RuntimeError("irr_amd conv runs on the HIP device only (no CPU fallback)")
+    return _OccUpsampleFn.apply(len(parts), float(mod.mul_const), *parts, mod.init_conv.weight, mod.init_conv.bias, mod.res_convs[0].weight,
+                                mod.res_convs[0].bias, mod.res_convs[1].weight, mod.res_convs[1].bias,
+                                mod.res_end_conv.weight, mod.res_end_conv.bias, mod.out_convs.weight, mod.out_convs.bias)
