@@ -13,7 +13,9 @@
  *     T + b*T_bs + c*H*W + y*W + x, where the batch stride ``T_bs`` (in elements) is passed
  *     explicitly so that a tensor may be a channel slice of a larger buffer (the DenseNet concat
  *     buffers of FlowEstimatorDense are written in place, no torch.cat copies);
- *   - ``stream`` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - ``stream`` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises; every launcher issues
+ *     KERNELS only (zero fills included: no hipMemsetAsync / hipMemcpyAsync), so it may be captured into a hipGraph -- a memset
+ *     node was observed not to be ordered against the kernels around it (profiles/r4_graph_bisect.txt);
  *   - no allocation inside: the caller owns every buffer (the reference instead resize_()s and
  *     fill_(0)s inside the C++ glue, correlation_cuda.cc:34-40,104-112);
  *   - return value: 0 on success, otherwise the hipError_t of the failing call / launch

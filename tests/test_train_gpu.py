@@ -229,8 +229,13 @@ def test_step_without_grad_sync_still_steps_on_complete_gradients():
             assert arena._side_lane.batch.n == 0 and not arena._side_lane._queued
         finally:
             arena.disable_async_wgrad()
-    assert torch.allclose(flats[0][0], flats[1][0], rtol=1e-4, atol=1e-7)
-    assert torch.allclose(flats[0][1], flats[1][1], rtol=0, atol=1e-7)
+    # (two runs differ in the last bits: bias / small-C warp gradients are summed with atomics, the gather's list order varies)
+    g0, g1 = flats[0][0].double(), flats[1][0].double()
+    assert float((g0 - g1).norm() / g0.norm()) <= 1e-5 and float((g0 - g1).abs().max()) <= 1e-4 * float(g0.abs().max())
+    # the first Adam step moves every parameter by ~lr = 1e-4 in the direction of its gradient's sign: only elements whose gradient
+    # is at the rounding level may differ between the runs; an incomplete gradient would move whole layers (>= 1 % of the elements)
+    dp = (flats[0][1] - flats[1][1]).abs()
+    assert float(dp.max()) <= 2.5e-4 and float((dp > 5e-5).float().mean()) <= 2e-3, (float(dp.max()), float((dp > 5e-5).float().mean()))
 
 
 @pytest.mark.parametrize("mode", ["eager", "graphed", "torch_adam"])
