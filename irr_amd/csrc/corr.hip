@@ -431,21 +431,17 @@ __global__ __launch_bounds__(256) void corr81_bwd_kernel(const float* __restrict
 //   SECOND == false: g1[c,p] = (1/C) sum_d g[d][p]   * f2[c][p+d]     (tile = f2)
 //   SECOND == true : g2[c,p] = (1/C) sum_d g[d][p-d] * f1[c][p-d]     (tile = f1, window mirrored)
 template <bool SECOND, int QX, int QY>
-__global__ __launch_bounds__(192) void corr81_bwd4_kernel(const float* __restrict__ other, const float* __restrict__ gout,
-                                                         const float* __restrict__ fwd_out, float* __restrict__ gin,
-                                                         int C, int H, int W, long other_bs, long gout_bs, long out_bs,
-                                                         long gin_bs) {
+__device__ __forceinline__ void corr81_bwd4_body(const float* __restrict__ other, const float* __restrict__ gout,
+                                                 const float* __restrict__ fwd_out, float* __restrict__ gin, int C, int H, int W,
+                                                 long other_bs, long gout_bs, long out_bs, long gin_bs, unsigned tpos, unsigned ntx,
+                                                 unsigned nty, float (*tile)[QY + 2 * HALO][QTile<QX>::BP], float (*red)[QC][QY][QX]) {
   static_assert(QX * QY == 256 && (QX == 32 || QX == 16), "256-pixel tiles of 32 x 8 or 16 x 16");
   constexpr int QTX = QX + 2 * HALO, QTY = QY + 2 * HALO, QP = QTile<QX>::BP, NQ = QX / 4;
-  __shared__ __attribute__((aligned(16))) float tile[QC][QTY][QP];
-  __shared__ __attribute__((aligned(16))) float red[3][QC][QY][QX];
   const int tid = threadIdx.x;
   const int grp = tid / 64;
   const int t64 = tid - grp * 64;
   const int q = t64 % NQ, ty = t64 / NQ;
-  // XCD-major tile order (common.h): the tiles of one XCD are neighbours, their 2.5x halo overlap is served by that XCD's L2
-  const unsigned tpos = irr_xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
-  const int x0 = (int)(tpos % gridDim.x) * QX, y0 = (int)((tpos / gridDim.x) % gridDim.y) * QY, b = (int)(tpos / (gridDim.x * gridDim.y));
+  const int x0 = (int)(tpos % ntx) * QX, y0 = (int)((tpos / ntx) % nty) * QY, b = (int)(tpos / (ntx * nty));
   const int x = x0 + 4 * q, y = y0 + ty;
   const bool inside = (x < W) && (y < H);
   const long plane = (long)H * W;
@@ -575,6 +571,38 @@ __global__ __launch_bounds__(192) void corr81_bwd4_kernel(const float* __restric
   }
 }
 
+template <bool SECOND, int QX, int QY>
+__global__ __launch_bounds__(192) void corr81_bwd4_kernel(const float* __restrict__ other, const float* __restrict__ gout,
+                                                         const float* __restrict__ fwd_out, float* __restrict__ gin,
+                                                         int C, int H, int W, long other_bs, long gout_bs, long out_bs,
+                                                         long gin_bs) {
+  __shared__ __attribute__((aligned(16))) float tile[QC][QY + 2 * HALO][QTile<QX>::BP];
+  __shared__ __attribute__((aligned(16))) float red[3][QC][QY][QX];
+  // XCD-major tile order (common.h): the tiles of one XCD are neighbours, their 2.5x halo overlap is served by that XCD's L2
+  const unsigned tpos = irr_xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+  corr81_bwd4_body<SECOND, QX, QY>(other, gout, fwd_out, gin, C, H, W, other_bs, gout_bs, out_bs, gin_bs, tpos, gridDim.x, gridDim.y,
+                                   tile, red);
+}
+
+// BOTH gradients from one launch (round 4): a 1-D grid of 2 x tiles blocks in XCD-major order, position 2t computes g1 of tile t and
+// position 2t + 1 its g2.  The two blocks run side by side on one XCD and read the same 81 planes of the output gradient around the
+// same tile -- the second read comes out of that XCD's L2 instead of HBM (two launches: gout fetched twice, 0.45 of the 0.8 GB they
+// move at 96x112x64).
+template <int QX, int QY>
+__global__ __launch_bounds__(192) void corr81_bwd4_pair_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                              const float* __restrict__ gout, const float* __restrict__ fwd_out,
+                                                              float* __restrict__ g1, float* __restrict__ g2, int C, int H, int W,
+                                                              long f1_bs, long f2_bs, long gout_bs, long out_bs, long g1_bs,
+                                                              long g2_bs, unsigned ntx, unsigned nty) {
+  __shared__ __attribute__((aligned(16))) float tile[QC][QY + 2 * HALO][QTile<QX>::BP];
+  __shared__ __attribute__((aligned(16))) float red[3][QC][QY][QX];
+  const unsigned pos = irr_xcd_order(blockIdx.x, gridDim.x);
+  if (pos & 1u)
+    corr81_bwd4_body<true, QX, QY>(f1, gout, fwd_out, g2, C, H, W, f1_bs, gout_bs, out_bs, g2_bs, pos >> 1, ntx, nty, tile, red);
+  else
+    corr81_bwd4_body<false, QX, QY>(f2, gout, fwd_out, g1, C, H, W, f2_bs, gout_bs, out_bs, g1_bs, pos >> 1, ntx, nty, tile, red);
+}
+
 // 16 x 16 tiles where they waste fewer lanes than 32 x 8 ones (96x112: 7 full tiles per row instead of 3.5); IRR_CORR_TILE32=1: A/B
 static bool corr_tile16(int W) {
   if (IRR_ENV_FLAG("IRR_CORR_TILE32")) return false;
@@ -621,6 +649,18 @@ extern "C" int irr_corr81_bwd_f32(const float* f1, const float* f2, const float*
   if ((W & 3) == 0 && al16 && !IRR_ENV_FLAG("IRR_CORR_SCALAR")) {
     const bool t16 = corr_tile16(W);
     const dim3 grid4 = t16 ? dim3(irr_cdiv(W, 16), irr_cdiv(H, 16), B) : dim3(irr_cdiv(W, 32), irr_cdiv(H, 8), B);
+    // both gradients of a LARGE problem: one launch, the pair of a tile shares gout through L2 (measured, 64 samples x 32 channels:
+    // 96x112 307 -> 263 us; 48x56 87 -> 108 us -- with 768 tiles the launch is a single round of blocks either way and the pair
+    // kernel's register count is the larger of the two bodies)
+    if (g1 && g2 && (long)grid4.x * grid4.y * grid4.z >= 2048 && !IRR_ENV_FLAG("IRR_CORR_NO_PAIR")) {
+      const unsigned nblk = 2u * grid4.x * grid4.y * grid4.z;
+      if (t16) hipLaunchKernelGGL((corr81_bwd4_pair_kernel<16, 16>), dim3(nblk), dim3(192), 0, (hipStream_t)stream, f1, f2, gout, out, g1, g2,
+                                  C, H, W, f1_bs, f2_bs, gout_bs, out_bs, g1_bs, g2_bs, grid4.x, grid4.y);
+      else hipLaunchKernelGGL((corr81_bwd4_pair_kernel<32, 8>), dim3(nblk), dim3(192), 0, (hipStream_t)stream, f1, f2, gout, out, g1, g2,
+                              C, H, W, f1_bs, f2_bs, gout_bs, out_bs, g1_bs, g2_bs, grid4.x, grid4.y);
+      IRR_LAUNCH_CHECK();
+      return 0;
+    }
     if (g1) {
       if (t16) hipLaunchKernelGGL((corr81_bwd4_kernel<false, 16, 16>), grid4, dim3(192), 0, (hipStream_t)stream, f2, gout, out, g1, C, H, W,
                                   f2_bs, gout_bs, out_bs, g1_bs);
