@@ -1,5 +1,6 @@
-"""Forward / data-gradient launches at the 6x7 and 12x14 pyramid levels (2B = 64 samples): conv_x3t_kernel vs what the routing picks
-with IRR_X3_NO_TINY=1 (the fp32 split-K kernel or conv_x3_kernel + its K-split epilogue).  Run twice: with and without the switch."""
+"""Forward launches of the decoder / context / refinement layer shapes at the 6x7 and 12x14 pyramid levels (2B = 64 samples): time, TFLOP/s and
+the kernel family the routing picks (code 0 = fp32 split-K kernel, 4171 ... = conv_x3_kernel + K-split epilogue).  profiles/NOTES.md,
+section C: a dedicated tiny-plane bf16x3 kernel was measured against these numbers and removed."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from irr_amd import conv as C
@@ -17,4 +18,4 @@ for H, W in ((6, 7), (12, 14)):
         gf = 2.0 * 64 * H * W * cin * cout * 9 / 1e9
         tot[(H, W)] = tot.get((H, W), 0.0) + t
         print(f"{H:2d}x{W:2d} {cin:4d}->{cout:4d} d{dil:2d}: {t * 1e3:7.1f} us  {gf / t:6.1f} TFLOP/s  code {code}", flush=True)
-print({k: f"{v * 1e3:.0f} us" for k, v in tot.items()}, "IRR_X3_NO_TINY =", os.environ.get("IRR_X3_NO_TINY"))
+print({k: f"{v * 1e3:.0f} us" for k, v in tot.items()})
