@@ -97,6 +97,37 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
   }
 }
 
+// Backward of a DOWNSAMPLING by >= 2 per axis (align_corners=True; the raw images resized to every pyramid level,
+// models/IRR_PWC.py:126-127 -- their gradient exists because the reference's step makes the inputs require grad, runtime.py:158-162):
+// neighbouring output pixels are >= 2 input pixels apart, so their 2 x 2 footprints are disjoint and gx is zero everywhere else.  The
+// gather form above evaluates ~9 candidate taps for every INPUT pixel (215 us for 384x448 -> 6x7 at 64 x 3 planes, five such calls
+// per step); here gx is zero-filled and one thread per OUTPUT pixel stores its (at most) four contributions -- plain stores, no atomics.
+__global__ __launch_bounds__(256) void resize_bwd_sparse_kernel(const float* __restrict__ gout, float* __restrict__ gx, int C, int H,
+                                                               int W, int OH, int OW, long gout_bs, long gx_bs, float alpha) {
+  const long oplane = (long)OH * OW;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= oplane) return;
+  const int b = blockIdx.z;
+  const int oy = (int)(p / OW), ox = (int)(p - (long)oy * OW);
+  const float sy = rs_src<false>(rs_scale<false>(H, OH), oy), sx = rs_src<false>(rs_scale<false>(W, OW), ox);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float ly1 = sy - y0, lx1 = sx - x0;
+  // per-axis weights exactly as tap_weight() forms them (a clamped second tap falls onto the first: the weights add up)
+  const float wy0 = y1 == y0 ? (1.f - ly1) + ly1 : 1.f - ly1, wx0 = x1 == x0 ? (1.f - lx1) + lx1 : 1.f - lx1;
+  const long plane = (long)H * W;
+  for (int c = blockIdx.y; c < C; c += gridDim.y) {
+    const float g = gout[(long)b * gout_bs + (long)c * oplane + p];
+    float* gc = gx + (long)b * gx_bs + (long)c * plane;
+    gc[(long)y0 * W + x0] = alpha * (wy0 * wx0 * g);
+    if (x1 != x0) gc[(long)y0 * W + x1] = alpha * (wy0 * lx1 * g);
+    if (y1 != y0) {
+      gc[(long)y1 * W + x0] = alpha * (ly1 * wx0 * g);
+      if (x1 != x0) gc[(long)y1 * W + x1] = alpha * (ly1 * lx1 * g);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int irr_resize_bilinear_ac_fwd_f32(const float* x, float* out, int B, int C, int H, int W, int OH, int OW,
@@ -112,6 +143,19 @@ extern "C" int irr_resize_bilinear_ac_fwd_f32(const float* x, float* out, int B,
 extern "C" int irr_resize_bilinear_ac_bwd_f32(const float* gout, float* gx, int B, int C, int H, int W, int OH, int OW,
                                               long gout_bs, long gx_bs, float alpha, void* stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || !gout || !gx || B > 65535) return IRR_EINVAL;
+  if (OH > 1 && OW > 1 && (H - 1) >= 2 * (OH - 1) && (W - 1) >= 2 * (OW - 1) && !IRR_ENV_FLAG("IRR_RESIZE_BWD_GATHER")) {
+    // downsampling by >= 2 per axis: disjoint 2 x 2 footprints (see resize_bwd_sparse_kernel)
+    const size_t per = sizeof(float) * (size_t)C * H * W;
+    if (gx_bs == (long)C * H * W) {
+      IRR_HIP_TRY(irr_zero_async(gx, per * (size_t)B, (hipStream_t)stream));
+    } else {
+      for (int b = 0; b < B; ++b) IRR_HIP_TRY(irr_zero_async(gx + (long)b * gx_bs, per, (hipStream_t)stream));
+    }
+    dim3 gs(irr_cdiv((long)OH * OW, 256), C < 8 ? C : 8, B);
+    hipLaunchKernelGGL(resize_bwd_sparse_kernel, gs, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs, gx_bs, alpha);
+    IRR_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid(irr_cdiv((long)H * W, 256), C < 8 ? C : 8, B);
   hipLaunchKernelGGL(resize_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs,
                      gx_bs, alpha);

@@ -106,6 +106,26 @@ def test_resize(golden_dir, case):
     np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"resize_{case}_gx"], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape,size", [((3, 3, 384, 448), (6, 7)), ((2, 3, 384, 448), (96, 112)), ((2, 2, 96, 112), (48, 56)),
+                                        ((2, 3, 100, 132), (2, 3)), ((1, 3, 436, 1024), (55, 128)), ((2, 1, 33, 47), (17, 24))])
+def test_resize_backward_of_a_downsampling(shape, size):
+    """The raw images are resized DOWN to every pyramid level (models/IRR_PWC.py:126-127); their gradient exists because the
+    reference's step makes the inputs require grad.  For a downsampling by >= 2 per axis the backward kernel stores the disjoint
+    2 x 2 footprints of the output pixels into a zero-filled gradient (resize_bwd_sparse_kernel); compared with ATen's CPU
+    interpolate backward, and with the gather-form kernel at a ratio just below 2 (last case: 33x47 -> 17x24 takes the gather form)."""
+    import torch.nn.functional as F
+    from irr_amd import functional as Fn
+    g = torch.Generator().manual_seed(sum(shape) + sum(size))
+    x = torch.randn(*shape, generator=g)
+    go = torch.randn(shape[0], shape[1], *size, generator=g)
+    xc = x.clone().requires_grad_(True)
+    F.interpolate(xc, size=size, mode="bilinear", align_corners=True).backward(go)
+    xd = x.cuda().requires_grad_(True)
+    y = Fn.resize_bilinear_ac(xd, *size)
+    y.backward(go.cuda())
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_warp_full_size_properties():
     """384x448-level shapes: zero flow is the identity (mask all ones), linearity in x."""
     from irr_amd import functional as Fn
