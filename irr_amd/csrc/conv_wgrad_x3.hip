@@ -733,7 +733,7 @@ static bool dil_ok(int Cout, int W, int dil) {
   const int cot = (Cout + 31) / 32, kg = pick_kg(W);
   if (dil == 2 || dil == 4) return cot == 4;
   if (dil == 8) return cot == 3;
-  if (dil == 16) return cot == 2 && kg != 1;               // (the (1,4) unit with two margin groups exceeds the LDS)
+  if (dil == 16) return cot == 2 && (kg != 1 || !IRR_ENV_FLAG("IRR_WX3_NO_D16_KG1"));      // (kg = 1: the (1, 2) unit, see launch_dil)
   return false;
 }
 
@@ -772,7 +772,9 @@ static int launch_dil(const WX3Args& a, int kg, hipStream_t st) {
   if (kg == 4) return launch_wx3<MW, 2, 4, 1, 1, DIL>(a, st);
   if (kg == 2) return launch_wx3<MW, 2, 2, 2, 1, DIL>(a, st);
   if constexpr (DIL <= 8) return launch_wx3<MW, 2, 1, 4, 1, DIL>(a, st);
-  return IRR_EINVAL;
+  // dilation 16 on rows of an odd number of groups (48x56): the (1, 4) unit with two margin groups per side exceeds the LDS; a
+  // (1, 2) unit -- two rows of the residue class, one k-step, 110 KiB -- fits (round 4: the layer ran on the fp32 kernel at 47 TFLOP/s)
+  return launch_wx3<MW, 2, 1, 2, 1, DIL>(a, st);
 }
 
 extern "C" int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,

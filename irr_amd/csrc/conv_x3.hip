@@ -769,7 +769,12 @@ static bool make_plan_rd(int B, int Cin, int H, int W, int Cout, int dil, int rd
     if (ks > 16) ks = 16;
     if (ks >= 2) p->ksplit = (int)ks;
   }
-  return p->eff >= 0.70;
+  // (dilation >= 8: the fp32 kernel stages nine tap-shifted copies there and is the slower alternative by a wider margin -- the
+  // 96 -> 64 dilation-16 forward at 48x56 has a best tile of 4 x 64 = 0.656 and runs 258 -> 145 us on this kernel;
+  // IRR_X3_MIN_EFF: experiment switch, percent)
+  static const double min_eff_env = getenv("IRR_X3_MIN_EFF") ? atof(getenv("IRR_X3_MIN_EFF")) / 100.0 : 0.0;
+  const double min_eff = min_eff_env > 0.0 ? min_eff_env : (dil >= 8 ? 0.65 : 0.70);
+  return p->eff >= min_eff;
 }
 
 static bool make_plan(int B, int Cin, int H, int W, int Cout, int dil, Plan* p) {
