@@ -749,7 +749,9 @@ extern "C" long irr_conv2d_wgrad_x3_ws_elems(int Cin, int Cout) { return (Cin > 
 
 extern "C" int irr_conv2d_wgrad_x3_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil) {
   if (k != 3 || stride != 1 || B <= 0) return 0;
-  if (dil != 1 && !(W % 8 == 0 && W >= 32 && Cin >= 64 && dil_ok(Cout, W, dil))) return 0;
+  // (W % 8 == 4 -- the 24x28 level: the last group of a row is half empty, as in the dilation-1 walk; round 4)
+  if (dil != 1 && !(W % 4 == 0 && W >= (IRR_ENV_FLAG("IRR_WX3_DIL_W8") ? 32 : 24) && (W % 8 == 0 || !IRR_ENV_FLAG("IRR_WX3_DIL_W8")) && Cin >= 64 &&
+                    dil_ok(Cout, W, dil))) return 0;
   if (dil != 1) return 5000 + dil;
   // Any width >= 7 (rows that are not a multiple of four pixels load element-wise) and, with the tall-image walk, any height:
   // the 6x7 and 12x14 pyramid levels ran on the fp32 kernel at 4-40 TFLOP/s (85 launches, 5.5 ms per step).
@@ -779,7 +781,7 @@ static int launch_dil(const WX3Args& a, int kg, hipStream_t st) {
 
 extern "C" int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
                                        int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs, void* stream) {
-  if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (W % 8) || !dil_ok(Cout, W, dil)) return IRR_EINVAL;
+  if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (W % 4) || !dil_ok(Cout, W, dil)) return IRR_EINVAL;
   const long n = (long)Cout * Cin * 9;
   hipStream_t st = (hipStream_t)stream;
   WX3Args a;

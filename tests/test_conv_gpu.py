@@ -356,6 +356,7 @@ def test_conv_smallco_dgrad_accumulate_mask(cout, dil):
 
 WX3_DIL_CASES = [(128, 128, 1, 24, 32, 2), (128, 128, 2, 19, 48, 4), (128, 96, 1, 40, 56, 8), (96, 64, 1, 50, 48, 16),
                  (96, 64, 2, 48, 56, 16), (96, 64, 1, 35, 40, 16),     # dilation 16 on rows of an odd group count: the (1, 2) unit (round 4)
+                 (128, 128, 3, 24, 28, 2), (128, 128, 2, 24, 28, 4), (128, 96, 3, 24, 28, 8), (96, 64, 2, 24, 28, 16), (128, 128, 1, 17, 36, 4),   # W % 8 == 4
                  (128, 128, 1, 20, 56, 2), (128, 128, 1, 33, 64, 4), (128, 96, 2, 24, 64, 8), (96, 64, 2, 40, 64, 16)]
 
 

@@ -19,7 +19,8 @@ ACC += [  # round 3: widths that are not a multiple of four, heights below 8 (ta
 ACC_DIL = [(128, 128, 1, 24, 32, 2), (128, 128, 2, 19, 48, 4), (128, 96, 1, 40, 56, 8), (96, 64, 1, 50, 48, 16), (128, 128, 1, 20, 56, 2),
            (128, 128, 1, 33, 64, 4), (128, 96, 2, 24, 64, 8), (96, 64, 2, 40, 64, 16), (96, 64, 2, 48, 56, 16), (96, 64, 1, 35, 40, 16)]
 PERF_DIL = [("ctx d2 L4", 128, 128, 64, 96, 112, 2), ("ctx d4 L4", 128, 128, 64, 96, 112, 4), ("ctx d8 L4", 128, 96, 64, 96, 112, 8),
-            ("ctx d16 L4", 96, 64, 64, 96, 112, 16), ("ctx d2 L3", 128, 128, 64, 48, 56, 2), ("ctx d8 L3", 128, 96, 64, 48, 56, 8), ("ctx d16 L3", 96, 64, 64, 48, 56, 16)]
+            ("ctx d16 L4", 96, 64, 64, 96, 112, 16), ("ctx d2 L3", 128, 128, 64, 48, 56, 2), ("ctx d8 L3", 128, 96, 64, 48, 56, 8), ("ctx d16 L3", 96, 64, 64, 48, 56, 16),
+            ("ctx d2 L2", 128, 128, 64, 24, 28, 2), ("ctx d4 L2", 128, 128, 64, 24, 28, 4), ("ctx d8 L2", 128, 96, 64, 24, 28, 8), ("ctx d16 L2", 96, 64, 64, 24, 28, 16)]
 PERF_SMALL = [("ctx.conv0 L1", 565, 128, 64, 12, 14), ("refine 128->128 L1", 128, 128, 64, 12, 14), ("dense.conv4 L1", 467, 64, 64, 12, 14),
               ("dense.conv5 L1", 531, 32, 64, 12, 14), ("refine 64->32 L1", 64, 32, 64, 12, 14), ("refine 32->32 L1", 32, 32, 64, 12, 14),
               ("ctx.conv0 L0", 565, 128, 64, 6, 7), ("refine 128->128 L0", 128, 128, 64, 6, 7), ("dense.conv4 L0", 467, 64, 64, 6, 7),
