@@ -1,5 +1,7 @@
 # Same-box A/B of the current tree against the round-3 tree (r3tree/ = git archive of 0e92235, built here; not tracked):
 #   bash tools/ab_r3.sh [rounds]      (run on the GPU box from the repository root)
+# Recreate r3tree/ here (CPU container) before the gpurun call:
+#   mkdir -p r3tree && git archive 0e92235 irr_amd include tools bench.py oracle | tar -x -C r3tree && (cd r3tree && python -m irr_amd.build)
 # Alternates the two benches so that box-to-box and thermal differences cancel; prints pairs/s and ms/step of each run.
 R=${1:-3}
 for i in $(seq 1 $R); do
