@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide: v_mfma_f32_32x32x16_bf16, dense
 X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0   # conv_x3: six bf16 MFMA products per fp32 product (exact 3-way split)
+H2_PEAK_TFLOPS = 2500.0 / 3.0          # the fp16x2 form of conv_x3: three fp16 MFMA products per fp32 product (dense fp16 = dense bf16 peak)
 X3_PLANES = {1: 352, 2: 616, 3: 640}
 
 
@@ -48,6 +49,9 @@ def kernel_name(var):
     """variant code of irr_amd.conv's KernelTimer -> (kernel template instantiation, its MFMA roof in fp32 TFLOP/s)"""
     if var == 109001:
         return ("conv_x3s_kernel", X3_PEAK_TFLOPS)
+    if var >= 200000:
+        c = var - 200000
+        return (f"conv_x3_kernel<{c // 1000},{(c // 100) % 10},{(c // 10) % 10},{X3_PLANES.get(c % 10, 0)},2>", H2_PEAK_TFLOPS)
     if var >= 100000:
         c = var - 100000
         return (f"conv_x3_kernel<{c // 1000},{(c // 100) % 10},{(c // 10) % 10},{X3_PLANES.get(c % 10, 0)}>", X3_PEAK_TFLOPS)
@@ -333,7 +337,9 @@ def main():
         roof = {"bound": "mfma", "kernel": kname,
                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": None,
-                "peak_note": ("algorithmic fp32 FLOPs (2*MACs); conv_x3 issues 6 bf16 MFMA products per fp32 product, "
+                "peak_note": ("algorithmic fp32 FLOPs (2*MACs); the fp16x2 form of conv_x3 issues 3 fp16 MFMA products per fp32 product, "
+                              "so its roof is the dense fp16 MFMA peak 2500 / 3 = 833.3 TFLOP/s" if peak == H2_PEAK_TFLOPS else
+                              "algorithmic fp32 FLOPs (2*MACs); conv_x3 issues 6 bf16 MFMA products per fp32 product, "
                               "so its roof is the dense bf16 MFMA peak 2500 / 6 = 416.7 TFLOP/s" if peak != FP32_MFMA_PEAK_TFLOPS
                               else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                 "launches": st["calls"], "avg_launch_us": round(st["seconds"] / st["calls"] * 1e6, 2),

@@ -260,6 +260,40 @@ int irr_wgrad_reduce_batch(const void* jobs, int njobs, void* stream);
 int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                             int B, int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs, void* stream);
 
+/* ---- "h2": the conv_x3 / conv_wgrad_x3 kernels with operands as TWO fp16 pieces of scaled values (round 4) ------------------
+ * x * 2^e = hi + lo (fp16 each, round-to-nearest; 23 significant bits, absolute error <= 2^-25 in scaled units for the small
+ * values of a tensor), a * b ~= ah*bh + ah*bl + al*bh accumulated in fp32 by v_mfma_f32_32x32x16_f16: half the matrix work of
+ * the bf16x3 form, the same error class (dropped terms <= 2^-24 |ab|).  fp16 has a 5-bit exponent, so every operand tensor is
+ * scaled by a power of two derived ON THE DEVICE from max |.| of the whole tensor (|x| * 2^e < 2^15); the launch undoes both
+ * scales before its epilogue.  The maxima live in device "amax slots" (plain floats):
+ *   irr_amax_f32: slot = max(slot, max |x|) over B plane-dense samples of n floats (batch stride bs); slot starts at 0.
+ *   x_amax / n_amax arguments: the operand's magnitude = max over n consecutive slots (an operand assembled from several
+ *   producers -- a DenseNet buffer -- carries one slot per part).  y_amax (nullable): the launch folds max |y| of what it
+ *   stores into that slot (atomic max), so a chain of launches needs no separate pass over its activations.
+ * Weights: irr_conv_pack_weights_h2 / _h2_sub = the x3 packers with two pieces per fragment; amax = device scalar >= max |w|
+ * over every weight that goes into wq (one scale per packed matrix; its exponent is stored in the 16-B unit behind the last
+ * fragment: irr_conv_h2_packed_bytes includes it).  irr_conv2d_h2_eligible: irr_conv2d_x3_eligible without the problems of the
+ * streaming 32-channel kernel (those stay on bf16x3).  irr_conv2d_fwd_h2: contract of irr_conv2d_fwd_x3_splitk (ws nullable).
+ * irr_conv2d_wgrad_h2: contract of irr_conv2d_wgrad_x3 (dil == 1) / irr_conv2d_wgrad_x3_dil (dil > 1), same scratch and fold. */
+int irr_amax_f32(const float* x, int B, long n, long bs, float* slot, void* stream);
+long irr_conv_h2_packed_bytes(int Cin, int Cout);
+int irr_conv_pack_weights_h2(const float* w, void* wq, int Cin, int Cout, int transpose, const float* amax, void* stream);
+int irr_conv_pack_weights_h2_sub(const float* w, void* wq, int w_cin, int w_cout, int total_rows, int chan0,
+                                 int nchan, int row_offset, const float* amax, void* stream);
+long irr_conv_pack_job_h2(void* job, const float* w, void* wq, int Cin, int Cout, int transpose, const float* amax);
+long irr_conv_pack_job_h2_sub(void* job, const float* w, void* wq, int w_cin, int w_cout, int total_rows, int chan0,
+                              int nchan, int row_offset, const float* amax);
+int irr_conv2d_h2_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil);
+int irr_conv2d_fwd_h2(const float* x, const void* wq, const float* bias, const float* res, float* y,
+                      int B, int Cin, int H, int W, int Cout, int dil,
+                      long x_bs, long y_bs, long res_bs,
+                      int lrelu, float alpha, int accumulate,
+                      const float* mask, long mask_bs, int nmask, float* ws, long ws_elems,
+                      const float* x_amax, int n_amax, float* y_amax, void* stream);
+int irr_conv2d_wgrad_h2(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
+                        int B, int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs,
+                        const float* x_amax, int nx, const float* gy_amax, int ng, void* stream);
+
 /* ---- tiny-Cout heads (Cout <= 4, stride 1): direct VALU kernels, same contracts as the MFMA entry points -------
  * conv_last 563->2 / 562->1, context tails 32->2 / 32->1, OccUpsampleNetwork.out_convs 32->1
  * (models/pwc_modules.py:161,198,221,239; models/irr_modules.py:44).  w is the plain (Cout,Cin,k,k) tensor. */

@@ -1,6 +1,6 @@
-"""conv() blocks of IRR-PWC on the MFMA kernels of libirr_hip.so: the fp32-faithful bf16x3-split family (conv_x3 /
-conv_x3s / conv_wgrad_x3) wherever its ``*_eligible`` predicates accept the problem, the fp32-MFMA family
-elsewhere (``IRR_CONV_MATH=f32`` forces the latter everywhere).
+"""conv() blocks of IRR-PWC on the MFMA kernels of libirr_hip.so: the fp32-faithful split-operand family (conv_x3 /
+conv_x3s / conv_wgrad_x3, DESIGN.md 5.0: fp16x2 "h2" form by default, bf16x3 with ``IRR_CONV_MATH=x3``) wherever its
+``*_eligible`` predicates accept the problem, the fp32-MFMA family elsewhere (``IRR_CONV_MATH=f32`` forces the latter everywhere).
 
 Mirrors the reference helper ``conv(in_planes, out_planes, kernel_size, stride, dilation, isReLU)``
 (models/pwc_modules.py:8-19, models/irr_modules.py:7-18): Conv2d with "same" padding and bias,
@@ -82,12 +82,18 @@ def out_hw(h: int, w: int, k: int, stride: int, dil: int) -> Tuple[int, int]:
 
 
 
-MATH = os.environ.get("IRR_CONV_MATH", "x3")
+# "h2" (default since round 4): fp16x2 of power-of-two-scaled operands, three MFMA products -- conv_x3_kernel<..., 2> /
+# conv_wgrad_x3_kernel<..., true> wherever they are eligible and the bf16x3 streaming kernel for the 32-channel layers;
+# "x3": bf16x3, six products, everywhere the x3 family is eligible (rounds 2-3 default); "f32": the fp32-MFMA kernels everywhere.
+DEFAULT_MATH = os.environ.get("IRR_CONV_MATH", "h2")
+MATH = DEFAULT_MATH
 
 
 def set_math(name: str) -> None:
+    """x3: bf16x3 (six products) wherever eligible; h2: fp16x2 of scaled operands (three products) wherever conv_x3_kernel /
+    conv_wgrad_x3_kernel are eligible, bf16x3 on the streaming 32-channel kernel; f32: the fp32-MFMA kernels everywhere."""
     global MATH
-    if name not in ("x3", "f32"):
+    if name not in ("x3", "f32", "h2"):
         raise ValueError(name)
     MATH = name
 
@@ -96,7 +102,7 @@ _X3_ENV_DONE = [False]
 
 
 def x3_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, dil: int) -> int:
-    if MATH != "x3":
+    if MATH not in ("x3", "h2"):
         return 0
     if not _X3_ENV_DONE[0]:
         _X3_ENV_DONE[0] = True
@@ -106,7 +112,15 @@ def x3_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, di
 
 
 
-from .conv_pack import packed_weights_x3  # noqa: E402,F401
+def h2_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, dil: int) -> int:
+    """non-zero: the problem runs on the fp16x2 form of conv_x3_kernel (MATH == "h2" and not a streaming-kernel problem)"""
+    if MATH != "h2" or not x3_code(B, cin, H, W, cout, k, stride, dil):
+        return 0
+    return int(hip.lib().irr_conv2d_h2_eligible(B, cin, H, W, cout, k, stride, dil))
+
+
+from .conv_pack import packed_weights_h2, packed_weights_x3  # noqa: E402,F401
+from .conv_amax import Amax, measure as amax_measure  # noqa: E402,F401
 
 
 # ----------------------------------------------------------------------------------------------
@@ -115,21 +129,34 @@ from .conv_pack import packed_weights_x3  # noqa: E402,F401
 def _call_conv(args) -> None:
     """Launch a conv entry point from its argument tuple.  irr_conv2d_fwd_x3 problems that are too small to fill the chip
     get a scratch buffer and run through the K-split entry point (csrc/conv_x3.hip: blockIdx.z splits the channel chunks)."""
-    if args[0] == "irr_conv2d_fwd_x3":
+    if args[0] in ("irr_conv2d_fwd_x3", "irr_conv2d_fwd_h2"):
         B, cin, H, W, cout, dil = args[6:12]
         n = hip.lib().irr_conv2d_fwd_x3_ws_elems(B, cin, H, W, cout, dil)
+        ws = torch.empty(n, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device())) if n > 0 else None
+        if args[0] == "irr_conv2d_fwd_h2":                  # (args: the x3 tuple + (x_amax ptr, n_amax, y_amax ptr) before the stream)
+            hip.call("irr_conv2d_fwd_h2", *args[1:-4], hip.ptr(ws), n, *args[-4:])
+            return
         if n > 0:
-            ws = torch.empty(n, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
             hip.call("irr_conv2d_fwd_x3_splitk", *args[1:-1], ws.data_ptr(), n, args[-1])
             return
     hip.call(*args)
 
 
+def _h2_args(x3_args, x, x_amax, y_amax):
+    """the argument tuple of irr_conv2d_fwd_x3 turned into irr_conv2d_fwd_h2's (_call_conv adds the scratch): x's magnitude is
+    measured here when the caller has no slot for it"""
+    xa = x_amax if x_amax is not None else amax_measure(x)
+    return ("irr_conv2d_fwd_h2",) + tuple(x3_args[1:-1]) + (xa.ptr(), xa.n, y_amax.ptr() if y_amax is not None else None, x3_args[-1]), xa
+
+
 def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, dil: int,
                  lrelu: bool, out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
-                 alpha: float = 1.0, accumulate: bool = False, real_cin: Optional[int] = None) -> torch.Tensor:
+                 alpha: float = 1.0, accumulate: bool = False, real_cin: Optional[int] = None,
+                 x_amax: Optional[Amax] = None, y_amax: Optional[Amax] = None) -> torch.Tensor:
     """out = [res +] alpha * act(conv(x, weight) + bias)   (accumulate: out += ...).
-    real_cin: the layer's true input-channel count when x / weight are zero-padded copies (KernelTimer prices algorithmic FLOPs)."""
+    real_cin: the layer's true input-channel count when x / weight are zero-padded copies (KernelTimer prices algorithmic FLOPs).
+    x_amax: slots that bound |x| (MATH == "h2"; measured here when absent).  y_amax: a zeroed slot that holds max |out| after the
+    call whatever kernel family ran (the h2 launch folds it in its epilogue, any other route costs one pass over out)."""
     # (the LeakyReLU'-mask epilogue of the kernel is only used by conv_dgrad)
     B, cin, H, W = x.shape
     cout, cin_w, k, _ = weight.shape
@@ -144,16 +171,21 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
         hip.call("irr_conv2d_smallco_fwd_f32", hip.ptr(x), hip.ptr(wc), hip.ptr(bias.detach() if bias is not None else None),
                  hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, k, dil, hip.bs(x), hip.bs(out),
                  hip.bs(res) if res is not None else 0, int(lrelu), float(alpha), int(accumulate), hip.stream())
+        if y_amax is not None:
+            amax_measure(out, y_amax)
         return out
     code = x3_code(B, cin, H, W, cout, k, stride, dil)
+    h2 = bool(code) and bool(h2_code(B, cin, H, W, cout, k, stride, dil))
     if code:
-        wq = packed_weights_x3(weight, False)
+        wq = packed_weights_h2(weight, False) if h2 else packed_weights_x3(weight, False)
         args = ("irr_conv2d_fwd_x3", hip.ptr(x), hip.ptr(wq), hip.ptr(bias.detach() if bias is not None else None),
                 hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, dil,
                 hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
                 int(lrelu), float(alpha), int(accumulate), None, 0, 0, hip.stream())
-        variant = 100000 + code
-        LAUNCHES["fwd_x3s" if code == 9001 else "fwd_x3"] += 1
+        if h2:
+            args, _xa = _h2_args(args, x, x_amax, y_amax)
+        variant = (200000 if h2 else 100000) + code
+        LAUNCHES["fwd_h2" if h2 else "fwd_x3s" if code == 9001 else "fwd_x3"] += 1
     else:
         LAUNCHES["fwd_f32"] += 1
         wp = packed_weights(weight, False)
@@ -168,6 +200,8 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
         if variant is None:
             variant = hip.lib().irr_conv2d_fwd_variant(B, cout, oh, ow, k)
         TIMER.wrap(variant, 2.0 * B * oh * ow * cout * (real_cin or cin) * k * k, lambda: _call_conv(args))
+    if y_amax is not None and not h2:
+        amax_measure(out, y_amax)
     return out
 
 
@@ -199,11 +233,13 @@ S2_GATHER_MAX_CIN = 96   # stride-2 3x3 data gradients with at most this many re
 def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in_hw: Tuple[int, int],
                gx: Optional[torch.Tensor] = None, accumulate: bool = False,
                mask: Optional[torch.Tensor] = None, nmask: int = 0,
-               res: Optional[torch.Tensor] = None, alpha: float = 1.0, real_cin: Optional[int] = None) -> torch.Tensor:
+               res: Optional[torch.Tensor] = None, alpha: float = 1.0, real_cin: Optional[int] = None,
+               gy_amax: Optional[Amax] = None, gx_amax: Optional[Amax] = None) -> torch.Tensor:
     """gx (+)= conv_transpose(gy, weight); gy must already carry the activation derivative.
     mask/nmask: afterwards gx[:, :nmask] *= LeakyReLU'(mask[:, :nmask]) in the same launch (mask = the saved
     activation that produced this conv's input), i.e. gx comes out as a PRE-activation gradient.
-    res/alpha: gx = res + alpha * conv_transpose(...) (residual branches: the skip gradient is added in the epilogue)."""
+    res/alpha: gx = res + alpha * conv_transpose(...) (residual branches: the skip gradient is added in the epilogue).
+    gy_amax / gx_amax: as x_amax / y_amax of conv_forward (gx_amax bounds the COMPLETE gx: res, accumulate and mask included)."""
     B, cout, oh, ow = gy.shape
     cout_w, cin, k, _ = weight.shape
     assert cout == cout_w
@@ -220,21 +256,27 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         LAUNCHES["dgrad_smallco"] += 1
         hip.call("irr_conv2d_smallco_dgrad_f32", hip.ptr(gy), hip.ptr(wc), hip.ptr(gx), margs[0], B, cin, H, W, cout, dil,
                  hip.bs(gy), hip.bs(gx), margs[1], margs[2], int(accumulate), hip.stream())
+        if gx_amax is not None:
+            amax_measure(gx, gx_amax)
         return gx
     if stride == 1 and cout == 1:
         # the MFMA kernel consumes input channels in pairs: give the single-channel gradient a zero partner
         gy = torch.cat([gy, torch.zeros_like(gy)], dim=1)
         weight = torch.cat([weight.detach(), torch.zeros_like(weight.detach())], dim=0)
         cout = 2
+    h2 = False
     if stride == 1 and cout >= 2:
         code = x3_code(B, cout, oh, ow, cin, k, 1, dil)
+        h2 = bool(code) and bool(h2_code(B, cout, oh, ow, cin, k, 1, dil))
         if code:
-            wq = packed_weights_x3(weight, True)
+            wq = packed_weights_h2(weight, True) if h2 else packed_weights_x3(weight, True)
             args = ("irr_conv2d_fwd_x3", hip.ptr(gy), hip.ptr(wq), None, hip.ptr(res), hip.ptr(gx), B, cout, oh, ow, cin,
                     dil, hip.bs(gy), hip.bs(gx), hip.bs(res) if res is not None else 0, 0, float(alpha),
                     int(accumulate), *margs, hip.stream())
-            variant = 100000 + code
-            LAUNCHES["dgrad_x3s" if code == 9001 else "dgrad_x3"] += 1
+            if h2:
+                args, _ga = _h2_args(args, gy, gy_amax, gx_amax)
+            variant = (200000 if h2 else 100000) + code
+            LAUNCHES["dgrad_h2" if h2 else "dgrad_x3s" if code == 9001 else "dgrad_x3"] += 1
         else:
             LAUNCHES["dgrad_f32"] += 1
             wp = packed_weights(weight, True)
@@ -268,13 +310,15 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
             gx += tmp
         if mask is not None and nmask > 0:
             gx[:, :nmask] *= torch.where(mask[:, :nmask] > 0, 1.0, 0.1)
+    if gx_amax is not None and not h2:
+        amax_measure(gx, gx_amax)
     return gx
 
 
 
 def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil: int,
                gw: Optional[torch.Tensor] = None, gbias: Optional[torch.Tensor] = None, alpha: float = 1.0,
-               defer: Optional[ReduceBatch] = None) -> torch.Tensor:
+               defer: Optional[ReduceBatch] = None, x_amax: Optional[Amax] = None, gy_amax: Optional[Amax] = None) -> torch.Tensor:
     """gw += d/dW; gw (Cout,Cin,k,k) is created zeroed when not given.  gbias (optional, (Cout,)) += sum of gy over
     (b, h, w): the bias gradient comes out of the same launch (the gy tiles are staged there anyway).
     ``defer``: the MFMA kernels leave the fold of their partial images to ``defer.run()`` (gw is complete only after it)."""
@@ -284,8 +328,10 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
     if gw is None:
         gw = torch.zeros(cout, cin, k, k, device=x.device, dtype=torch.float32)
     assert gw.is_contiguous()
-    use_x3 = (MATH == "x3" and not (cout <= 4 and stride == 1)
+    use_x3 = (MATH in ("x3", "h2") and not (cout <= 4 and stride == 1)
               and bool(hip.lib().irr_conv2d_wgrad_x3_eligible(B, cin, H, W, cout, k, stride, dil)))
+    # h2: where both operands carry amax slots (the callers provide them for the layers whose forward runs on the h2 kernel)
+    use_h2 = use_x3 and MATH == "h2" and x_amax is not None and gy_amax is not None
     # scratch: one partial [Cout][k*k][Cin] image per block column of the launch (the Cout <= 4 / Cin = 3 kernels: one image)
     smallci = cin == 3 and k == 3 and cout > 4
     if (cout <= 4 and stride == 1) or smallci:
@@ -295,7 +341,7 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
     else:
         nws = hip.lib().irr_conv2d_wgrad_ws_elems(B, cin, H, W, cout, oh, ow, k, stride, dil, hip.bs(x), hip.bs(gy))
     ws = torch.empty(nws, device=x.device, dtype=torch.float32)
-    LAUNCHES["wgrad_smallci" if smallci else "wgrad_smallco" if (cout <= 4 and stride == 1) else
+    LAUNCHES["wgrad_smallci" if smallci else "wgrad_smallco" if (cout <= 4 and stride == 1) else "wgrad_h2" if use_h2 else
              "wgrad_x3_dil" if (use_x3 and dil > 1) else "wgrad_x3" if use_x3 else "wgrad_f32"] += 1
     if smallci:
         hip.call("irr_conv2d_smallci_wgrad_f32", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
@@ -308,7 +354,10 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
     if defer is not None:
         defer.begin()
     try:
-        if use_x3 and dil > 1:
+        if use_h2:
+            hip.call("irr_conv2d_wgrad_h2", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
+                     cout, dil, hip.bs(x), hip.bs(gy), x_amax.ptr(), x_amax.n, gy_amax.ptr(), gy_amax.n, hip.stream())
+        elif use_x3 and dil > 1:
             hip.call("irr_conv2d_wgrad_x3_dil", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
                      cout, dil, hip.bs(x), hip.bs(gy), hip.stream())
         elif use_x3:

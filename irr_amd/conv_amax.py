@@ -1,0 +1,43 @@
+"""Amax slots of the fp16x2 ("h2") conv kernels (include/irr_hip.h, section "h2"; csrc/x3_split.h).
+
+fp16 has a 5-bit exponent, so the h2 kernels scale every operand tensor by a power of two derived -- on the device, no host
+round trip -- from max |.| of the whole tensor.  The maxima live in small float32 device tensors ("slots"); an operand assembled
+from several producers (a DenseNet buffer) carries one slot per part and the consumer takes the maximum over a run of slots.
+A slot is filled either by the producing launch itself (``y_amax`` of irr_conv2d_fwd_h2: an atomic max in its epilogue) or by one
+pass over the tensor (``measure``: irr_amax_f32, HBM-bound)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import hip
+from .conv_pack import LAUNCHES
+
+
+class Amax:
+    """``n`` consecutive float32 slots of ``slots`` starting at ``first``: their maximum bounds |t| of some tensor t"""
+    __slots__ = ("slots", "first", "n")
+
+    def __init__(self, slots: torch.Tensor, first: int = 0, n: int = 1):
+        assert slots.dtype == torch.float32 and slots.is_contiguous() and 0 <= first and first + n <= slots.numel() and n >= 1
+        self.slots, self.first, self.n = slots, int(first), int(n)
+
+    @staticmethod
+    def zeros(device, n: int = 1) -> "Amax":
+        return Amax(torch.zeros(n, device=device, dtype=torch.float32), 0, n)
+
+    def ptr(self) -> int:
+        return self.slots.data_ptr() + 4 * self.first
+
+    def sub(self, i: int, n: int = 1) -> "Amax":
+        return Amax(self.slots, self.first + i, n)
+
+
+def measure(x: torch.Tensor, into: Optional[Amax] = None) -> Amax:
+    """fold max |x| into a slot (a fresh zeroed one when ``into`` is None); x: (B, C, H, W) with dense planes"""
+    B, C, H, W = x.shape
+    a = into if into is not None else Amax.zeros(x.device, 1)
+    LAUNCHES["amax"] += 1
+    hip.call("irr_amax_f32", hip.ptr(x), B, C * H * W, hip.bs(x), a.ptr(), hip.stream())
+    return a

@@ -12,20 +12,22 @@ import torch
 
 from . import conv as _c
 from . import hip
-from .conv import _call_conv, conv_dgrad, conv_forward, conv_forward_skip, conv_wgrad, x3_code
+from .conv import Amax, _call_conv, _h2_args, amax_measure, conv_dgrad, conv_forward, conv_forward_skip, conv_wgrad, h2_code, x3_code
 from .conv_pack import LAUNCHES, _dense_column_packs, _padded_cin
 
 
 def wgrad_param(x, gy, weight, bias, stride: int, dil: int, want_bias: bool = True, alpha: float = 1.0,
-                acc=None):
+                acc=None, x_amax: Optional[Amax] = None, gy_amax: Optional[Amax] = None):
     """Weight (+bias) gradient of one conv use.  Returns (gw, gb) tensors for autograd -- or (None, None) when the
     result was accumulated asynchronously into the gradient arena (SIDE lane).  ``acc`` = optional (gw, gb) pair to
-    accumulate into (shared weights used several times inside one autograd node)."""
+    accumulate into (shared weights used several times inside one autograd node).
+    x_amax / gy_amax: the operands' amax slots (both given + MATH == "h2": the launch runs on the fp16x2 form)."""
     routed = _c.SIDE.route(weight, bias) if _c.SIDE is not None else None
     if routed is not None:
         gwv, gbv = routed
+        keep = (x, gy) if (x_amax is None or gy_amax is None) else (x, gy, x_amax.slots, gy_amax.slots)
         _c.SIDE.launch(lambda: conv_wgrad(x, gy, weight.shape, stride, dil, gw=gwv, gbias=gbv if want_bias else None,
-                                       alpha=alpha, defer=_c.SIDE.batch), (x, gy),
+                                       alpha=alpha, defer=_c.SIDE.batch, x_amax=x_amax, gy_amax=gy_amax), keep,
                     (weight, bias if (want_bias and gbv is not None) else None), gw=gwv)
         return None, None
     if acc is not None:
@@ -33,8 +35,21 @@ def wgrad_param(x, gy, weight, bias, stride: int, dil: int, want_bias: bool = Tr
     else:
         gw = None
         gb = torch.zeros(weight.shape[0], device=x.device, dtype=torch.float32) if (want_bias and bias is not None) else None
-    gw = conv_wgrad(x, gy, weight.shape, stride, dil, gw=gw, gbias=gb if want_bias else None, alpha=alpha)
+    gw = conv_wgrad(x, gy, weight.shape, stride, dil, gw=gw, gbias=gb if want_bias else None, alpha=alpha,
+                    x_amax=x_amax, gy_amax=gy_amax)
     return gw, gb
+
+
+def _fwd_h2(x, weight, stride: int, dil: int) -> bool:
+    """conv(x, weight) runs on the fp16x2 form"""
+    B, cin, H, W = x.shape
+    return bool(h2_code(B, cin, H, W, weight.shape[0], weight.shape[2], stride, dil))
+
+
+def _dgrad_h2(gy_shape, weight, stride: int, dil: int) -> bool:
+    """the stride-1 data gradient of conv(., weight) for an output gradient of gy_shape runs on the fp16x2 form"""
+    B, cout, oh, ow = gy_shape
+    return stride == 1 and cout >= 2 and bool(h2_code(B, cout, oh, ow, weight.shape[1], weight.shape[2], 1, dil))
 
 
 def lrelu_bwd_bias(gy: torch.Tensor, y: Optional[torch.Tensor], lrelu: bool, gpre: Optional[torch.Tensor],
@@ -57,13 +72,15 @@ class _ConvBlock(hip.Function):
         x = x if _planes_dense(x) else x.contiguous()
         if res is not None and not _planes_dense(res):
             res = res.contiguous()
+        xa = amax_measure(x) if _fwd_h2(x, weight, stride, dil) else None
         if res is None and alpha == 1.0:
-            y = conv_forward(x, weight, bias, stride, dil, lrelu)
+            y = conv_forward(x, weight, bias, stride, dil, lrelu, x_amax=xa)
             act = y
         else:
             # keep the activated conv output for the LeakyReLU derivative
-            act = conv_forward(x, weight, bias, stride, dil, lrelu)
+            act = conv_forward(x, weight, bias, stride, dil, lrelu, x_amax=xa)
             y = act * alpha if res is None else torch.add(res, act, alpha=alpha)
+        ctx.x_amax = xa
         ctx.cfg = (stride, dil, lrelu, alpha, res is not None)
         ctx.save_for_backward(x, weight, act if lrelu else None)
         ctx.has_bias = bias is not None
@@ -89,13 +106,16 @@ class _ConvBlock(hip.Function):
             lrelu_bwd_bias(g, act, lrelu, gpre, gb)                  # mask and bias gradient in one HBM pass
             if lrelu:
                 g = gpre
-        gx = conv_dgrad(g, ctx.weight_obj, stride, dil, x.shape[2:]) if ctx.needs_input_grad[0] else None
+        ga = None
+        if (ctx.x_amax is not None and want_w) or (ctx.needs_input_grad[0] and _dgrad_h2(g.shape, weight, stride, dil)):
+            ga = amax_measure(g)
+        gx = conv_dgrad(g, ctx.weight_obj, stride, dil, x.shape[2:], gy_amax=ga) if ctx.needs_input_grad[0] else None
         gw = None
         if want_w:
             if bias_in_wgrad:
-                gw, gb = wgrad_param(x, g, ctx.weight_obj, ctx.bias_obj, stride, dil, want_bias=True)
+                gw, gb = wgrad_param(x, g, ctx.weight_obj, ctx.bias_obj, stride, dil, want_bias=True, x_amax=ctx.x_amax, gy_amax=ga)
             else:
-                gw, _ = wgrad_param(x, g, ctx.weight_obj, None, stride, dil, want_bias=False)
+                gw, _ = wgrad_param(x, g, ctx.weight_obj, None, stride, dil, want_bias=False, x_amax=ctx.x_amax, gy_amax=ga)
         return gx, gw, gb, None, None, None, gres, None
 
 
@@ -166,11 +186,19 @@ class _DenseEstimatorFn(hip.Function):
         has_base = base is not None
         buf = torch.empty(B, ctot + (E if has_base else 0), H, W, device=parts[0].device, dtype=torch.float32)
         cat_channels_into(buf[:, 448:], parts)
+        # fp16x2 route: one amax slot per buffer part, in channel order [c5, c4, c3, c2, c1, x]; conv i+1 reads parts 5-i .. 5 and
+        # its launch folds the magnitude of its output into slot 4-i
+        S = None
+        if _fwd_h2(buf[:, 448:ctot], ws[0], 1, 1):
+            S = Amax.zeros(buf.device, 6)
+            amax_measure(buf[:, 448:ctot], S.sub(5))
         off = 448
         for i in range(5):
             co = _DenseEstimatorFn.GROW[i]
-            conv_forward(buf[:, off:ctot], ws[i], bs[i], 1, 1, True, out=buf[:, off - co:off])
+            conv_forward(buf[:, off:ctot], ws[i], bs[i], 1, 1, True, out=buf[:, off - co:off],
+                         x_amax=S.sub(5 - i, i + 1) if S is not None else None, y_amax=S.sub(4 - i) if S is not None else None)
             off -= co
+        ctx.amax = S
         if has_base:
             base_c = base if _planes_dense(base) else base.contiguous()
             out = conv_forward(buf[:, :ctot], ws[5], bs[5], 1, 1, False, res=base_c, alpha=1.0)
@@ -217,9 +245,19 @@ class _DenseEstimatorFn(hip.Function):
             conv_dgrad(g_est, ws[5], 1, 1, (H, W), gx=G[:, :ctot], accumulate=True, mask=buf[:, :ctot], nmask=32)
         else:
             lrelu_bwd_bias(G[:, :32], buf[:, :32], True, G[:, :32], None)
-        use_x3 = [bool(x3_code(B, t0, H, W, t1 - t0, 3, 1, 1)) for (t0, t1) in ((32, 96), (96, 192), (192, 320), (320, 448), (448, ctot))]
+        use_x3 = [(2 if (h2_code(B, t0, H, W, t1 - t0, 3, 1, 1)) else 1) if x3_code(B, t0, H, W, t1 - t0, 3, 1, 1) else 0
+                  for (t0, t1) in ((32, 96), (96, 192), (192, 320), (320, 448), (448, ctot))]
         packs = _dense_column_packs(ctx.wobjs[:5], cin0, tuple(use_x3))
-        grads_w[4], grads_b[4] = wgrad_param(buf[:, 32:ctot], G[:, :32], ctx.wobjs[4], ctx.bobjs[4], 1, 1)   # conv5
+        # fp16x2 route: one amax slot per slice of G, in channel order [g5, g4, g3, g2, g1, gx]; column k reads slices 0 .. k and
+        # folds the magnitude of the slice it completes into slot k+1
+        S = ctx.amax
+        Gs = None
+        if S is not None or any(u == 2 for u in use_x3):
+            Gs = Amax.zeros(dev, 6)
+            amax_measure(G[:, :32], Gs.sub(0))
+        grads_w[4], grads_b[4] = wgrad_param(buf[:, 32:ctot], G[:, :32], ctx.wobjs[4], ctx.bobjs[4], 1, 1,
+                                             x_amax=S.sub(1, 5) if S is not None else None,
+                                             gy_amax=Gs.sub(0) if Gs is not None else None)   # conv5
         bounds = [(32, 96), (96, 192), (192, 320), (320, 448), (448, ctot)]
         for k_, (t0, t1) in enumerate(bounds):
             last = k_ == 4
@@ -230,11 +268,14 @@ class _DenseEstimatorFn(hip.Function):
             # cost-volume gradient kernels no longer read their 81-plane output)
             nm = (nrelu if last else t1 - t0)
             margs = (hip.ptr(buf[:, t0:t1]), hip.bs(buf), nm) if nm > 0 else (None, 0, 0)
-            LAUNCHES["dense_column_x3" if use_x3[k_] else "dense_column_f32"] += 1
+            LAUNCHES["dense_column_h2" if use_x3[k_] == 2 else "dense_column_x3" if use_x3[k_] else "dense_column_f32"] += 1
             if use_x3[k_]:
                 args = ("irr_conv2d_fwd_x3", hip.ptr(G), hip.ptr(packs[k_]), None, None, hip.ptr(G[:, t0:t1]), B, t0, H, W,
                         t1 - t0, 1, hip.bs(G), hip.bs(G), 0, 0, 1.0, 1, *margs, hip.stream())
                 variant = 100000 + x3_code(B, t0, H, W, t1 - t0, 3, 1, 1)
+                if use_x3[k_] == 2:
+                    args, _ = _h2_args(args, G[:, :t0], Gs.sub(0, k_ + 1), Gs.sub(k_ + 1) if not last else None)
+                    variant += 100000
             else:
                 args = ("irr_conv2d_fwd_f32", hip.ptr(G), hip.ptr(packs[k_]), None, None, hip.ptr(G[:, t0:t1]), B, t0, H, W,
                         t1 - t0, H, W, 3, 1, 1, hip.bs(G), hip.bs(G), 0, 0, 1.0, 1, *margs, hip.stream())
@@ -245,7 +286,11 @@ class _DenseEstimatorFn(hip.Function):
                 _c.TIMER.wrap(variant, 2.0 * B * H * W * t0 * (t1 - t0) * 9, lambda: _call_conv(args), "dgrad")
             if not last:                                   # G[:, t0:t1] is now the pre-activation gradient of conv(4-k_)
                 i = 3 - k_
-                grads_w[i], grads_b[i] = wgrad_param(buf[:, t1:ctot], G[:, t0:t1], ctx.wobjs[i], ctx.bobjs[i], 1, 1)
+                if Gs is not None and use_x3[k_] != 2:
+                    amax_measure(G[:, t0:t1], Gs.sub(k_ + 1))
+                grads_w[i], grads_b[i] = wgrad_param(buf[:, t1:ctot], G[:, t0:t1], ctx.wobjs[i], ctx.bobjs[i], 1, 1,
+                                                     x_amax=S.sub(k_ + 2, 4 - k_) if S is not None else None,
+                                                     gy_amax=Gs.sub(k_ + 1) if (Gs is not None and S is not None) else None)
         # g_est is still being read by the asynchronous wgrad lane (conv_last): autograd gets its own copy, because
         # the engine may accumulate the other gradients of `base` into the returned tensor IN PLACE
         gbase = g_est.clone() if (has_base and ctx.needs_input_grad[1]) else None
@@ -294,21 +339,35 @@ class _ConvChainFn(hip.Function):
         acts = []
         cur = x
         n = len(ws)
+        # fp16x2 route: in_amax[i] = amax slot of layer i's input where that layer runs on the h2 kernel -- the chain input is
+        # measured, every other slot is filled by the producing layer's launch (y_amax)
+        shapes = [tuple(x.shape)]
+        for i in range(n):
+            oh, ow = _c.out_hw(shapes[-1][2], shapes[-1][3], ws[i].shape[2], cfg[i][0], cfg[i][1])
+            shapes.append((shapes[-1][0], ws[i].shape[0], oh, ow))
+        h2_in = [bool(h2_code(shapes[i][0], shapes[i][1], shapes[i][2], shapes[i][3], ws[i].shape[0], ws[i].shape[2], cfg[i][0], cfg[i][1]))
+                 for i in range(n)]
+        slots = Amax.zeros(x.device, n) if any(h2_in) else None
+        in_amax = [slots.sub(i) if h2_in[i] else None for i in range(n)]
+        if h2_in[0]:
+            amax_measure(x, in_amax[0])
         for i in range(n):
             stride, dil, lrelu = cfg[i]
             last = i == n - 1
+            ya = in_amax[i + 1] if not last else None
             if last and res is not None:
                 res_c = res if _planes_dense(res) else res.contiguous()
                 if lrelu:
-                    a = conv_forward(cur, ws[i], bs[i], stride, dil, True)      # keep the activation for its mask
+                    a = conv_forward(cur, ws[i], bs[i], stride, dil, True, x_amax=in_amax[i])      # keep the activation for its mask
                     acts.append(a)
                     cur = torch.add(res_c, a)
                 else:
-                    cur = conv_forward(cur, ws[i], bs[i], stride, dil, False, res=res_c)
+                    cur = conv_forward(cur, ws[i], bs[i], stride, dil, False, res=res_c, x_amax=in_amax[i])
                     acts.append(None)
             else:
-                cur = conv_forward(cur, ws[i], bs[i], stride, dil, lrelu)
+                cur = conv_forward(cur, ws[i], bs[i], stride, dil, lrelu, x_amax=in_amax[i], y_amax=ya)
                 acts.append(cur)
+        ctx.in_amax = in_amax
         ctx.cfg = cfg
         ctx.has_res = res is not None
         ctx.weight_objs = ws
@@ -335,18 +394,35 @@ class _ConvChainFn(hip.Function):
             lrelu_bwd_bias(gy, a_last, True, gpre, None)
             g = gpre
         grads = [None] * (2 * n)
+        in_amax = ctx.in_amax
+        # layer i wants the magnitude of ITS output gradient when its weight gradient (input slot known) or its data gradient runs on
+        # the h2 kernels; the data-gradient launch of layer i+1 folds it into a slot, the chain's own output gradient is measured
+        gshape = [None] * n
+        hw_ = tuple(x.shape)
+        for i in range(n):
+            oh, ow = _c.out_hw(hw_[2], hw_[3], ws[i].shape[2], cfg[i][0], cfg[i][1])
+            hw_ = (hw_[0], ws[i].shape[0], oh, ow)
+            gshape[i] = hw_
+        need_g = [in_amax[i] is not None or ((i > 0 or ctx.needs_input_grad[0]) and _dgrad_h2(gshape[i], ws[i], cfg[i][0], cfg[i][1]))
+                  for i in range(n)]
+        gslots = Amax.zeros(dev, n) if any(need_g) else None
+        ga = None
+        if need_g[n - 1]:
+            ga = amax_measure(g, gslots.sub(n - 1))
         for i in range(n - 1, -1, -1):
             stride, dil, _ = cfg[i]
             inp = acts[i - 1] if i > 0 else x
-            grads[2 * i], grads[2 * i + 1] = wgrad_param(inp, g, ws[i], ctx.bias_objs[i], stride, dil)
+            grads[2 * i], grads[2 * i + 1] = wgrad_param(inp, g, ws[i], ctx.bias_objs[i], stride, dil, x_amax=in_amax[i], gy_amax=ga)
+            gxa = gslots.sub(i - 1) if (i > 0 and need_g[i - 1]) else None
             if i > 0:
                 prev_lrelu = cfg[i - 1][2]
                 g = conv_dgrad(g, ws[i], stride, dil, inp.shape[2:], mask=inp if prev_lrelu else None,
-                               nmask=inp.shape[1] if prev_lrelu else 0)
+                               nmask=inp.shape[1] if prev_lrelu else 0, gy_amax=ga, gx_amax=gxa)
             elif ctx.needs_input_grad[0]:
-                g = conv_dgrad(g, ws[i], stride, dil, inp.shape[2:])
+                g = conv_dgrad(g, ws[i], stride, dil, inp.shape[2:], gy_amax=ga)
             else:
                 g = None
+            ga = gxa
         return (g, gres, None) + tuple(grads)
 
 

@@ -31,6 +31,8 @@ class _PackRegistry:
         self.version = 0
         self.epoch = WEIGHT_EPOCH[0]
         self._table = None              # (signature, device table, njobs, nblocks)
+        self.amax_sources = {}          # id(weight) -> (weakref(weight), its one-element max |w| tensor): the h2 packs' scales
+        self.amax_groups = []           # (weakrefs of the weights of a combined matrix, its one-element group maximum)
 
     def register(self, key, weight, dst, builder, retag):
         if key in self.entries:
@@ -69,12 +71,34 @@ class _PackRegistry:
             host = torch.frombuffer(buf, dtype=torch.uint8).clone()
             self._table = (sig, host.to(self.device), len(live), block0)
         _, table, njobs, nblocks = self._table
+        self.refresh_amax()
         with hip.device_of(table):
             hip.call("irr_conv_pack_batch", hip.ptr(table), njobs, nblocks, hip.stream())
         LAUNCHES["pack_batch"] += 1
         for _, e, _ in live:
             e[3]()
         return True
+
+
+    def refresh_amax(self) -> None:
+        """max |w| of every weight with an h2 pack (one multi-tensor launch + one copy per weight's slot) and the group maxima of
+        the combined matrices -- before the batched repack reads them"""
+        live = []
+        for key, (ref, t) in list(self.amax_sources.items()):
+            w = ref()
+            if w is None:
+                del self.amax_sources[key]
+            else:
+                live.append((w.detach(), t))
+        if not live:
+            return
+        norms = torch._foreach_norm([w for w, _ in live], float("inf"))
+        torch._foreach_copy_([t for _, t in live], [n_.reshape(1) for n_ in norms])
+        LAUNCHES["amax_weights"] += 1
+        for refs, g in self.amax_groups:
+            ws = [r() for r in refs]
+            if all(w is not None for w in ws):
+                torch.amax(torch.cat([w.__dict__["_irr_amax"] for w in ws]).reshape(1, -1), dim=1, out=g)
 
 
 _REGISTRIES = {}
@@ -100,7 +124,7 @@ def _announce_rewrite(reg: _PackRegistry, old_tag, new_tag) -> None:
         WEIGHT_EPOCH[0] += 1
 
 
-def _packed(weight: torch.Tensor, transpose: bool, slot: str, nbytes_fn, dtype, single, builder_name):
+def _packed(weight: torch.Tensor, transpose: bool, slot: str, nbytes_fn, dtype, single, builder_name, amax=None):
     """shared body of packed_weights / packed_weights_x3: cache ON the tensor object (so it dies with the parameter and can
     never be confused with another tensor that later reuses the same address), refreshed whenever the parameter's storage,
     version counter or the weight epoch changes -- through the batched launch when the copy is already registered."""
@@ -139,6 +163,9 @@ def _packed(weight: torch.Tensor, transpose: bool, slot: str, nbytes_fn, dtype, 
         fn = getattr(hip.lib(), builder_name)
         if builder_name == "irr_conv_pack_job_f32":
             builder = lambda job, wptr, wp=wp: fn(job, wptr, wp.data_ptr(), lcin, lcout, k, int(transpose))
+        elif builder_name == "irr_conv_pack_job_h2":
+            at = amax(weight)                                  # (the one-element tensor, not the parameter: entries hold weak references)
+            builder = lambda job, wptr, wp=wp, at=at: fn(job, wptr, wp.data_ptr(), lcin, lcout, int(transpose), at.data_ptr())
         else:
             builder = lambda job, wptr, wp=wp: fn(job, wptr, wp.data_ptr(), lcin, lcout, int(transpose))
         reg.register((id(weight), slot, key), weight, wp, builder, retag)
@@ -167,12 +194,40 @@ def packed_weights_x3(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
 
 
 
+# ---- fp16x2 ("h2") packs: one power-of-two scale per packed matrix, from max |w| -----------------------------------------------
+# Every weight that has an h2 pack owns a persistent one-element device tensor with its max |w| (cached on the parameter).  The
+# registry refreshes ALL of them with one multi-tensor launch right before the batched repack (_PackRegistry.refresh), so the
+# pack jobs -- which keep the tensors' addresses -- always read current values.
+def _weight_amax(weight: torch.Tensor) -> torch.Tensor:
+    t = weight.__dict__.get("_irr_amax")
+    if t is None or t.device != weight.device:
+        t = weight.__dict__["_irr_amax"] = torch.zeros(1, device=weight.device, dtype=torch.float32)
+        _registry(weight.device).amax_sources[id(weight)] = (weakref.ref(weight), t)
+    return t
+
+
+def _refresh_weight_amax(weight: torch.Tensor) -> torch.Tensor:
+    t = _weight_amax(weight)
+    torch.amax(weight.detach().abs().reshape(1, -1), dim=1, out=t)
+    return t
+
+
+def packed_weights_h2(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
+    """Pre-split (2 x fp16 of w * 2^e) packed copy of ``weight`` for irr_conv2d_fwd_h2 (see _packed)"""
+    assert weight.shape[2] == 3
+    return _packed(weight, transpose, "_irr_packed_h2", lambda ci, co, k: hip.lib().irr_conv_h2_packed_bytes(ci, co), torch.uint8,
+                   lambda wc, wp, ci, co, k, tr: hip.call("irr_conv_pack_weights_h2", hip.ptr(wc), hip.ptr(wp), ci, co, tr,
+                                                          hip.ptr(_refresh_weight_amax(weight)), hip.stream()),
+                   "irr_conv_pack_job_h2", amax=_weight_amax)
+
+
 def _dense_column_packs(ws5, cin0: int, use_x3=(False,) * 5):
     """Combined (transposed, flipped) packed weights for the five column targets c4, c3, c2, c1, x of the DenseNet
     buffer; cached on the first weight tensor (per kernel-family choice) and rebuilt when any of the five conv weights
     changed -- as sub-jobs of the batched pack launch once they are registered.  The buffers are allocated (zeroed) once:
     rows and columns that no layer covers stay zero, the sub-jobs only rewrite what they own.
-    use_x3[k]: column k runs on irr_conv2d_fwd_x3 and needs the pre-split layout."""
+    use_x3[k]: 0 = column k runs on the fp32 kernel, 1 = on irr_conv2d_fwd_x3 (bf16x3 pre-split layout), 2 = on irr_conv2d_fwd_h2
+    (fp16x2 layout; the five matrices share ONE scale, the maximum over the block's five weights)."""
     def cur_tags():
         return tuple((w.data_ptr(), w._version) for w in ws5) + (WEIGHT_EPOCH[0], cin0)
     tags = cur_tags()
@@ -195,6 +250,13 @@ def _dense_column_packs(ws5, cin0: int, use_x3=(False,) * 5):
     packs = [] if fresh else holder["packs"]
     lib = hip.lib()
     wrefs = [weakref.ref(w) for w in ws5]
+    gamax = None
+    if any(u == 2 for u in use_x3):
+        gamax = holder.get("gamax")
+        if gamax is None:
+            gamax = holder["gamax"] = torch.zeros(1, device=dev, dtype=torch.float32)
+            reg.amax_groups.append((wrefs, gamax))
+        torch.amax(torch.cat([_refresh_weight_amax(w) for w in ws5]).reshape(1, -1), dim=1, out=gamax)
 
     def retag(holder=holder, wrefs=wrefs):
         live = [r() for r in wrefs]
@@ -205,7 +267,9 @@ def _dense_column_packs(ws5, cin0: int, use_x3=(False,) * 5):
         n = t1 - t0
         cop = (n + 31) // 32 * 32
         if fresh:
-            if use_x3[k_]:
+            if use_x3[k_] == 2:
+                packs.append(torch.zeros(lib.irr_conv_h2_packed_bytes(t0, n), device=dev, dtype=torch.uint8))
+            elif use_x3[k_]:
                 packs.append(torch.zeros(lib.irr_conv_x3_packed_bytes(t0, n), device=dev, dtype=torch.uint8))
             else:
                 packs.append(torch.zeros(lib.irr_conv_packed_weight_elems(t0, n, 3), device=dev, dtype=torch.float32))
@@ -216,7 +280,11 @@ def _dense_column_packs(ws5, cin0: int, use_x3=(False,) * 5):
             wsrc = ws5[i - 1]
             w = wsrc.detach().contiguous()
             wcin, wcout, c0 = w.shape[1], w.shape[0], t0 - in0[i - 1]
-            if use_x3[k_]:
+            if use_x3[k_] == 2:
+                hip.call("irr_conv_pack_weights_h2_sub", hip.ptr(w), hip.ptr(wp), wcin, wcout, t0, c0, n, row0[i], hip.ptr(gamax), hip.stream())
+                builder = (lambda job, wptr, wp=wp, a=(wcin, wcout, t0, c0, n, row0[i]), g=gamax:
+                           lib.irr_conv_pack_job_h2_sub(job, wptr, wp.data_ptr(), *a, g.data_ptr()))
+            elif use_x3[k_]:
                 hip.call("irr_conv_pack_weights_x3_sub", hip.ptr(w), hip.ptr(wp), wcin, wcout, t0, c0, n, row0[i], hip.stream())
                 builder = (lambda job, wptr, wp=wp, a=(wcin, wcout, t0, c0, n, row0[i]):
                            lib.irr_conv_pack_job_x3_sub(job, wptr, wp.data_ptr(), *a))

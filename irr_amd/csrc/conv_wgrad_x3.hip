@@ -66,6 +66,10 @@ struct WX3Args {
   int cols_per_block;
   unsigned long long* dbg;       // WX3_TRACE builds only
   int ngx, ngy, ngz;             // logical grid: block columns x ci tiles x co tiles (launched as a 1-D grid, see the kernel)
+  // H2 instantiations (fp16x2 of scaled operands, x3_split.h): device slots whose maxima bound |x| and |gy| (kernel roles)
+  const float* x_amax;
+  const float* g_amax;
+  int nx_amax, ng_amax;
 };
 
 
@@ -76,8 +80,10 @@ __device__ __forceinline__ uint32_t alignbit16(uint32_t hi, uint32_t lo) { retur
 // DIL > 1 (dilated context-network layers): the three vertical taps are DIL rows apart, so a column additionally fixes a
 // row residue and walks rows res, res + DIL, res + 2 DIL, ...: in that walk the taps are again neighbouring rows and the
 // ring works unchanged.  The +-DIL column taps are whole dwords (DIL = 2, 4) or whole groups (8, 16) of the neighbours.
-template <int MW, int NW, int KG, int R, int KW = 1, int DIL = 1, bool NARROW = false>
+// H2: the operands as two fp16 pieces of x * 2^ex / gy * 2^eg (three piece products per k-step instead of six); the flush scales back.
+template <int MW, int NW, int KG, int R, int KW = 1, int DIL = 1, bool NARROW = false, bool H2 = false>
 __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const WX3Args a) {
+  constexpr int NP = H2 ? 2 : 3;                            // pieces per operand
   constexpr int NTHR = MW * NW * KW * 64;
   constexpr int RING = 2 * R + 2;                          // x rows resident
   constexpr int MG = DIL > 8 ? DIL / 8 : 1;                // margin groups on each side of a staged x row
@@ -116,8 +122,14 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   static_assert((R * KG) % 2 == 0, "a unit must hold an even number of 8-pixel groups");
   static_assert(NK % KW == 0, "the k-steps of a unit must divide evenly among the wave groups");
   extern __shared__ u32x4 lds[];
-  u32x4* const xs = lds;                                   // [3][32*NW][XPITCH]
-  u32x4* const gs = lds + 3 * XPLANE;                      // [3][32*MW][GPITCH]
+  u32x4* const xs = lds;                                   // [NP][32*NW][XPITCH]
+  u32x4* const gs = lds + NP * XPLANE;                     // [NP][32*MW][GPITCH]
+  float sx = 1.f, sg = 1.f, unscale_x = 1.f, unscale_g = 1.f;
+  if (H2) {
+    const int ex = x3_h2_exp(x3_h2_amax(a.x_amax, a.nx_amax)), eg = x3_h2_exp(x3_h2_amax(a.g_amax, a.ng_amax));
+    sx = ldexpf(1.f, ex); unscale_x = ldexpf(1.f, -ex);
+    sg = ldexpf(1.f, eg); unscale_g = ldexpf(1.f, -eg);
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -266,13 +278,22 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
         if (mu[r] < 0) continue;
         // one value -> three bf16 pieces (same rounding sequence as split8), each into its half-dword of the margin slot
         const float v0 = mraw[r];
-        const uint32_t hp = pk_bf16(v0, 0.f);
-        float r0 = v0 - lo_f(hp);
-        asm volatile("" : "+v"(r0));
-        const uint32_t mp = pk_bf16(r0, 0.f);
-        float s0 = r0 - lo_f(mp);
-        asm volatile("" : "+v"(s0));
-        const uint32_t lp = pk_bf16(s0, 0.f);
+        uint32_t hp, mp, lp = 0;
+        if (H2) {
+          const float a0 = v0 * sx;
+          const _Float16 hh = (_Float16)a0;
+          const _Float16 ll = (_Float16)(a0 - (float)hh);
+          hp = __builtin_bit_cast(unsigned short, hh);
+          mp = __builtin_bit_cast(unsigned short, ll);
+        } else {
+          hp = pk_bf16(v0, 0.f);
+          float r0 = v0 - lo_f(hp);
+          asm volatile("" : "+v"(r0));
+          mp = pk_bf16(r0, 0.f);
+          float s0 = r0 - lo_f(mp);
+          asm volatile("" : "+v"(s0));
+          lp = pk_bf16(s0, 0.f);
+        }
         const int side = RU_GRP(mu[r]);
         const int slot = (row0 + RU_RR(mu[r]) + RING) % RING;
         const int idx = RU_CH(mu[r]) * XPITCH + slot * XG + (side ? KG + MG : MG - 1);
@@ -280,7 +301,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
         const int sh = side ? 0 : 16;                        // left margin: pixel c0-1 is the HIGH half of dword 3
         w[0] = (hp & 0xffffu) << sh;
         w[XPLANE * 4] = (mp & 0xffffu) << sh;
-        w[2 * XPLANE * 4] = (lp & 0xffffu) << sh;
+        if (NP == 3) w[2 * XPLANE * 4] = (lp & 0xffffu) << sh;
       }
 #pragma unroll
       for (int r = 0; r < XR; ++r) {
@@ -294,13 +315,14 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
 #if WX3_ABL == 1
         h = __builtin_bit_cast(u32x4, xraw[r][0]); m = __builtin_bit_cast(u32x4, xraw[r][1]); l = h; (void)v;
 #else
-        split8(v, h, m, l);
+        if (H2) split8_h2(v, sx, h, m);
+        else split8(v, h, m, l);
 #endif
         const int slot = (row0 + RU_RR(xu[r]) + RING) % RING;      // rows >= -1
         const int idx = RU_CH(xu[r]) * XPITCH + slot * XG + RU_GRP(xu[r]) + GOFS;
         xs[idx] = h;
         xs[idx + XPLANE] = m;
-        xs[idx + 2 * XPLANE] = l;
+        if (NP == 3) xs[idx + 2 * XPLANE] = l;
       }
       if (XB && row0 + R > col_row_lo) col_row_lo = row0 + R;      // rows below are counted
     }
@@ -314,12 +336,13 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
 #if WX3_ABL == 1
         h = __builtin_bit_cast(u32x4, graw[r][0]); m = __builtin_bit_cast(u32x4, graw[r][1]); l = h;
 #else
-        split8(v, h, m, l);
+        if (H2) split8_h2(v, sg, h, m);
+        else split8(v, h, m, l);
 #endif
         const int idx = RU_CH(gu[r]) * GPITCH + (gbuf * R + RU_RR(gu[r])) * KG + RU_GRP(gu[r]);
         gs[idx] = h;
         gs[idx + GPLANE] = m;
-        gs[idx + 2 * GPLANE] = l;
+        if (NP == 3) gs[idx + 2 * GPLANE] = l;
       }
     }
   };
@@ -334,7 +357,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   // 96 .. 288: 2-4 % SLOWER on every shape.  LDS latency is not what holds a lone wave at 70 % MFMA density)
   auto compute = [&](int y, int gbuf) {
     constexpr int NKW = NK / KW;                           // this wave's k-steps: wk, wk + KW, ...
-    u32x4 af[3];
+    u32x4 af[NP];
     auto b_index = [&](int ki, int dy, int q) {
       const int ks = wk + KW * ki;
       const int gi = 2 * ks + g;
@@ -348,10 +371,11 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       const int row = gi / KG, grp = gi - row * KG;
       af[p] = gs[a_base + (gbuf * R + row) * KG + grp + p * GPLANE];
     };
-    constexpr int NS = NKW * 9;
+    constexpr int SPK = 3 * NP;                            // stages per k-step: (dy, B piece q)
+    constexpr int NS = NKW * SPK;
     u32x4 ob[2], lb[2], rb[2];                             // the group and its left / right neighbours (DIL <= 2: one dword each)
     auto read_b = [&](int sel, int st) {
-      const int xi = b_index(st / 9, (st % 9) / 3, st % 3);
+      const int xi = b_index(st / SPK, (st % SPK) / NP, st % NP);
       ob[sel] = xs[xi];
       if (WX3_ABL == 2) {
       } else if (DIL <= 2) {
@@ -369,14 +393,14 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     };
     auto read_a = [&](int ki) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) read_a1(ki, p);
+      for (int p = 0; p < NP; ++p) read_a1(ki, p);
     };
     read_a(0);
     read_b(0, 0);
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
       const int cur = st & 1;
-      const int dy = (st % 9) / 3, q = st % 3;
+      const int dy = (st % SPK) / NP, q = st % NP;
       if (st + 1 < NS) read_b(cur ^ 1, st + 1);
       __builtin_amdgcn_sched_barrier(0);
       const u32x4 o = ob[cur];
@@ -405,13 +429,19 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       }
       // products of weight >= 2^-17: (A piece, B piece) in {(l,h),(m,h),(h,h),(m,m),(h,m),(h,l)}
 #pragma unroll
-      for (int pa = 2; pa >= 0; --pa) {
-        if (pa + q > 2) continue;
-        acc[dy * 3 + 0] = mma(af[pa], fm, acc[dy * 3 + 0]);
-        acc[dy * 3 + 1] = mma(af[pa], o, acc[dy * 3 + 1]);
-        acc[dy * 3 + 2] = mma(af[pa], fp, acc[dy * 3 + 2]);
+      for (int pa = NP - 1; pa >= 0; --pa) {
+        if (pa + q > (WX3_ABL == 20 ? 1 : NP - 1)) continue;      // (ablation 20, timing only: three products of two pieces)
+        if constexpr (H2) {
+          acc[dy * 3 + 0] = mma_h(af[pa], fm, acc[dy * 3 + 0]);
+          acc[dy * 3 + 1] = mma_h(af[pa], o, acc[dy * 3 + 1]);
+          acc[dy * 3 + 2] = mma_h(af[pa], fp, acc[dy * 3 + 2]);
+        } else {
+          acc[dy * 3 + 0] = mma(af[pa], fm, acc[dy * 3 + 0]);
+          acc[dy * 3 + 1] = mma(af[pa], o, acc[dy * 3 + 1]);
+          acc[dy * 3 + 2] = mma(af[pa], fp, acc[dy * 3 + 2]);
+        }
       }
-      if (st % 9 == 8 && st + 1 < NS) read_a(st / 9 + 1);   // next k-step's gy fragments (after their last use)
+      if (st % SPK == SPK - 1 && st + 1 < NS) read_a(st / SPK + 1);   // next k-step's gy fragments (after their last use)
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -553,7 +583,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
       const int ci = ci0 + wn * 32 + j;
-      if (co < a.Cout && ci < a.Cin) wsp[((long)co * 9 + t) * a.Cin + ci] = a.alpha * acc[t][r];
+      if (co < a.Cout && ci < a.Cin) wsp[((long)co * 9 + t) * a.Cin + ci] = H2 ? a.alpha * ((acc[t][r] * unscale_x) * unscale_g) : a.alpha * acc[t][r];
     }
   }
   if constexpr (XB) if (a.xbias && bz == 0) {
@@ -608,16 +638,17 @@ long ws_capacity(int Cin, int Cout) {
   return parts * n;
 }
 
-template <int MW, int NW, int KG, int R, int KW = 1, int DIL = 1, bool NARROW = false>
-int launch_wx3(WX3Args a, hipStream_t st) {
+template <int MW, int NW, int KG, int R, int KW = 1, int DIL = 1, bool NARROW = false, bool H2 = false>
+int launch_wx3_np(WX3Args a, hipStream_t st) {
   constexpr int RING = 2 * R + 2, XG = KG + 2 * (DIL > 8 ? DIL / 8 : 1);
-  constexpr size_t lds_stage = 16 * (3 * (size_t)(32 * NW) * (RING * XG + 1) + 3 * (size_t)(32 * MW) * (2 * R * KG + 1));
+  constexpr size_t NPC = H2 ? 2 : 3;
+  constexpr size_t lds_stage = 16 * (NPC * (size_t)(32 * NW) * (RING * XG + 1) + NPC * (size_t)(32 * MW) * (2 * R * KG + 1));
   constexpr size_t lds_red = KW > 1 ? (size_t)(KW / 2) * MW * NW * 144 * 64 * 4 : 0;
   constexpr size_t lds_bytes = lds_stage > lds_red ? lds_stage : lds_red;
   static_assert(lds_bytes <= 160 * 1024, "unit does not fit the 160 KiB LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e0 = hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<MW, NW, KG, R, KW, DIL, NARROW>,
+    hipError_t e0 = hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<MW, NW, KG, R, KW, DIL, NARROW, H2>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e0 != hipSuccess) return (int)e0;
     attr_set = true;
@@ -675,12 +706,18 @@ int launch_wx3(WX3Args a, hipStream_t st) {
 #endif
   a.n = (long)a.Cout * 9 * a.Cin;
   if ((long)a.ngx * a.n > ws_capacity(a.Cin, a.Cout)) return IRR_EINVAL;      // (cannot happen: gx <= want)
-  hipLaunchKernelGGL((conv_wgrad_x3_kernel<MW, NW, KG, R, KW, DIL, NARROW>), dim3((unsigned)a.ngx * gy_ * gz_), dim3(MW * NW * KW * 64),
+  hipLaunchKernelGGL((conv_wgrad_x3_kernel<MW, NW, KG, R, KW, DIL, NARROW, H2>), dim3((unsigned)a.ngx * gy_ * gz_), dim3(MW * NW * KW * 64),
                      lds_bytes, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   g_last_parts = a.ngx;
   return 0;
+}
+
+// (a.x_amax set: the fp16x2 instantiation)
+template <int MW, int NW, int KG, int R, int KW = 1, int DIL = 1, bool NARROW = false>
+int launch_wx3(const WX3Args& a, hipStream_t st) {
+  return a.x_amax ? launch_wx3_np<MW, NW, KG, R, KW, DIL, NARROW, true>(a, st) : launch_wx3_np<MW, NW, KG, R, KW, DIL, NARROW, false>(a, st);
 }
 
 // (KG, R) by image width: strips of KG groups must tile the row without waste
@@ -779,14 +816,16 @@ static int launch_dil(const WX3Args& a, int kg, hipStream_t st) {
   return launch_wx3<MW, 2, 1, 2, 1, DIL>(a, st);
 }
 
-extern "C" int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
-                                       int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs, void* stream) {
+static int wgrad_x3_dil_impl(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
+                             int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs, const float* x_amax, int nx,
+                             const float* g_amax, int ng, void* stream) {
   if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (W % 4) || !dil_ok(Cout, W, dil)) return IRR_EINVAL;
   const long n = (long)Cout * Cin * 9;
   hipStream_t st = (hipStream_t)stream;
   WX3Args a;
   a.ws = ws; a.gbias = gbias; a.xbias = nullptr; a.alpha = alpha;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.x_bs = x_bs; a.gy_bs = gy_bs;
+  a.x_amax = x_amax; a.nx_amax = nx; a.g_amax = g_amax; a.ng_amax = ng;
   const long lim = (1L << 29) - 64;
   const long bsmax = x_bs > gy_bs ? x_bs : gy_bs;
   long per = bsmax > 0 ? (lim - (long)(Cin > Cout ? Cin : Cout) * H * W) / bsmax : B;
@@ -812,8 +851,14 @@ extern "C" int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* g
   return 0;
 }
 
-extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
-                                   int Cin, int H, int W, int Cout, long x_bs, long gy_bs, void* stream) {
+extern "C" int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
+                                       int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs, void* stream) {
+  return wgrad_x3_dil_impl(x, gy, gw, ws, gbias, alpha, B, Cin, H, W, Cout, dil, x_bs, gy_bs, nullptr, 0, nullptr, 0, stream);
+}
+
+static int wgrad_x3_impl(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
+                         int Cin, int H, int W, int Cout, long x_bs, long gy_bs, const float* x_amax, int nx,
+                         const float* g_amax, int ng, void* stream) {
   if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return IRR_EINVAL;
   if ((W % 4) && (((uintptr_t)x | (uintptr_t)gy) & 3)) return IRR_EINVAL;
   const long n = (long)Cout * Cin * 9;
@@ -840,6 +885,8 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
   a.Cout = swapped ? Cin : Cout;
   a.x_bs = swapped ? gy_bs : x_bs;
   a.gy_bs = swapped ? x_bs : gy_bs;
+  a.x_amax = swapped ? g_amax : x_amax; a.nx_amax = swapped ? ng : nx;
+  a.g_amax = swapped ? x_amax : g_amax; a.ng_amax = swapped ? nx : ng;
   const long lim = (1L << 29) - 64;                                        // elements: byte voffsets below the 2 GiB marker
   const long bsmax = x_bs > gy_bs ? x_bs : gy_bs;
   long per = bsmax > 0 ? (lim - (long)(Cin > Cout ? Cin : Cout) * H * W) / bsmax : B;
@@ -879,4 +926,19 @@ extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, f
     if (rr) return rr;
   }
   return 0;
+}
+
+extern "C" int irr_conv2d_wgrad_x3(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
+                                   int Cin, int H, int W, int Cout, long x_bs, long gy_bs, void* stream) {
+  return wgrad_x3_impl(x, gy, gw, ws, gbias, alpha, B, Cin, H, W, Cout, x_bs, gy_bs, nullptr, 0, nullptr, 0, stream);
+}
+
+// The two launches above on the fp16x2 form (dil = 1: irr_conv2d_wgrad_x3's problems, else irr_conv2d_wgrad_x3_dil's; same
+// eligibility, scratch and fold): x_amax[0 .. nx) / gy_amax[0 .. ng) = device slots whose maxima bound |x| / |gy|.
+extern "C" int irr_conv2d_wgrad_h2(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
+                                   int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs, const float* x_amax, int nx,
+                                   const float* gy_amax, int ng, void* stream) {
+  if (!x_amax || !gy_amax || nx <= 0 || ng <= 0 || dil < 1) return IRR_EINVAL;
+  if (dil > 1) return wgrad_x3_dil_impl(x, gy, gw, ws, gbias, alpha, B, Cin, H, W, Cout, dil, x_bs, gy_bs, x_amax, nx, gy_amax, ng, stream);
+  return wgrad_x3_impl(x, gy, gw, ws, gbias, alpha, B, Cin, H, W, Cout, x_bs, gy_bs, x_amax, nx, gy_amax, ng, stream);
 }

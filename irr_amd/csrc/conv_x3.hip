@@ -59,7 +59,57 @@ struct X3Args {
   int ngy;                                 // co-tile groups per pixel tile (folded into the 1-D x grid, see the kernel)
   int ksplit;                              // > 1 (small pyramid levels): blockIdx.z walks a slice of the 16-channel chunks and
   float* part;                             // stores raw partial sums part[kz][b][co][pixel]; x3_splitk_epilogue_kernel finishes
+  // NP == 2 (the fp16x2 "h2" form, x3_split.h) only:
+  const float* x_amax;                     // max |x| of the input tensor = max over n_amax device slots -> the operand scale
+  int n_amax;
+  float* y_amax;                           // nullable: slot that receives max |y| of this launch's output (atomic max on the bit pattern)
 };
+
+// max |v| over a wave -> at most one atomic max on the slot (non-negative floats order like their bit patterns; a NaN pattern
+// wins).  Thousands of waves fold into ONE address and same-address atomics serialise at the memory side (~10 ns each: 6k of them
+// were the whole run time of the amax pass over a small tensor), so a wave first LOOKS at the slot with a coherent (agent-scope)
+// load: the slot only grows, and after the first few waves almost nobody has anything to add (a stale look only costs an atomic
+// that changes nothing).  The atomic is the returning form and the wave consumes the result before it ends: a returned value
+// means the update has been performed, whatever the hardware does with posted atomics at the end of a kernel.
+__device__ __forceinline__ float x3_amax_wave(float m) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(m, off, 64);
+    m = (o > m || o != o) ? o : m;
+  }
+  return m;
+}
+#ifndef X3_AMAX_PRECHECK
+#define X3_AMAX_PRECHECK 1     // 0 (A/B): every wave / block issues its atomic
+#endif
+__device__ __forceinline__ void x3_amax_commit(float m, float* slot) {       // one lane
+  const float cur = X3_AMAX_PRECHECK ? __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1.f;
+  if (m > cur || m != m) {
+    const unsigned int old = atomicMax((unsigned int*)slot, __builtin_bit_cast(unsigned int, m));
+    asm volatile("" ::"v"(old));                            // wait for the atomic's return: performed before the wave ends
+  }
+}
+__device__ __forceinline__ void x3_amax_publish(float m, float* slot) {
+  m = x3_amax_wave(m);
+  if ((threadIdx.x & 63) == 0) x3_amax_commit(m, slot);
+}
+// the same for a whole 256-thread block (every thread must arrive): one look at the slot per block
+__device__ __forceinline__ void x3_amax_publish_block256(float m, float* slot) {
+  __shared__ float wm[4];
+  m = x3_amax_wave(m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float r = wm[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) r = (wm[i] > r || wm[i] != wm[i]) ? wm[i] : r;
+    x3_amax_commit(r, slot);
+  }
+}
+__device__ __forceinline__ float x3_amax_fold(float m, float v) {
+  const float a = __builtin_fabsf(v);
+  return (a > m || a != a) ? a : m;
+}
 
 
 // Block = CT*PG symmetric waves, two blocks per CU (256 registers per wave, 128 of them accumulators): every wave
@@ -68,11 +118,14 @@ struct X3Args {
 // 8-wave block per CU and double-buffered LDS was built and measured: 5-20 % slower on every layer shape, because
 // nothing overlaps a block's prologue/epilogue there; on random data both variants run into the same power-limited
 // clock: all-zero operands run 32 % faster than random ones on the same launch.)
-template <int CT, int PG, int NT, int PLANE_PIX>
+// NP = 3: bf16x3, six products (above).  NP = 2: fp16x2 of operands scaled by a power of two, three products (x3_split.h, "h2"):
+// the activations are scaled by 2^ex from a.x_amax, the packed weights carry their own exponent in the 16-B unit behind the
+// last fragment, and the accumulators are scaled back before the epilogue.
+template <int CT, int PG, int NT, int PLANE_PIX, int NP = 3>
 __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a) {
   constexpr int NTHR = CT * PG * 64;
   constexpr int NR = (2 * PLANE_PIX + NTHR - 1) / NTHR;      // staging rounds: one (pixel, k-group) unit per thread per round
-  __shared__ u32x4 lds[6 * PLANE_PIX];                      // [piece][g][pixel] x 16 B
+  __shared__ u32x4 lds[2 * NP * PLANE_PIX];                 // [piece][g][pixel] x 16 B
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -137,7 +190,15 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
   }
   const uint32_t wvoff = (uint32_t)((cot * 64 + lane) * 16);
   const uint32_t wpiece = (uint32_t)a.CoT * 1024u;         // bytes between pieces
-  const uint32_t wtap = 3u * wpiece;
+  const uint32_t wtap = (uint32_t)NP * wpiece;
+  float sx = 1.f, inv_x = 1.f, inv_w = 1.f;                // h2: operand scale of x, and the two factors that undo both scales
+  if (NP == 2) {
+    const int ex = x3_h2_exp(x3_h2_amax(a.x_amax, a.n_amax));
+    const int ew = ((const int*)(a.wq + (long)a.nchunk * 9 * NP * a.CoT * 64))[0];
+    sx = ldexpf(1.f, ex);
+    inv_x = ldexpf(1.f, -ex);
+    inv_w = ldexpf(1.f, -ew);
+  }
 
   f32x16 acc[NT];
 #pragma unroll
@@ -155,11 +216,11 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
       for (int e = 0; e < 8; ++e)
         raw[r][e] = (X3_ABL == 3 && c > 0) ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)svoff[r], (int)(s0 + e * hw4), 0));
   };
-  u32x4 wa[2][3];
+  u32x4 wa[2][NP];
   auto issue_w = [&](int slot, int c, int tap) {
     const uint32_t so = ((uint32_t)c * 9u + (uint32_t)tap) * wtap;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
       wa[slot][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)wvoff, (int)(so + p * wpiece), 0));
   };
   const int c_begin = (int)(((long)blockIdx.z * a.nchunk) / a.ksplit), c_end = (int)(((long)(blockIdx.z + 1) * a.nchunk) / a.ksplit);
@@ -172,11 +233,12 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       u32x4 h, m, l;
-      split8(raw[r], h, m, l);
+      if (NP == 2) split8_h2(raw[r], sx, h, m);
+      else split8(raw[r], h, m, l);
       if (swidx[r] >= 0) {
         lds[swidx[r]] = h;
         lds[swidx[r] + 2 * PLANE_PIX] = m;
-        lds[swidx[r] + 4 * PLANE_PIX] = l;
+        if (NP == 3) lds[swidx[r] + 4 * PLANE_PIX] = l;
       }
     }
     __syncthreads();
@@ -193,35 +255,51 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
         }
         __builtin_amdgcn_sched_barrier(0);
         const int toff = (tap / 3) * LW * dy + (tap % 3) * d;
-        u32x4 xb[2][3];
+        u32x4 xb[2][NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) xb[0][p] = lds[xidx[0] + toff + 2 * p * PLANE_PIX];
+        for (int p = 0; p < NP; ++p) xb[0][p] = lds[xidx[0] + toff + 2 * p * PLANE_PIX];
 #pragma unroll
         for (int s = 0; s < NT; ++s) {
           const int cur = s & 1;
           if (s + 1 < NT) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) xb[cur ^ 1][p] = lds[xidx[s + 1] + toff + 2 * p * PLANE_PIX];
+            for (int p = 0; p < NP; ++p) xb[cur ^ 1][p] = lds[xidx[s + 1] + toff + 2 * p * PLANE_PIX];
           }
           __builtin_amdgcn_sched_barrier(0);        // keep the next sub-tile's LDS reads AHEAD of this one's six MFMAs
           f32x16 t = acc[s];
-          t = mma(wa[slot][2], xb[cur][0], t);      // lo * hi
-          t = mma(wa[slot][0], xb[cur][2], t);      // hi * lo
-          t = mma(wa[slot][1], xb[cur][1], t);      // mid * mid
-          t = mma(wa[slot][1], xb[cur][0], t);      // mid * hi
-          t = mma(wa[slot][0], xb[cur][1], t);      // hi * mid
-          t = mma(wa[slot][0], xb[cur][0], t);      // hi * hi
+          if constexpr (NP == 2) {
+            t = mma_h(wa[slot][1], xb[cur][0], t);    // lo * hi
+            t = mma_h(wa[slot][0], xb[cur][1], t);    // hi * lo
+            t = mma_h(wa[slot][0], xb[cur][0], t);    // hi * hi
+          } else {
+            if (X3_ABL != 20) {                       // ablation 20 (timing only): three products of two pieces
+            t = mma(wa[slot][NP - 1], xb[cur][0], t); // lo * hi
+            t = mma(wa[slot][0], xb[cur][NP - 1], t); // hi * lo
+            t = mma(wa[slot][1], xb[cur][1], t);      // mid * mid
+            }
+            t = mma(wa[slot][1], xb[cur][0], t);      // mid * hi
+            t = mma(wa[slot][0], xb[cur][1], t);      // hi * mid
+            t = mma(wa[slot][0], xb[cur][0], t);      // hi * hi
+          }
           acc[s] = t;
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       // nine taps flip the slot parity: hand the prefetched (c+1, tap 0) fragments back to slot 0
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wa[0][p] = wa[1][p];
+      for (int p = 0; p < NP; ++p) wa[0][p] = wa[1][p];
     }
     __syncthreads();
   }
   if (!active) return;
+  if (NP == 2) {                             // back to the operands' own scale (two exact power-of-two factors)
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][r] = (acc[s][r] * inv_x) * inv_w;
+  }
+  float ymax = 0.f;
+  const bool want_amax = NP == 2 && a.y_amax != nullptr && a.ksplit <= 1;
 
   // ---- epilogue: D[i][jj], i = (r&3) + 8*(r>>2) + 4*g, jj = lane&31 ----
   const long ohw = hw;
@@ -269,7 +347,9 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
         for (int k = 0; k < RB; ++k) {
           float v = acc[s][r0 + k] + bv[k];
           if (a.lrelu) v = irr_lrelu(v);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v * a.alpha), yr, (int)vo[k], 0, 0);
+          v *= a.alpha;
+          if (want_amax && vo[k] != OOB) ymax = x3_amax_fold(ymax, v);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)vo[k], 0, 0);
         }
         continue;
       }
@@ -291,10 +371,12 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
         v = a.res ? rv[k] + a.alpha * v : v * a.alpha;
         v += dv[k];                                   // 0 unless accumulating
         if (a.mask && co < a.nmask) v *= irr_lrelu_grad(mv[k]);
+        if (want_amax && vo[k] != OOB) ymax = x3_amax_fold(ymax, v);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)vo[k], 0, 0);
       }
     }
   }
+  if (want_amax) x3_amax_publish(ymax, a.y_amax);
 }
 
 static std::atomic<int> g_min_blocks{384};     // (the ONE process-wide routing policy, see irr_conv_x3_set_min_blocks) launches with fewer blocks cannot fill 256 CUs x 2 blocks: they stay on the fp32 kernels
@@ -634,10 +716,11 @@ static bool x3s_ok(int B, int Cin, int H, int W, int Cout, int dil) {
 }
 
 // ---- weight packing: see pack_x3_unit (pack.h) for the layout and the three modes ----
+template <int NP>
 __global__ void pack_x3_kernel(const float* __restrict__ w, u32x4* __restrict__ wq, int Cin, int Cout, int CoT, int nchunk,
-                               int mode, int w_cin, int chan0, int row_offset, int w_cout, long nunits) {
+                               int mode, int w_cin, int chan0, int row_offset, int w_cout, long nunits, const float* __restrict__ amax) {
   const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u < nunits) pack_x3_unit(w, wq, Cin, Cout, CoT, nchunk, mode, w_cin, chan0, row_offset, w_cout, u);
+  if (u < nunits) pack_x3_unit<NP>(w, wq, Cin, Cout, CoT, nchunk, mode, w_cin, chan0, row_offset, w_cout, u, amax);
 }
 
 struct TileCfg { int nt, tr, tc; };
@@ -661,14 +744,15 @@ static bool pick_tile(int H, int W, int dy, int dx, int PG, int plane_pix, const
 }
 
 template <int CT, int PG, int NT, int PLANE_PIX>
-int launch_x3(X3Args& a, const TileCfg& t, hipStream_t st) {
+int launch_x3(X3Args& a, const TileCfg& t, hipStream_t st, int np) {
   a.TR = t.tr; a.TC = t.tc;
   const int Hs = (a.H + a.RD - 1) / a.RD;
   a.tiles_x = (a.W + t.tc - 1) / t.tc;
   a.tiles_y = (Hs + t.tr - 1) / t.tr;
   a.ngy = (a.CoT + CT - 1) / CT;
   dim3 grid((unsigned)((long)a.B * a.RD * a.tiles_x * a.tiles_y * a.ngy), 1, (unsigned)a.ksplit);
-  hipLaunchKernelGGL((conv_x3_kernel<CT, PG, NT, PLANE_PIX>), grid, dim3(CT * PG * 64), 0, st, a);
+  if (np == 2) hipLaunchKernelGGL((conv_x3_kernel<CT, PG, NT, PLANE_PIX, 2>), grid, dim3(CT * PG * 64), 0, st, a);
+  else hipLaunchKernelGGL((conv_x3_kernel<CT, PG, NT, PLANE_PIX, 3>), grid, dim3(CT * PG * 64), 0, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -816,8 +900,65 @@ extern "C" int irr_conv_pack_weights_x3(const float* w, void* wq, int Cin, int C
   if (!w || !wq || Cin < 16 || Cout <= 0) return IRR_EINVAL;
   const int CoT = (Cout + 31) / 32, nchunk = x3_nchunk(Cin, Cout);
   const long nunits = (long)nchunk * 9 * CoT * 64;
-  hipLaunchKernelGGL(pack_x3_kernel, dim3(irr_cdiv(nunits, 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)wq, Cin, Cout,
-                     CoT, nchunk, transpose ? 1 : 0, 0, 0, 0, 0, nunits);
+  hipLaunchKernelGGL(pack_x3_kernel<3>, dim3(irr_cdiv(nunits, 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)wq, Cin, Cout,
+                     CoT, nchunk, transpose ? 1 : 0, 0, 0, 0, 0, nunits, (const float*)nullptr);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- the fp16x2 ("h2") form: two pieces per fragment + one 16-B unit that holds the pack's scale exponent ----
+extern "C" long irr_conv_h2_packed_bytes(int Cin, int Cout) {
+  const long CoT = (Cout + 31) / 32, nchunk = x3_nchunk(Cin, Cout);
+  return (nchunk * 9 * 2 * CoT * 64 + 1) * 16;
+}
+
+extern "C" int irr_conv_pack_weights_h2(const float* w, void* wq, int Cin, int Cout, int transpose, const float* amax, void* stream) {
+  if (!w || !wq || !amax || Cin < 16 || Cout <= 0) return IRR_EINVAL;
+  const int CoT = (Cout + 31) / 32, nchunk = x3_nchunk(Cin, Cout);
+  const long nunits = (long)nchunk * 9 * CoT * 64;
+  hipLaunchKernelGGL(pack_x3_kernel<2>, dim3(irr_cdiv(nunits, 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)wq, Cin, Cout,
+                     CoT, nchunk, transpose ? 1 : 0, 0, 0, 0, 0, nunits, amax);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_conv_pack_weights_h2_sub(const float* w, void* wq, int w_cin, int w_cout, int total_rows, int chan0,
+                                            int nchan, int row_offset, const float* amax, void* stream) {
+  if (!w || !wq || !amax || w_cin <= 0 || w_cout <= 0 || total_rows < 16 || (total_rows & 15) || chan0 < 0 || nchan <= 0 ||
+      chan0 + nchan > w_cin || row_offset < 0 || (row_offset & 7) || (w_cout & 7) || row_offset + w_cout > total_rows)
+    return IRR_EINVAL;
+  const int CoT = (nchan + 31) / 32, nchunk = total_rows / 16;
+  const long nunits = (long)nchunk * 9 * CoT * 64;
+  hipLaunchKernelGGL(pack_x3_kernel<2>, dim3(irr_cdiv(nunits, 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)wq, total_rows,
+                     nchan, CoT, nchunk, 2, w_cin, chan0, row_offset, w_cout, nunits, amax);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+// slot = max(slot, max |x|) over a (B, n) block of plane-dense samples (batch stride bs): the per-tensor magnitude the h2
+// kernels scale their operands by.  slot must hold a non-negative float (0 to start); several launches may fold into one slot.
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n4, long n, long bs, float* __restrict__ slot) {
+  const float* xb = x + (long)blockIdx.y * bs;
+  float m = 0.f;
+  const long stride = (long)gridDim.x * 256;
+  if ((((uintptr_t)xb) & 15) == 0) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const f32x4 v = ((const f32x4*)xb)[i];
+      m = x3_amax_fold(x3_amax_fold(x3_amax_fold(x3_amax_fold(m, v[0]), v[1]), v[2]), v[3]);
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = x3_amax_fold(m, xb[i]);
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = x3_amax_fold(m, xb[i]);
+  }
+  x3_amax_publish_block256(m, slot);
+}
+
+extern "C" int irr_amax_f32(const float* x, int B, long n, long bs, float* slot, void* stream) {
+  if (!x || !slot || B <= 0 || n <= 0) return IRR_EINVAL;
+  long blocks = irr_cdiv(n / 4 + 1, 256 * 8);             // >= eight 16-B loads per thread
+  const long cap = 1024 / B > 0 ? 1024 / B : 1;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, n / 4, n, bs, slot);
   IRR_LAUNCH_CHECK();
   return 0;
 }
@@ -829,8 +970,8 @@ extern "C" int irr_conv_pack_weights_x3_sub(const float* w, void* wq, int w_cin,
     return IRR_EINVAL;
   const int CoT = (nchan + 31) / 32, nchunk = total_rows / 16;
   const long nunits = (long)nchunk * 9 * CoT * 64;
-  hipLaunchKernelGGL(pack_x3_kernel, dim3(irr_cdiv(nunits, 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)wq, total_rows,
-                     nchan, CoT, nchunk, 2, w_cin, chan0, row_offset, w_cout, nunits);
+  hipLaunchKernelGGL(pack_x3_kernel<3>, dim3(irr_cdiv(nunits, 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)wq, total_rows,
+                     nchan, CoT, nchunk, 2, w_cin, chan0, row_offset, w_cout, nunits, (const float*)nullptr);
   IRR_LAUNCH_CHECK();
   return 0;
 }
@@ -844,31 +985,39 @@ extern "C" int irr_conv2d_x3_eligible(int B, int Cin, int H, int W, int Cout, in
   return p.ct * 1000 + p.pg * 100 + p.t.nt * 10 + (p.plane == 352 ? 1 : p.plane == 616 ? 2 : 3);
 }
 
+// the fp16x2 form takes what conv_x3_kernel takes; the problems of the streaming 32-channel kernel stay on bf16x3 (code 0 here)
+extern "C" int irr_conv2d_h2_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil) {
+  const int code = irr_conv2d_x3_eligible(B, Cin, H, W, Cout, k, stride, dil);
+  return code == 9001 ? 0 : code;
+}
+
 // finishes a K-split launch: y = epilogue(sum over the slices of part[kz][b][co][pixel])  (same order of operations as the
 // epilogue of conv_x3_kernel: bias, LeakyReLU, residual / alpha, accumulate, LeakyReLU'-mask)
 __global__ __launch_bounds__(256) void x3_splitk_epilogue_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                                 const float* __restrict__ res, float* __restrict__ y,
                                                                 const float* __restrict__ mask, int B, int Cout, long hw, int ksplit,
                                                                 long y_bs, long res_bs, long mask_bs, int nmask, int lrelu,
-                                                                float alpha, int accumulate) {
+                                                                float alpha, int accumulate, float* __restrict__ y_amax) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n = (long)B * Cout * hw;
-  if (i >= n) return;
-  const long pix = i % hw;
-  const long r = i / hw;
-  const int co = (int)(r % Cout);
-  const long b = r / Cout;
   float v = 0.f;
-  for (int k = 0; k < ksplit; ++k) v += part[(long)k * n + i];
-  v += bias ? bias[co] : 0.f;
-  if (lrelu) v = irr_lrelu(v);
-  const long o = (long)co * hw + pix;
-  if (res) v = res[b * res_bs + o] + alpha * v;
-  else v *= alpha;
-  float* dst = y + b * y_bs + o;
-  if (accumulate) v += *dst;
-  if (mask && co < nmask) v *= irr_lrelu_grad(mask[b * mask_bs + o]);
-  *dst = v;
+  if (i < n) {
+    const long pix = i % hw;
+    const long r = i / hw;
+    const int co = (int)(r % Cout);
+    const long b = r / Cout;
+    for (int k = 0; k < ksplit; ++k) v += part[(long)k * n + i];
+    v += bias ? bias[co] : 0.f;
+    if (lrelu) v = irr_lrelu(v);
+    const long o = (long)co * hw + pix;
+    if (res) v = res[b * res_bs + o] + alpha * v;
+    else v *= alpha;
+    float* dst = y + b * y_bs + o;
+    if (accumulate) v += *dst;
+    if (mask && co < nmask) v *= irr_lrelu_grad(mask[b * mask_bs + o]);
+    *dst = v;
+  }
+  if (y_amax) x3_amax_publish_block256(__builtin_fabsf(v), y_amax);      // (uniform: every thread of the block arrives)
 }
 
 // floats of scratch a K-split launch needs (0: the problem runs unsplit)
@@ -882,9 +1031,11 @@ extern "C" long irr_conv2d_fwd_x3_ws_elems(int B, int Cin, int H, int W, int Cou
 static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const float* res, float* y, int B,
                        int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
                        float alpha, int accumulate, const float* mask, long mask_bs, int nmask, float* ws, long ws_elems,
-                       void* stream, float* y2 = nullptr, long y2_bs = 0) {
+                       void* stream, float* y2 = nullptr, long y2_bs = 0, int np = 3, const float* x_amax = nullptr, int n_amax = 0,
+                       float* y_amax = nullptr) {
   if (!x || !wq || !y || B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1) return IRR_EINVAL;
   if (y2 && (!res || accumulate || mask || !x3s_ok(B, Cin, H, W, Cout, dil))) return IRR_EINVAL;      // second output: streaming kernel only
+  if (np == 2 && (!x_amax || n_amax <= 0 || x3s_ok(B, Cin, H, W, Cout, dil))) return IRR_EINVAL;
   if (x3s_ok(B, Cin, H, W, Cout, dil)) {
     X3SArgs s;
     s.wq = (const u32x4*)wq; s.bias = bias;
@@ -959,6 +1110,7 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
   a.mask_bs = mask_bs; a.nmask = nmask;
   a.ksplit = (ws && (long)p.ksplit * B * Cout * H * W <= ws_elems) ? p.ksplit : 1;     // no scratch: run unsplit (slower, same result class)
   a.part = ws;
+  a.x_amax = x_amax; a.n_amax = n_amax; a.y_amax = y_amax;
   // 32-bit byte voffsets below the 2 GiB out-of-range marker: split the batch accordingly
   const long lim = (1L << 29) - (long)(Cin + 16) * H * W - 64;        // elements
   if (lim <= 0) return IRR_EINVAL;
@@ -975,29 +1127,29 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
     hipStream_t st = (hipStream_t)stream;
     const int key = p.ct * 1000 + p.pg * 100 + p.t.nt * 10 + (p.plane == 352 ? 1 : p.plane == 616 ? 2 : 3);
     switch (key) {
-      case 4181: rc = launch_x3<4, 1, 8, 352>(a, p.t, st); break;
-      case 4171: rc = launch_x3<4, 1, 7, 352>(a, p.t, st); break;
-      case 4182: rc = launch_x3<4, 1, 8, 616>(a, p.t, st); break;
-      case 4172: rc = launch_x3<4, 1, 7, 616>(a, p.t, st); break;
-      case 3181: rc = launch_x3<3, 1, 8, 352>(a, p.t, st); break;
-      case 3171: rc = launch_x3<3, 1, 7, 352>(a, p.t, st); break;
-      case 3182: rc = launch_x3<3, 1, 8, 616>(a, p.t, st); break;
-      case 3172: rc = launch_x3<3, 1, 7, 616>(a, p.t, st); break;
-      case 2282: rc = launch_x3<2, 2, 8, 616>(a, p.t, st); break;
-      case 2272: rc = launch_x3<2, 2, 7, 616>(a, p.t, st); break;
-      case 1442: rc = launch_x3<1, 4, 4, 616>(a, p.t, st); break;
-      case 1421: rc = launch_x3<1, 4, 2, 352>(a, p.t, st); break;
-      case 4141: rc = launch_x3<4, 1, 4, 352>(a, p.t, st); break;
-      case 3141: rc = launch_x3<3, 1, 4, 352>(a, p.t, st); break;
-      case 2242: rc = launch_x3<2, 2, 4, 616>(a, p.t, st); break;
-      case 2243: rc = launch_x3<2, 2, 4, 640>(a, p.t, st); break;
+      case 4181: rc = launch_x3<4, 1, 8, 352>(a, p.t, st, np); break;
+      case 4171: rc = launch_x3<4, 1, 7, 352>(a, p.t, st, np); break;
+      case 4182: rc = launch_x3<4, 1, 8, 616>(a, p.t, st, np); break;
+      case 4172: rc = launch_x3<4, 1, 7, 616>(a, p.t, st, np); break;
+      case 3181: rc = launch_x3<3, 1, 8, 352>(a, p.t, st, np); break;
+      case 3171: rc = launch_x3<3, 1, 7, 352>(a, p.t, st, np); break;
+      case 3182: rc = launch_x3<3, 1, 8, 616>(a, p.t, st, np); break;
+      case 3172: rc = launch_x3<3, 1, 7, 616>(a, p.t, st, np); break;
+      case 2282: rc = launch_x3<2, 2, 8, 616>(a, p.t, st, np); break;
+      case 2272: rc = launch_x3<2, 2, 7, 616>(a, p.t, st, np); break;
+      case 1442: rc = launch_x3<1, 4, 4, 616>(a, p.t, st, np); break;
+      case 1421: rc = launch_x3<1, 4, 2, 352>(a, p.t, st, np); break;
+      case 4141: rc = launch_x3<4, 1, 4, 352>(a, p.t, st, np); break;
+      case 3141: rc = launch_x3<3, 1, 4, 352>(a, p.t, st, np); break;
+      case 2242: rc = launch_x3<2, 2, 4, 616>(a, p.t, st, np); break;
+      case 2243: rc = launch_x3<2, 2, 4, 640>(a, p.t, st, np); break;
       default: return IRR_EINVAL;
     }
     if (rc) return rc;
     if (a.ksplit > 1) {
       const long n = (long)a.B * Cout * H * W;
       hipLaunchKernelGGL(x3_splitk_epilogue_kernel, dim3((unsigned)irr_cdiv(n, 256)), dim3(256), 0, st, ws, bias, a.res, a.y, a.mask, a.B,
-                         Cout, (long)H * W, a.ksplit, y_bs, res_bs, mask_bs, nmask, lrelu, alpha, accumulate);
+                         Cout, (long)H * W, a.ksplit, y_bs, res_bs, mask_bs, nmask, lrelu, alpha, accumulate, np == 2 ? y_amax : nullptr);
       IRR_LAUNCH_CHECK();
     }
   }
@@ -1025,4 +1177,14 @@ extern "C" int irr_conv2d_fwd_x3_splitk(const float* x, const void* wq, const fl
                                         long ws_elems, void* stream) {
   return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, accumulate, mask, mask_bs, nmask,
                      ws, ws_elems, stream);
+}
+
+// irr_conv2d_fwd_x3_splitk on the fp16x2 form (ws may be null: the problem then runs unsplit): wq from irr_conv_pack_weights_h2,
+// x_amax[0 .. n_amax) = device slots whose maximum bounds |x|, y_amax (nullable) receives max |y| (atomic max: pre-set to 0).
+extern "C" int irr_conv2d_fwd_h2(const float* x, const void* wq, const float* bias, const float* res, float* y, int B,
+                                 int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
+                                 float alpha, int accumulate, const float* mask, long mask_bs, int nmask, float* ws,
+                                 long ws_elems, const float* x_amax, int n_amax, float* y_amax, void* stream) {
+  return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, accumulate, mask, mask_bs, nmask,
+                     ws, ws_elems, stream, nullptr, 0, 2, x_amax, n_amax, y_amax);
 }

@@ -9,8 +9,9 @@ struct IrrPackJob {            // opaque to the host: size and the block0 offset
   void* dst;                  // packed destination (device)
   long n;                     // elements (kind 0/1) or 16-B units x lanes (kind 2) of the job
   long block0;                // first 256-thread block of the job inside the batched launch
-  int kind;                   // 0 = fp32 pack, 1 = fp32 combined-matrix sub-block, 2 = bf16x3 pack (modes 0 / 1 / 2)
+  int kind;                   // 0 = fp32 pack, 1 = fp32 combined-matrix sub-block, 2 = bf16x3 pack (modes 0 / 1 / 2), 3 = fp16x2 pack (same modes)
   int p[9];
+  const float* amax;          // kind 3: device scalar >= max |w| over EVERY weight that goes into dst (the pack's one scale)
 };
 
 // fp32 packed layout wp[cp][tap][half][CoP]  (conv_fwd.hip)
@@ -60,8 +61,12 @@ __device__ __forceinline__ void pack_sub_elem(const float* __restrict__ w, float
 // mode 1: w is (Cin, Cout, 3, 3) = original layout, used transposed + flipped -> stride-1 data gradient
 // mode 2: sub-block of a COMBINED data-gradient matrix (DenseNet backward): rows [row_offset, row_offset + w_cout)
 //         take layer weights w (w_cout, w_cin, 3, 3) transposed+flipped, restricted to input channels [chan0, chan0+Cout)
+// NP = 2 (kind 3, "h2"): two fp16 pieces of w * 2^ew, ew from *amax (x3_h2_exp); piece stride as for NP = 3; the 16-B unit behind the
+// last fragment holds ew (every job of a combined matrix writes the same value there).
+template <int NP = 3>
 __device__ __forceinline__ void pack_x3_unit(const float* __restrict__ w, u32x4* __restrict__ wq, int Cin, int Cout, int CoT, int nchunk,
-                                             int mode, int w_cin, int chan0, int row_offset, int w_cout, long u) {
+                                             int mode, int w_cin, int chan0, int row_offset, int w_cout, long u,
+                                             const float* __restrict__ amax = nullptr) {
   const int lane = (int)(u & 63);
   long r = u >> 6;
   const int cot = (int)(r % CoT);
@@ -89,11 +94,17 @@ __device__ __forceinline__ void pack_x3_unit(const float* __restrict__ w, u32x4*
     }
     v[e] = val;
   }
+  int ew = 0;
+  if (NP == 2) {
+    ew = x3_h2_exp(amax[0]);
+    if (u == 0) wq[(long)nchunk * 9 * NP * CoT * 64] = u32x4{(uint32_t)ew, 0u, 0u, 0u};
+  }
   if (mode == 2 && !any) return;                   // rows of other layers: leave untouched
   u32x4 h, m, l;
-  split8(v, h, m, l);
-  const long base = (((long)chunk * 9 + tap) * 3 * CoT + cot) * 64 + lane;
+  if (NP == 2) split8_h2(v, ldexpf(1.f, ew), h, m);
+  else split8(v, h, m, l);
+  const long base = (((long)chunk * 9 + tap) * NP * CoT + cot) * 64 + lane;
   wq[base] = h;
   wq[base + (long)CoT * 64] = m;
-  wq[base + 2L * CoT * 64] = l;
+  if (NP == 3) wq[base + 2L * CoT * 64] = l;
 }

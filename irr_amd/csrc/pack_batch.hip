@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const IrrPackJob* __res
   if (i >= j.n) return;
   if (j.kind == 0) pack_f32_elem(j.w, (float*)j.dst, j.p[0], j.p[1], j.p[2], j.p[3], j.p[4], j.n, i);
   else if (j.kind == 1) pack_sub_elem(j.w, (float*)j.dst, j.p[0], j.p[2], j.p[3], j.p[4], j.p[5], j.p[6], i);
-  else pack_x3_unit(j.w, (u32x4*)j.dst, j.p[0], j.p[1], j.p[2], j.p[3], j.p[4], j.p[5], j.p[6], j.p[7], j.p[8], i);
+  else if (j.kind == 2) pack_x3_unit<3>(j.w, (u32x4*)j.dst, j.p[0], j.p[1], j.p[2], j.p[3], j.p[4], j.p[5], j.p[6], j.p[7], j.p[8], i);
+  else pack_x3_unit<2>(j.w, (u32x4*)j.dst, j.p[0], j.p[1], j.p[2], j.p[3], j.p[4], j.p[5], j.p[6], j.p[7], j.p[8], i, j.amax);
 }
 
 static int x3_nchunk_(int Cin, int Cout) { return (Cin == 16 && Cout <= 32) ? 2 : (Cin + 15) / 16; }     // = conv_x3.hip
@@ -80,6 +81,26 @@ extern "C" long irr_conv_pack_job_x3_sub(void* job, const float* w, void* wq, in
   j.p[7] = row_offset; j.p[8] = w_cout;
   *(IrrPackJob*)job = j;
   return (j.n + 255) / 256;
+}
+
+// fp16x2 ("h2") forms of the two builders above: amax = device scalar >= max |w| over every weight that goes into wq
+extern "C" long irr_conv_pack_job_h2(void* job, const float* w, void* wq, int Cin, int Cout, int transpose, const float* amax) {
+  if (!amax) return IRR_EINVAL;
+  const long nb = irr_conv_pack_job_x3(job, w, wq, Cin, Cout, transpose);
+  if (nb < 0) return nb;
+  ((IrrPackJob*)job)->kind = 3;
+  ((IrrPackJob*)job)->amax = amax;
+  return nb;
+}
+
+extern "C" long irr_conv_pack_job_h2_sub(void* job, const float* w, void* wq, int w_cin, int w_cout, int total_rows, int chan0,
+                                         int nchan, int row_offset, const float* amax) {
+  if (!amax) return IRR_EINVAL;
+  const long nb = irr_conv_pack_job_x3_sub(job, w, wq, w_cin, w_cout, total_rows, chan0, nchan, row_offset);
+  if (nb < 0) return nb;
+  ((IrrPackJob*)job)->kind = 3;
+  ((IrrPackJob*)job)->amax = amax;
+  return nb;
 }
 
 // jobs: DEVICE array of njobs records whose block0 fields are the exclusive prefix sums of the jobs' block counts

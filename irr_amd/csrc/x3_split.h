@@ -58,3 +58,53 @@ __device__ __forceinline__ void split8(const float* v, u32x4& h, u32x4& m, u32x4
 __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+
+// ---- "h2": two-term fp16 split of SCALED operands, three piece products -------------------------------------------------
+// x * s = hi + lo with hi = fp16(x * s) and lo = fp16(x * s - hi) (round-to-nearest each time; the residual is exact in
+// fp32): 11 + 1 + 11 = 23 significant bits wherever lo is a normal fp16 number, i.e. for |x * s| >= 2^-2; below that lo is
+// a subnormal fp16 value (the fp16 MFMA of gfx950 neither flushes inputs nor outputs) and the ABSOLUTE error of the pair
+// stays <= 2^-25.  s is a power of two chosen from max |x| of the whole tensor so that |x * s| < 2^15 (x3_h2_scale): the
+// largest 2^17 : 1 of a tensor's value range is carried at full precision, the rest at the absolute precision of that range's
+// lower end -- the same shape of error an fp32 accumulation of the products has.  a * b ~= ah*bh + ah*bl + al*bh
+// (dropped: al*bl <= 2^-24 |ab|), accumulated in fp32 by v_mfma_f32_32x32x16_f16: half the matrix work of the bf16x3 form.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split8_h2(const float* v, float s, u32x4& h, u32x4& l) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float a0 = v[2 * q] * s, a1 = v[2 * q + 1] * s;
+    asm volatile("" : "+v"(a0));                            // (scalar v_mul_f32, not v_pk_mul_f32: see split8)
+    const f32x2 a = {a0, a1};
+    const f16x2 hp = __builtin_convertvector(a, f16x2);
+    float r0 = a[0] - (float)hp[0], r1 = a[1] - (float)hp[1];
+    asm volatile("" : "+v"(r0));                            // (keeps the subtractions scalar, see split8)
+    const f32x2 r = {r0, r1};
+    h[q] = __builtin_bit_cast(uint32_t, hp);
+    l[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+  }
+}
+
+__device__ __forceinline__ f32x16 mma_h(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// Power-of-two scale of a tensor whose largest magnitude is amax: |x| * 2^e < 2^15.  (amax = 0, not finite or not a number:
+// e = 0 -- such operands overflow or poison the fp16 pieces exactly as they would poison an fp32 convolution's sums.)
+__device__ __forceinline__ int x3_h2_exp(float amax) {
+  if (!(amax > 0.f) || !(amax < __builtin_huge_valf())) return 0;
+  int e;
+  (void)frexpf(amax, &e);                                   // amax = m * 2^e, 0.5 <= m < 1
+  e = 15 - e;
+  return e > 96 ? 96 : e < -96 ? -96 : e;
+}
+// max over the n slots of an amax vector: agent-scope atomic loads (vector-memory loads served by L2 -- as plain loads of a
+// uniform address they would go through the scalar data cache)
+__device__ __forceinline__ float x3_h2_amax(const float* slots, int n) {
+  float m = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float v = __hip_atomic_load(slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    m = (v > m || v != v) ? v : m;                          // a NaN slot wins (and turns the scale off)
+  }
+  return m;
+}

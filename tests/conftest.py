@@ -29,12 +29,13 @@ def _built_library():
     yield
 
 
-@pytest.fixture(params=["default", "x3_all"])
+@pytest.fixture(params=["default", "x3_all", "h2_all"])
 def routing(request):
     """Kernel-family routing of the conv layers for the reference-fixture tests.  ``default``: what the library picks for
-    the (small) test shapes -- mostly the fp32-MFMA family.  ``x3_all``: irr_conv_x3_set_min_blocks(0), i.e. every layer
-    the bf16x3-split family ACCEPTS runs on it (conv_x3 / conv_x3s forward and data gradient incl. the combined DenseNet
-    column packs, conv_wgrad_x3) -- the routing bench.py's BASELINE-size step gets by default."""
+    the (small) test shapes -- mostly the fp32-MFMA family.  ``x3_all`` / ``h2_all``: irr_conv_x3_set_min_blocks(0), i.e. every
+    layer the split-operand family ACCEPTS runs on it (conv_x3 / conv_x3s forward and data gradient incl. the combined DenseNet
+    column packs, conv_wgrad_x3) in its bf16x3 form / in the fp16x2 form wherever that exists -- h2_all is the routing
+    bench.py's BASELINE-size step gets by default."""
     from irr_amd import conv as C, hip
     C.x3_code(1, 64, 8, 8, 64, 3, 1, 1)                  # applies IRR_X3_MIN_BLOCKS once, if set
     C.LAUNCHES.clear()
@@ -42,11 +43,12 @@ def routing(request):
         yield "default"
         return
     old = hip.lib().irr_conv_x3_set_min_blocks(0)
-    C.set_math("x3")
+    C.set_math("x3" if request.param == "x3_all" else "h2")
     try:
-        yield "x3_all"
-        x3 = sum(v for k, v in C.LAUNCHES.items() if "x3" in k)
-        assert x3 > 0, f"x3_all routing launched no x3 kernel: {dict(C.LAUNCHES)}"
+        yield request.param
+        fam = "x3" if request.param == "x3_all" else "h2"
+        n = sum(v for k, v in C.LAUNCHES.items() if fam in k)
+        assert n > 0, f"{request.param} routing launched no {fam} kernel: {dict(C.LAUNCHES)}"
     finally:
         hip.lib().irr_conv_x3_set_min_blocks(old)
-        C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
+        C.set_math(C.DEFAULT_MATH)

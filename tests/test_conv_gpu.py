@@ -125,7 +125,7 @@ def x3_everywhere():
     C.set_math("x3")
     yield
     hip.lib().irr_conv_x3_set_min_blocks(old)
-    C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
+    C.set_math(C.DEFAULT_MATH)
 
 
 @pytest.mark.parametrize("case", X3_CASES, ids=[f"{c[0]}to{c[1]}d{c[2]}_{c[4]}x{c[5]}" for c in X3_CASES])
@@ -209,7 +209,7 @@ def test_conv_x3_level4_linearity_and_routing():
     assert torch.equal(2 * y1, y2)
     C.set_math("f32")
     yf = C.conv_forward(x, w, None, 1, 1, False)
-    C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
+    C.set_math(C.DEFAULT_MATH)
     assert (y1 - yf).abs().max().item() < 2e-6 * yf.abs().max().item() * 4
 
 
@@ -299,7 +299,7 @@ def test_conv_x3_k_split_small_levels(case):
         _k_split_checks(C, hip, cin, cout, dil, B, H, W)
     finally:
         hip.lib().irr_conv_x3_set_min_blocks(old)
-        C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
+        C.set_math(C.DEFAULT_MATH)
 
 
 def _k_split_checks(C, hip, cin, cout, dil, B, H, W):
@@ -499,7 +499,7 @@ def test_x3_family_baseline_size_properties():
     assert torch.equal(2 * y1, y2)
     C.set_math("f32")
     yf = C.conv_forward(x, w, None, 1, 1, False)
-    C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
+    C.set_math(C.DEFAULT_MATH)
     assert (y1 - yf).abs().max().item() <= 4e-6 * yf.abs().max().item()
 
 
@@ -538,7 +538,7 @@ def test_x3_matches_fp32_kernel_at_baseline_sizes(case):
         gf = C.conv_dgrad(gy, w, 1, dil, (H, W))
     finally:
         hip.lib().irr_conv_x3_set_min_blocks(old)
-        C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
+        C.set_math(C.DEFAULT_MATH)
     assert (y3 - yf).abs().max().item() <= 4e-6 * yf.abs().max().item()
     if g3 is not None:
         assert (g3 - gf).abs().max().item() <= 4e-6 * gf.abs().max().item()
@@ -570,7 +570,7 @@ def test_wgrad_x3_matches_fp32_kernel_at_baseline_sizes(case):
             C.conv_wgrad(x, gy, (cout, cin, 3, 3), 1, dil, gw=gw, gbias=gb)
             out[m] = (gw, gb)
     finally:
-        C.set_math(os.environ.get("IRR_CONV_MATH", "x3"))
+        C.set_math(C.DEFAULT_MATH)
     sw, sb = out["f32"][0].abs().max().item(), out["f32"][1].abs().max().item()
     assert (out["x3"][0] - out["f32"][0]).abs().max().item() <= 4e-6 * sw
     assert (out["x3"][1] - out["f32"][1]).abs().max().item() <= 1e-5 * sb

@@ -1,0 +1,186 @@
+"""The fp16x2 ("h2") form of the split-operand conv family (csrc/x3_split.h, conv_x3.hip, conv_wgrad_x3.hip; include/irr_hip.h
+section "h2"): amax slots, operand scaling over hostile value ranges, the fused output magnitude, weight scales that follow the
+optimizer -- each against fp64 references, with the fp32-MFMA kernel's own error as the yardstick."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+H2_CASES = [  # (Cin, Cout, dil, B, H, W): every block shape of conv_x3_kernel, ragged edges, channel tails, row-folded dilation
+    (115, 128, 1, 2, 24, 28), (565, 128, 1, 1, 16, 48), (371, 96, 1, 1, 33, 47), (531, 32, 1, 1, 32, 48), (128, 64, 1, 1, 40, 24),
+    (128, 128, 2, 1, 24, 28), (128, 128, 4, 2, 30, 36), (16, 565, 1, 1, 24, 28), (35, 96, 1, 1, 12, 58), (128, 96, 8, 1, 50, 56),
+    (64, 96, 16, 1, 90, 112), (64, 64, 1, 2, 24, 28),
+]
+RANGES = ["unit", "per_channel", "tiny_grad", "outlier", "huge", "sparse"]
+
+
+@pytest.fixture
+def h2_everywhere():
+    from irr_amd import conv as C, hip
+    old = hip.lib().irr_conv_x3_set_min_blocks(0)
+    C.set_math("h2")
+    C.LAUNCHES.clear()
+    yield
+    hip.lib().irr_conv_x3_set_min_blocks(old)
+    C.set_math(C.DEFAULT_MATH)
+
+
+def _operands(case, rng):
+    cin, cout, dil, B, H, W = case
+    g = torch.Generator().manual_seed(cin * 7 + cout + len(rng))
+    x = torch.randn(B, cin, H, W, generator=g)
+    gy = torch.randn(B, cout, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    if rng == "per_channel":
+        x = x * torch.exp(2.0 * torch.randn(B, cin, 1, 1, generator=g))
+    elif rng == "tiny_grad":
+        gy = gy * 1e-9
+    elif rng == "outlier":                       # one value 10^6 x the rest: the rest sits 20 binades below the scale's top
+        x = x * 1e-2
+        x[0, 0, 3, 3] = 1e4
+    elif rng == "huge":                          # beyond the fp16 range in both directions without the scales
+        x = x * 3e12
+        gy = gy * 1e-20
+        w = w * 1e-6
+    elif rng == "sparse":
+        x = torch.relu(x) * 3.0
+        gy = gy * (torch.rand(gy.shape, generator=g) > 0.9)
+    return x, w, gy
+
+
+def _rel(a, ref):
+    return ((a.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+
+
+@pytest.mark.parametrize("rng", RANGES)
+@pytest.mark.parametrize("case", H2_CASES, ids=[f"{c[0]}to{c[1]}d{c[2]}_{c[4]}x{c[5]}" for c in H2_CASES])
+def test_h2_is_fp32_faithful(case, rng, h2_everywhere):
+    """forward, data gradient and weight gradient on the fp16x2 kernels against fp64: the error stays in the fp32 class
+    (<= max(4x the fp32-MFMA kernels' error on the same operands, 2e-6) and <= 5e-6 of the result's range) for every operand range --
+    the power-of-two scales derived from the amax slots keep the fp16 pieces inside their exponent range."""
+    from irr_amd import conv as C
+    cin, cout, dil, B, H, W = case
+    x, w, gy = _operands(case, rng)
+    b = torch.linspace(-1, 1, cout) * float(x.abs().mean()) * 0.1
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=dil, dilation=dil)
+    gref = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=dil, dilation=dil)
+    wref = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), padding=dil, dilation=dil)
+    err = {}
+    for m in ("f32", "h2"):
+        C.set_math(m)
+        xc, wc, gc = x.cuda(), w.cuda(), gy.cuda()
+        y = C.conv_forward(xc, wc, b.cuda(), 1, dil, False)
+        gx = C.conv_dgrad(gc, wc, 1, dil, (H, W))
+        xa, ga = (C.amax_measure(xc), C.amax_measure(gc)) if m == "h2" else (None, None)
+        gw = C.conv_wgrad(xc, gc, w.shape, 1, dil, x_amax=xa, gy_amax=ga)
+        err[m] = (_rel(y, ref), _rel(gx, gref), _rel(gw, wref))
+    assert C.LAUNCHES["fwd_h2"] == 1, dict(C.LAUNCHES)
+    for i, what in enumerate(("forward", "data gradient", "weight gradient")):
+        if i == 1 and not C.LAUNCHES["dgrad_h2"]:
+            continue
+        if i == 2 and not C.LAUNCHES["wgrad_h2"]:
+            continue
+        assert err["h2"][i] <= max(4 * err["f32"][i], 2e-6) and err["h2"][i] <= 5e-6, (what, err)
+
+
+def test_amax_slots(h2_everywhere):
+    """irr_amax_f32: channel-slice views with a batch stride, folding several tensors into one slot, unaligned sizes, NaN"""
+    from irr_amd import conv as C
+    torch.manual_seed(3)
+    buf = torch.randn(3, 37, 9, 13, device="cuda")
+    for view in (buf, buf[:, 5:18], buf[:, 36:], buf[1:2, 1:]):
+        a = C.amax_measure(view)
+        assert a.slots[a.first].item() == view.abs().max().item()
+    s = C.Amax.zeros(buf.device, 4)
+    C.amax_measure(buf[:, :10], s.sub(2))
+    C.amax_measure(buf[:, 10:] * 0.5, s.sub(2))
+    assert s.slots.tolist()[2] == max(buf[:, :10].abs().max().item(), (buf[:, 10:] * 0.5).abs().max().item())
+    assert s.slots[0].item() == 0 and s.slots[1].item() == 0 and s.slots[3].item() == 0
+    z = torch.zeros(2, 3, 5, 7, device="cuda")
+    assert C.amax_measure(z).slots.item() == 0
+    z[1, 2, 4, 6] = float("nan")
+    assert torch.isnan(C.amax_measure(z).slots).item()
+    big = torch.randn(2, 64, 96, 112, device="cuda")
+    big[1, 63, 95, 111] = -77.0
+    assert C.amax_measure(big).slots.item() == 77.0
+
+
+@pytest.mark.parametrize("case", [(115, 128, 1, 2, 24, 28), (128, 64, 1, 1, 40, 24), (565, 128, 1, 16, 12, 14)], ids=["ct4", "ct2", "ksplit"])
+def test_fused_output_magnitude_equals_a_pass_over_the_output(case, h2_everywhere):
+    """y_amax of irr_conv2d_fwd_h2 (epilogue of conv_x3_kernel and of the K-split finishing kernel): bit-equal to max |y| of what
+    the launch stored -- plain, with residual + alpha, and as a data gradient with accumulate + LeakyReLU' mask"""
+    from irr_amd import conv as C, hip
+    cin, cout, dil, B, H, W = case
+    if case[3] == 16:
+        hip.lib().irr_conv_x3_set_min_blocks(384)            # the K-split path needs the real routing threshold
+        assert hip.lib().irr_conv2d_fwd_x3_ws_elems(B, cin, H, W, cout, dil) > 0
+    torch.manual_seed(cin)
+    x = torch.randn(B, cin, H, W, device="cuda") * 3
+    w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+    b = torch.randn(cout, device="cuda")
+    res = torch.randn(B, cout, H, W, device="cuda") * 10
+    for kw in ({}, {"res": res, "alpha": 0.1}):
+        ya = C.Amax.zeros(x.device)
+        y = C.conv_forward(x, w, b, 1, dil, True, y_amax=ya, **kw)
+        assert ya.slots.item() == y.abs().max().item(), kw
+    gy = torch.randn(B, cout, H, W, device="cuda")
+    gx = torch.randn(B, cin, H, W, device="cuda")
+    mask = torch.randn(B, cin, H, W, device="cuda")
+    ga = C.Amax.zeros(x.device)
+    C.conv_dgrad(gy, w, 1, dil, (H, W), gx=gx, accumulate=True, mask=mask, nmask=cin, gx_amax=ga)
+    assert ga.slots.item() == gx.abs().max().item()
+    assert C.LAUNCHES["fwd_h2"] == 2 and C.LAUNCHES["dgrad_h2"] == 1, dict(C.LAUNCHES)
+
+
+def test_weight_scale_follows_in_place_updates(h2_everywhere):
+    """the packed fp16x2 weights carry one scale per matrix, taken from max |w|: a parameter rewritten in place (optimizer step,
+    load_state_dict) gets a fresh scale with its repack -- checked by growing the weights 10^5-fold between two calls"""
+    from irr_amd import conv as C
+    torch.manual_seed(0)
+    x = torch.randn(1, 128, 24, 28, device="cuda")
+    w = torch.nn.Parameter(torch.randn(64, 128, 3, 3, device="cuda") * 0.03)
+    for scale in (1.0, 1e5, 1e-7):
+        with torch.no_grad():
+            w.mul_(scale)
+        y = C.conv_forward(x, w, None, 1, 1, False)
+        ref = F.conv2d(x.double(), w.detach().double(), None, padding=1)
+        assert _rel(y, ref.cpu()) <= 3e-6, scale
+        gx = C.conv_dgrad(torch.ones_like(y), w, 1, 1, (24, 28))
+        gref = torch.nn.grad.conv2d_input(x.shape, w.detach().double(), torch.ones_like(ref), padding=1)
+        assert _rel(gx, gref.cpu()) <= 3e-6, scale
+
+
+def test_dense_estimator_and_chain_nodes_on_h2(h2_everywhere):
+    """the DenseNet estimator node and a sequential chain under the h2 routing (per-part amax slots in forward, per-slice slots in
+    the column-wise backward, producer-filled slots along the chain) against the same nodes on the fp32-MFMA kernels"""
+    from irr_amd import conv as C
+    torch.manual_seed(1)
+    B, H, W = 2, 24, 28
+    parts = [torch.randn(B, c, H, W, device="cuda", requires_grad=True) for c in (81, 32, 2)]
+    chans = [115, 243, 371, 467, 531, 563]
+    grow = [128, 128, 96, 64, 32, 2]
+    wb = []
+    for ci, co in zip(chans, grow):
+        wb += [torch.nn.Parameter(torch.randn(co, ci, 3, 3, device="cuda") * (2.0 / (ci * 9)) ** 0.5), torch.nn.Parameter(torch.randn(co, device="cuda") * 0.1)]
+    chain_w = [torch.nn.Parameter(torch.randn(co, ci, 3, 3, device="cuda") * (2.0 / (ci * 9)) ** 0.5) for ci, co in ((563, 128), (128, 128), (128, 96), (96, 64))]
+    chain_b = [torch.nn.Parameter(torch.zeros(w_.shape[0], device="cuda")) for w_ in chain_w]
+    cfg = ((1, 1, True), (1, 2, True), (1, 4, True), (1, 8, True))
+
+    def run(math):
+        C.set_math(math)
+        for t in parts + wb + chain_w + chain_b:
+            t.grad = None
+        buf, out = C.dense_estimator(parts, None, wb, preact_grad_channels=81)
+        cw = []
+        for w_, b_ in zip(chain_w, chain_b):
+            cw += [w_, b_]
+        z = C._ConvChainFn.apply(buf, None, cfg, *cw)
+        ((out ** 2).sum() + (z ** 2).sum() * 0.1).backward()
+        return [out.detach().clone(), z.detach().clone()] + [t.grad.detach().clone() for t in parts + wb + chain_w]
+
+    ref = run("f32")
+    got = run("h2")
+    assert C.LAUNCHES["fwd_h2"] >= 8 and C.LAUNCHES["dense_column_h2"] >= 4 and C.LAUNCHES["wgrad_h2"] >= 8 and C.LAUNCHES["dgrad_h2"] >= 3, dict(C.LAUNCHES)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-30, i

@@ -435,8 +435,10 @@ def test_bench_shape_bs32_384x448_backward_vs_oracle():
     buffer-range-clamp branches of the weight-gradient kernels), default routing, asynchronous lane: losses (2e-5) and EVERY
     parameter gradient against the oracle run on the host in chunks of 8 pairs (oracle.train_grads_chunked == the whole-batch
     step, tests/test_oracle_golden.py)."""
+    from irr_amd import conv as C
     routing = _vs_chunked_oracle(32, 384, 448, 8, tol=3e-4)
-    for fam in ("fwd_x3", "fwd_x3s", "dgrad_x3", "dense_column_x3", "wgrad_x3", "wgrad_x3_dil"):
+    for fam in (("fwd_h2", "fwd_x3s", "dgrad_h2", "dense_column_h2", "wgrad_h2", "wgrad_x3") if C.MATH == "h2" else
+                ("fwd_x3", "fwd_x3s", "dgrad_x3", "dense_column_x3", "wgrad_x3", "wgrad_x3_dil")):
         assert routing.get(fam, 0) > 0, (fam, routing)
 
 
@@ -446,8 +448,12 @@ def test_config4_share_bs8_448x1024_backward_vs_oracle():
 
 
 def test_async_wgrad_lane_is_race_free_at_4x384x448():
-    """test_async_wgrad_lane_is_race_free (tests/test_e2e_gpu.py) at a shape whose kernels run for milliseconds: every gradient
-    of four two-stream backward passes equals the single-stream gradient of the same inputs."""
+    """test_async_wgrad_lane_is_race_free (tests/test_e2e_gpu.py) at a shape whose kernels run for milliseconds: every gradient of
+    eight two-stream backward passes equals the single-stream gradient of the same inputs up to the order of its float atomics.
+    The detector is the gradient with respect to the IMAGES (pure main-stream work, the end of the longest dependency chain):
+    single-stream passes repeat it to 9e-7; round 4 found passes at 4-6e-6 whenever the main stream ran two or more lane groups
+    ahead (WgradSide.max_lead, irr_amd/conv_lane.py: cause not found, bounded lead as the remedy) -- the bound asserted here, 2e-6,
+    separates the two states."""
     m, mal, arena, opt, step = _setup(4, lane=False)
     b = _batch(4, 384, 448)
 
@@ -456,21 +462,33 @@ def test_async_wgrad_lane_is_race_free_at_4x384x448():
             arena.enable_async_wgrad()
         try:
             arena.zero_grad()
+            for k in ("input1", "input2"):
+                b[k].grad = None
+                b[k].requires_grad_(True)
             ld, _ = mal(b)
             ld["total_loss"].backward()
             arena.sync()
             torch.cuda.synchronize()
-            return arena.flat.clone()
+            return arena.flat.clone(), torch.cat([b["input1"].grad.flatten(), b["input2"].grad.flatten()]).clone()
         finally:
             if lane:
                 arena.disable_async_wgrad()
 
-    ref = grads(False)
-    for it in range(4):
-        g = grads(True)
+    ref, ref_img = grads(False)
+    again, again_img = grads(False)
+    noise = (again_img - ref_img).double().norm().item() / ref_img.double().norm().item()
+    assert noise <= 2e-6, noise
+    for it in range(8):
+        g, img = grads(True)
         d = (g - ref).double().norm().item() / ref.double().norm().item()
-        bad = ((g - ref).abs() > 1e-3 * ref.abs() + 1e-4).sum().item()
-        assert d <= 1e-4 and bad == 0, (it, d, bad)
+        di = (img - ref_img).double().norm().item() / ref_img.double().norm().item()
+        off, worst = 0, 0.0
+        for p_ in m.parameters():
+            k = p_.numel()
+            e = (g[off:off + k] - ref[off:off + k]).double().norm().item() / (ref[off:off + k].double().norm().item() + 1e-30)
+            worst = max(worst, e)
+            off += k
+        assert d <= 5e-7 and di <= 2e-6 and worst <= 1e-5, (it, d, di, worst)
 
 
 def test_direct_wgrad_same_stream_matches_autograd_path():
