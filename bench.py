@@ -54,7 +54,7 @@ def kernel_name(var):
         return (f"conv_x3_kernel<{c // 1000},{(c // 100) % 10},{(c // 10) % 10},{X3_PLANES.get(c % 10, 0)},2>", H2_PEAK_TFLOPS)
     if var >= 100000:
         c = var - 100000
-        return (f"conv_x3_kernel<{c // 1000},{(c // 100) % 10},{(c // 10) % 10},{X3_PLANES.get(c % 10, 0)}>", X3_PEAK_TFLOPS)
+        return (f"conv_x3_kernel<{c // 1000},{(c // 100) % 10},{(c // 10) % 10},{X3_PLANES.get(c % 10, 0)},3>", X3_PEAK_TFLOPS)
     return (f"conv_fwd_kernel<{var // 100},{(var // 10) % 10},{var % 10}>", FP32_MFMA_PEAK_TFLOPS)
 CONV_GFLOP_PER_PAIR = {(384, 448): 1088.4, (448, 1024): 2902.5}   # 3x forward conv FLOPs
 SECONDARY = (8, 448, 1024)             # per-GPU share of BASELINE configs[4] (Sintel-shaped 448x1024, bs64 on 8 GPUs)
@@ -495,6 +495,12 @@ def main():
                                        "before_backward (.item(), as the reference)"},
                "loss": head["loss"],
                "conv_math": C.MATH,
+               "conv_math_note": {"h2": "fp32 tensors in HBM; the MFMA convs split every operand, scaled by a power of two from max|.| of its "
+                                        "tensor, into two fp16 pieces (23 significant bits) and accumulate three piece products in fp32 "
+                                        "(v_mfma_f32_32x32x16_f16); error against fp64 = the fp32-MFMA kernels' (profiles/r4_h2_check.txt, "
+                                        "tests/test_h2_gpu.py); IRR_CONV_MATH=x3: bf16x3 / six products, =f32: fp32 MFMA",
+                                  "x3": "fp32 tensors in HBM; the MFMA convs split every operand into three bf16 pieces and accumulate six "
+                                        "piece products in fp32", "f32": "fp32 MFMA everywhere"}.get(C.MATH),
                "launches_per_step": head["routing"],
                "step_conv_tflops": round(value / world * gf * 1e9 / 1e12, 1) if gf else None,
                # whole-step conv rate over the fp32-MFMA peak (157.3): above 1 because the x3 family runs fp32 products on the bf16 pipe
