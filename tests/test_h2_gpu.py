@@ -181,6 +181,6 @@ def test_dense_estimator_and_chain_nodes_on_h2(h2_everywhere):
 
     ref = run("f32")
     got = run("h2")
-    assert C.LAUNCHES["fwd_h2"] >= 8 and C.LAUNCHES["dense_column_h2"] >= 4 and C.LAUNCHES["wgrad_h2"] >= 8 and C.LAUNCHES["dgrad_h2"] >= 3, dict(C.LAUNCHES)
+    assert C.LAUNCHES["fwd_h2"] >= 8 and C.LAUNCHES["dense_column_h2"] >= 4 and C.LAUNCHES["wgrad_h2"] >= 7 and C.LAUNCHES["dgrad_h2"] >= 3, dict(C.LAUNCHES)
     for i, (a, b) in enumerate(zip(got, ref)):
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-30, i
