@@ -15,6 +15,10 @@ from . import hip
 from .conv_pack import LAUNCHES
 
 
+POOL_SLOTS = 4096
+_POOLS = {}
+
+
 class Amax:
     """``n`` consecutive float32 slots of ``slots`` starting at ``first``: their maximum bounds |t| of some tensor t"""
     __slots__ = ("slots", "first", "n")
@@ -25,7 +29,18 @@ class Amax:
 
     @staticmethod
     def zeros(device, n: int = 1) -> "Amax":
-        return Amax(torch.zeros(n, device=device, dtype=torch.float32), 0, n)
+        """n fresh zeroed slots.  They are carved from a zero-filled pool tensor per device (one fill launch per POOL_SLOTS slots
+        instead of one per autograd node, ~100 per step); a slot is handed out once and never reused, an exhausted pool is
+        replaced (the old one lives as long as any Amax refers to it)."""
+        if torch.cuda.is_current_stream_capturing():          # a captured step owns its slots: the replay must find them zeroed
+            return Amax(torch.zeros(n, device=device, dtype=torch.float32), 0, n)
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        pool = _POOLS.get(key)
+        if pool is None or pool[1] + n > POOL_SLOTS:
+            pool = _POOLS[key] = [torch.zeros(POOL_SLOTS, device=device, dtype=torch.float32), 0]
+        first = pool[1]
+        pool[1] += n
+        return Amax(pool[0], first, n)
 
     def ptr(self) -> int:
         return self.slots.data_ptr() + 4 * self.first

@@ -190,7 +190,7 @@ class _DenseEstimatorFn(hip.Function):
         # its launch folds the magnitude of its output into slot 4-i
         S = None
         if _fwd_h2(buf[:, 448:ctot], ws[0], 1, 1):
-            S = Amax.zeros(buf.device, 6)
+            S = Amax.zeros(buf.device, 7)                        # (slot 6: the est slot behind the parts, when there is one)
             amax_measure(buf[:, 448:ctot], S.sub(5))
         off = 448
         for i in range(5):
@@ -203,15 +203,21 @@ class _DenseEstimatorFn(hip.Function):
             base_c = base if _planes_dense(base) else base.contiguous()
             out = conv_forward(buf[:, :ctot], ws[5], bs[5], 1, 1, False, res=base_c, alpha=1.0)
             buf[:, ctot:].copy_(out)
+            if S is not None:
+                amax_measure(out, S.sub(6))
         else:
             out = conv_forward(buf[:, :ctot], ws[5], bs[5], 1, 1, False)
         ctx.save_for_backward(buf, *ws)
         ctx.cfg = (cin0, E, has_base, tuple(widths), int(nrelu))
         ctx.wobjs, ctx.bobjs = ws, bs
-        return buf, out
+        # third output: the slots that bound |buf| (parts + est), for a consumer of the whole buffer (the context network)
+        slots = S.slots[S.first:S.first + S.n] if S is not None else None
+        if slots is not None:
+            ctx.mark_non_differentiable(slots)
+        return buf, out, slots
 
     @staticmethod
-    def backward(ctx, g_buf, g_out):
+    def backward(ctx, g_buf, g_out, _g_slots=None):
         buf = ctx.saved_tensors[0]
         ws = ctx.saved_tensors[1:]
         cin0, E, has_base, widths, nrelu = ctx.cfg
@@ -316,7 +322,10 @@ def dense_estimator(x, base, weights_and_biases, preact_grad_channels: int = 0):
         raise RuntimeError("irr_amd conv runs on the HIP device only (no CPU fallback)")
     if preact_grad_channels and preact_grad_channels != int(parts[0].shape[1]):
         raise ValueError("preact_grad_channels must cover exactly the first input part")
-    return _DenseEstimatorFn.apply(len(parts), base, int(preact_grad_channels), *parts, *weights_and_biases)
+    buf, out, slots = _DenseEstimatorFn.apply(len(parts), base, int(preact_grad_channels), *parts, *weights_and_biases)
+    if slots is not None:                                   # (read by conv_chain when this very tensor object is its input)
+        buf.__dict__["_irr_amax"] = Amax(slots, 0, 7 if base is not None else 6)
+    return buf, out
 
 
 # ----------------------------------------------------------------------------------------------
@@ -333,7 +342,7 @@ class _ConvChainFn(hip.Function):
     pre-activation gradient layer i-1 needs, and every bias gradient comes out of the wgrad launch."""
 
     @staticmethod
-    def forward(ctx, x, res, cfg, *wb):
+    def forward(ctx, x, res, cfg, x_amax, *wb):
         ws, bs = wb[0::2], wb[1::2]
         x = x if _planes_dense(x) else x.contiguous()
         acts = []
@@ -350,7 +359,10 @@ class _ConvChainFn(hip.Function):
         slots = Amax.zeros(x.device, n) if any(h2_in) else None
         in_amax = [slots.sub(i) if h2_in[i] else None for i in range(n)]
         if h2_in[0]:
-            amax_measure(x, in_amax[0])
+            if x_amax is not None:                             # the producer of x already knows its magnitude
+                in_amax[0] = x_amax
+            else:
+                amax_measure(x, in_amax[0])
         for i in range(n):
             stride, dil, lrelu = cfg[i]
             last = i == n - 1
@@ -423,7 +435,7 @@ class _ConvChainFn(hip.Function):
             else:
                 g = None
             ga = gxa
-        return (g, gres, None) + tuple(grads)
+        return (g, gres, None, None) + tuple(grads)
 
 
 def conv_chain(x, layers, res=None):
@@ -434,7 +446,10 @@ def conv_chain(x, layers, res=None):
     wb = []
     for l in layers:
         wb += [l.weight, l.bias]
-    return _ConvChainFn.apply(x, res, cfg, *wb)
+    xa = x.__dict__.get("_irr_amax")
+    if not (isinstance(xa, Amax) and xa.slots.device == x.device and x.dim() == 4):
+        xa = None
+    return _ConvChainFn.apply(x, res, cfg, xa, *wb)
 
 
 # ----------------------------------------------------------------------------------------------
