@@ -95,10 +95,13 @@ class _PackRegistry:
         norms = torch._foreach_norm([w for w, _ in live], float("inf"))
         torch._foreach_copy_([t for _, t in live], [n_.reshape(1) for n_ in norms])
         LAUNCHES["amax_weights"] += 1
+        alive = []
         for refs, g in self.amax_groups:
             ws = [r() for r in refs]
             if all(w is not None for w in ws):
                 torch.amax(torch.cat([w.__dict__["_irr_amax"] for w in ws]).reshape(1, -1), dim=1, out=g)
+                alive.append((refs, g))
+        self.amax_groups = alive                              # (groups of dead models go)
 
 
 _REGISTRIES = {}
