@@ -211,7 +211,9 @@ def test_train_step_applies_augmentation_before_the_forward_pass():
             losses.append((float(ld["total_loss"].detach()), opt.param_flat.double().sum().item()))
         finally:
             arena.disable_async_wgrad()
-    assert losses[0][0] == pytest.approx(losses[1][0], rel=1e-5) and losses[0][1] == pytest.approx(losses[1][1], rel=1e-7), losses
+    # (the parameter sum after ONE Adam step moves by 2e-4 for every near-zero gradient whose sign the float atomics of the backward
+    # pass decide: run-to-run 1e-7 relative, seen at 1.1e-7 once in six runs -- 1e-6 still separates a wrong batch by orders of magnitude)
+    assert losses[0][0] == pytest.approx(losses[1][0], rel=1e-5) and losses[0][1] == pytest.approx(losses[1][1], rel=1e-6), losses
 
 
 def test_step_without_grad_sync_still_steps_on_complete_gradients():
