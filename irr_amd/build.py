@@ -26,8 +26,13 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libirr_hip.so")
 ARCH = "gfx950"
 
+# -fno-slp-vectorize -fno-vectorize for EVERY file (round 4, profiles/NOTES.md C.3): the vectorisers turn adjacent scalar fp32 operations
+# into packed ones (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), and a wave executing those gave WRONG results whenever a wave of another
+# kernel that streams MFMAs shared its SIMD -- conv_smallco_dgrad4_kernel beside the dilation-16 weight gradient on the second
+# stream: 30-39 of 40 launches off by 4e-3, 0 of 40 with scalar v_fmac_f32 (tools/pair_probe.py).  (Beside MFMAs of the SAME wave a
+# packed fp32 instruction also costs far more than its issue slot: x3_split.h.)
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
-          "-Wno-unused-function"]
+          "-Wno-unused-function", "-fno-slp-vectorize", "-fno-vectorize"]
 _BASE_FLAGS = len(COMMON)  # everything appended below is an ablation / trace macro switch
 # per-file extras.  warp.hip reproduces ATen's fp32 rounding sequence: no contraction there.
 if os.environ.get("IRR_WG_ABL"):
@@ -65,11 +70,8 @@ if os.environ.get("IRR_WG_TR4"):
 if len(COMMON) != _BASE_FLAGS and not TAG:
     raise RuntimeError("ablation / trace macros change the kernels: set IRR_BUILD_TAG=<name> so the build goes to "
                        "irr_amd/lib_<name>/ instead of replacing the product library")
-# The x3 kernels are compiled without the SLP vectoriser: it turns adjacent scalar fp32 adds into v_pk_add_f32, and a packed
-# fp32 instruction beside a stream of MFMAs costs far more than its issue slot (x3_split.h; +0.3-0.6 % per train step).
 EXTRA = {"warp.hip": ["-ffp-contract=off"], "resize.hip": ["-ffp-contract=off"],
-         "augment.hip": ["-ffp-contract=off"],
-         "conv_wgrad_x3.hip": ["-fno-slp-vectorize"], "conv_x3.hip": ["-fno-slp-vectorize"]}
+         "augment.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:

@@ -89,7 +89,7 @@ class WgradSide:
         # held alive here and the backward nodes never touch a gradient slice again once its weight-gradient launch is issued).
         self.group = max(1, int(os.environ.get("IRR_LANE_GROUP", "4")))
         self._queued = []                       # (fn, tensors, params) not handed to the lane yet
-        self.max_lead = max(0, int(os.environ.get("IRR_LANE_MAX_LEAD", "1")))      # groups the main stream may run ahead (0: unbounded), see _kick
+        self.max_lead = max(0, int(os.environ.get("IRR_LANE_MAX_LEAD", "0")))      # groups the main stream may run ahead (0: unbounded), see _kick
         # The routed gradients are complete only after flush() + join().  GradArena.sync() / FusedAdam.step() / TrainStep do
         # that explicitly; for every other caller (the reference's own ``loss.backward(); optimizer.step()`` loop,
         # runtime.py:188-189) the first launch of a backward pass registers join() as a FINAL CALLBACK of that pass: it runs on
@@ -131,15 +131,12 @@ class WgradSide:
         if not torch.cuda.is_current_stream_capturing():      # (an event recorded inside a capture cannot be queried)
             while self._inflight and self._inflight[0][0].query():
                 self._inflight.popleft()
-            # Bounded lead: the main stream never runs more than `max_lead` handed-over groups ahead of the lane (it waits for the
-            # group before that).  Round 4 measured (tools/lane_race_probe.py, tools/node_probe.py, profiles/NOTES.md section C):
-            # with the main stream two or more groups ahead, single data-gradient results at the 96x112 level came out
-            # with 5e-3-level deviations in half of the samples in about every second pass -- 5e-6 on the image gradient, <= 5e-5
-            # on the worst parameter gradient, far inside the parity tolerances, with both split-operand forms (rarely with
-            # bf16x3, whose main stream is slower, often with fp16x2), never on one stream and never with a lead of one group.
-            # The cause is NOT found (ruled out: the amax slots and their atomics, memory lifetimes / the caching allocator,
-            # uninitialised reads, register spills, same-stream kernel overlap, the round-4 warp / cost-volume kernels; every
-            # launch is bit-reproducible beside any other launch in isolation).  The bound costs 1 % of the step.
+            # Optional bound on how far the main stream runs ahead of the lane (IRR_LANE_MAX_LEAD = n groups; 0 = unbounded, the
+            # default).  It was the stop-gap for round 4's lane deviation (5e-6 on the image gradient in every second pass) until
+            # the cause was found: packed fp32 VALU instructions (v_pk_fma_f32, emitted by the SLP vectoriser in
+            # conv_smallco_dgrad4_kernel) return wrong results while a wave of ANOTHER kernel that streams MFMAs shares the SIMD --
+            # the dilation-16 weight gradient on the lane is the one launch shape whose blocks leave room for that.  The library is
+            # built without the vectorisers since (irr_amd/build.py; tools/pair_probe.py reproduces the pair in two seconds).
             if self.max_lead and len(self._inflight) > self.max_lead:
                 torch.cuda.current_stream().wait_event(self._inflight[-self.max_lead - 1][0])
         if self.batch is None or not self.batch.n:

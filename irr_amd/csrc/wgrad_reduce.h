@@ -47,17 +47,24 @@ __device__ __forceinline__ void irr_reduce_block(const IrrReduceJob& J, long blk
   f4 s = {0.f, 0.f, 0.f, 0.f};
   if ((J.n & 3) == 0) {
     if (j0 < J.n) {
+      // (component-wise adds on purpose: vector-typed arithmetic becomes v_pk_add_f32, and packed fp32 instructions gave wrong
+      // results beside MFMA waves of another stream -- this kernel runs on the lane beside the main stream's convolutions; build.py)
       f4 a0 = s, a1 = s, a2 = s, a3 = s;
+      auto add4 = [](f4& a, const f4 v) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += v[e];
+      };
       int p = pl;
       for (; p + 12 < J.P; p += 16) {
         const f4 v0 = *(const f4*)(J.ws + (long)p * J.n + j0), v1 = *(const f4*)(J.ws + (long)(p + 4) * J.n + j0),
                  v2 = *(const f4*)(J.ws + (long)(p + 8) * J.n + j0), v3 = *(const f4*)(J.ws + (long)(p + 12) * J.n + j0);
-        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        add4(a0, v0); add4(a1, v1); add4(a2, v2); add4(a3, v3);
       }
-      if (p < J.P) a0 += *(const f4*)(J.ws + (long)p * J.n + j0);
-      if (p + 4 < J.P) a1 += *(const f4*)(J.ws + (long)(p + 4) * J.n + j0);
-      if (p + 8 < J.P) a2 += *(const f4*)(J.ws + (long)(p + 8) * J.n + j0);
-      s = (a0 + a1) + (a2 + a3);
+      if (p < J.P) add4(a0, *(const f4*)(J.ws + (long)p * J.n + j0));
+      if (p + 4 < J.P) add4(a1, *(const f4*)(J.ws + (long)(p + 4) * J.n + j0));
+      if (p + 8 < J.P) add4(a2, *(const f4*)(J.ws + (long)(p + 8) * J.n + j0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = (a0[e] + a1[e]) + (a2[e] + a3[e]);
     }
   } else {
 #pragma unroll
