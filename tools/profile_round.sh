@@ -26,7 +26,7 @@ python tools/rocpd_traffic_json.py $F $W > $OUT/hbm_traffic.json
 rm -rf $OUT/pf $OUT/pw
 IRR_CONV_MATH=f32 python bench.py --no-cpu-baseline --no-secondary --no-extra-legs > $OUT/${TAG}_bench_math_f32.json 2>> $OUT/${TAG}_bench.err
 IRR_CONV_MATH=x3 python bench.py --no-cpu-baseline --no-secondary --no-extra-legs > $OUT/${TAG}_bench_math_x3.json 2>> $OUT/${TAG}_bench.err
-IRR_LANE_MAX_LEAD=0 python bench.py --no-cpu-baseline --no-secondary --no-extra-legs > $OUT/${TAG}_bench_unbounded_lead.json 2>> $OUT/${TAG}_bench.err
+IRR_LANE_MAX_LEAD=1 python bench.py --no-cpu-baseline --no-secondary --no-extra-legs > $OUT/${TAG}_bench_bounded_lead.json 2>> $OUT/${TAG}_bench.err
 # 4. the second crop of north_star (per-GPU share of configs[4]): kernel stats + PMC passes of its own
 python bench.py --no-cpu-baseline --no-extra-legs --batch 8 --height 448 --width 1024 > $OUT/${TAG}_bench_448x1024_bs8.json 2>> $OUT/${TAG}_bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/kt2 -o kt2 -- python3 bench.py --no-cpu-baseline --no-extra-legs --batch 8 --height 448 --width 1024 --steps 5 > $OUT/${TAG}_bench_448x1024_under_rocprof.json 2>> $OUT/${TAG}_bench.err
@@ -45,8 +45,8 @@ python tools/warp_bench.py 2>/dev/null > $OUT/${TAG}_warp_bench.txt
 python tools/wx3_check.py 2>/dev/null > $OUT/${TAG}_wgrad_x3_microbench.txt
 python tools/h2_check.py 2>/dev/null > $OUT/${TAG}_h2_check.txt
 python tools/lane_race_probe.py 12 2>/dev/null > $OUT/${TAG}_lane_probe.txt
-IRR_LANE_MAX_LEAD=0 python tools/lane_race_probe.py 12 2>/dev/null > $OUT/${TAG}_lane_probe_unbounded.txt
-IRR_CONV_MATH=x3 IRR_LANE_MAX_LEAD=0 python tools/lane_race_probe.py 24 2>/dev/null > $OUT/${TAG}_lane_probe_unbounded_x3.txt
+IRR_CONV_MATH=x3 python tools/lane_race_probe.py 24 2>/dev/null > $OUT/${TAG}_lane_probe_x3.txt
+python tools/pair_probe.py 2>/dev/null > $OUT/${TAG}_pair_probe.txt
 python tools/truth_probe.py 2>/dev/null > $OUT/${TAG}_math_agreement.txt
 python tools/level_times.py 2>/dev/null > $OUT/${TAG}_level_times.txt
 python tools/conv_breakdown.py 32 --fp32 2>/dev/null > $OUT/${TAG}_conv_breakdown.txt
