@@ -364,6 +364,12 @@ def main():
                 "by_kernel": {kernel_name(v)[0]: {"launches": s_["calls"], "ms_per_step": round(s_["seconds"] / steps * 1e3, 2),
                                                   "achieved": round(s_["flops"] / s_["seconds"] / 1e12, 1)}
                               for v, s_ in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:6]}}
+        if kname == "conv_x3s_kernel":
+            # the 32-channel streaming kernel is bandwidth-bound: 72 FLOP per algorithmic byte for a 32 -> 32 layer
+            roof["bandwidth_view"] = {"bound": "hbm", "algorithmic_TBps": round(ach / 72.0, 3), "exclusive_algorithmic_TBps":
+                                      round(st["fwd_flops"] / st["fwd_seconds"] / 1e12 / 72.0, 3) if st["fwd_seconds"] > 0 else None,
+                                      "peak_TBps": 8.0, "note": "in + out maps of a 32 -> 32 layer = FLOPs / 72; residual / mask / accumulate operands "
+                                      "come on top (PMC: profiles/hbm_traffic.json)"}
         # HBM bytes per launch of that kernel from the committed PMC passes (profiles/hbm_traffic*.json: separate --pmc FETCH_SIZE /
         # WRITE_SIZE runs of THIS command, FETCH x2 gfx950 correction).  PMC counters cannot be collected from inside the process,
         # so the bytes are only reported when the json was measured on a library built from the very sources that are loaded now.
