@@ -379,6 +379,13 @@ def main():
             if tr.get("_source_hash") != B_.source_hash() or B_.built_hash() != B_.source_hash():
                 roof["traffic_source"] = (f"stale: {TRAFFIC_FILES[(height, width, batch_pairs)]} was measured on sources "
                                           f"{tr.get('_source_hash')}, the library is built from {B_.source_hash()}")
+            elif k == "conv_x3s_kernel" and any(n.startswith("conv_x3s_kernel<") for n in tr):
+                # (the timer does not distinguish the streaming kernel's epilogue variants: launch-weighted mean over them)
+                ent = [v for n, v in tr.items() if n.startswith("conv_x3s_kernel<")]
+                nl = sum(v["launches"] for v in ent)
+                roof["traffic"] = round(sum((v["fetch_MB_per_launch_corrected"] + v["write_MB_per_launch"]) * v["launches"] for v in ent) / nl * 1e6)
+                roof["traffic_source"] = (f"profiles/{TRAFFIC_FILES[(height, width, batch_pairs)]} (rocprofv3 PMC passes over this "
+                                          f"command, launch-weighted mean over the kernel's epilogue variants, sources {tr['_source_hash']})")
             elif k in tr:
                 roof["traffic"] = round((tr[k]["fetch_MB_per_launch_corrected"] + tr[k]["write_MB_per_launch"]) * 1e6)
                 roof["traffic_source"] = (f"profiles/{TRAFFIC_FILES[(height, width, batch_pairs)]} (rocprofv3 PMC passes over this "
