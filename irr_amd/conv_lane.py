@@ -133,10 +133,9 @@ class WgradSide:
                 self._inflight.popleft()
             # Optional bound on how far the main stream runs ahead of the lane (IRR_LANE_MAX_LEAD = n groups; 0 = unbounded, the
             # default).  It was the stop-gap for round 4's lane deviation (5e-6 on the image gradient in every second pass) until
-            # the cause was found: packed fp32 VALU instructions (v_pk_fma_f32, emitted by the SLP vectoriser in
-            # conv_smallco_dgrad4_kernel) return wrong results while a wave of ANOTHER kernel that streams MFMAs shares the SIMD --
-            # the dilation-16 weight gradient on the lane is the one launch shape whose blocks leave room for that.  The library is
-            # built without the vectorisers since (irr_amd/build.py; tools/pair_probe.py reproduces the pair in two seconds).
+            # it was traced: the SLP-vectorised build of conv_smallco_dgrad4_kernel (v_pk_fma_f32) returns wrong values while waves of
+            # the lane's dilation-16 weight gradient -- the one launch shape whose four-wave blocks leave room for other waves on their
+            # SIMDs -- run beside it; built without the vectoriser it does not.  The library is built without the vectorisers since (irr_amd/build.py; tools/pair_probe.py reproduces the pair in two seconds).
             if self.max_lead and len(self._inflight) > self.max_lead:
                 torch.cuda.current_stream().wait_event(self._inflight[-self.max_lead - 1][0])
         if self.batch is None or not self.batch.n:

@@ -1,4 +1,4 @@
-"""Round 4: packed fp32 VALU instructions beside MFMA waves of another stream (irr_amd/build.py, profiles/NOTES.md C.3)."""
+"""Round 4: the kernel pair behind the lane deviation, and the build flags that keep it away (irr_amd/build.py, profiles/NOTES.md C.3)."""
 import pytest
 import torch
 
@@ -46,7 +46,7 @@ def test_smallco_data_gradient_is_bit_stable_beside_the_dilated_weight_gradient(
 
 
 def test_library_has_no_packed_fp32_math_outside_the_forward_cost_volume():
-    """the build flags that keep the vectorisers out (a kernel with packed fp32 math is only safe where no MFMA kernel of another
-    stream can run beside it: corr81_fwd4_kernel, forward pass)"""
+    """the build flags that keep the vectorisers out (only corr81_fwd4_kernel -- forward pass, nothing of another stream beside it --
+    keeps explicit packed math)"""
     from irr_amd import build
     assert "-fno-slp-vectorize" in build.COMMON and "-fno-vectorize" in build.COMMON

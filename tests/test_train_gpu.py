@@ -453,9 +453,9 @@ def test_async_wgrad_lane_is_race_free_at_4x384x448():
     """test_async_wgrad_lane_is_race_free (tests/test_e2e_gpu.py) at a shape whose kernels run for milliseconds: every gradient of
     eight two-stream backward passes equals the single-stream gradient of the same inputs up to the order of its float atomics.
     The detector is the gradient with respect to the IMAGES (pure main-stream work, the end of the longest dependency chain):
-    single-stream passes repeat it to 9e-7.  Round 4 found passes at 4-6e-6: a main-stream kernel with packed fp32 instructions
-    (conv_smallco_dgrad4_kernel, v_pk_fma_f32 from the SLP vectoriser) returned wrong values whenever waves of the lane's
-    dilation-16 weight gradient shared its SIMDs; the library is built without the vectorisers since (irr_amd/build.py,
+    single-stream passes repeat it to 9e-7.  Round 4 found passes at 4-6e-6: the SLP-vectorised build of a main-stream kernel
+    (conv_smallco_dgrad4_kernel, v_pk_fma_f32) returned wrong values whenever waves of the lane's dilation-16 weight gradient ran
+    beside it; the library is built without the vectorisers since (irr_amd/build.py,
     tools/pair_probe.py).  The bound asserted here, 2e-6, separates the two states."""
     m, mal, arena, opt, step = _setup(4, lane=False)
     b = _batch(4, 384, 448)
