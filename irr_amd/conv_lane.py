@@ -135,7 +135,8 @@ class WgradSide:
             # default).  It was the stop-gap for round 4's lane deviation (5e-6 on the image gradient in every second pass) until
             # it was traced: the SLP-vectorised build of conv_smallco_dgrad4_kernel (v_pk_fma_f32) returns wrong values while waves of
             # the lane's dilation-16 weight gradient -- the one launch shape whose four-wave blocks leave room for other waves on their
-            # SIMDs -- run beside it; built without the vectoriser it does not.  The library is built without the vectorisers since (irr_amd/build.py; tools/pair_probe.py reproduces the pair in two seconds).
+            # SIMDs -- run beside it (one packed instruction with swapped accumulator halves); built without the vectoriser it
+            # does not.  The library is built without the vectorisers since (irr_amd/build.py; tools/pair_probe.py reproduces the pair in two seconds).
             if self.max_lead and len(self._inflight) > self.max_lead:
                 torch.cuda.current_stream().wait_event(self._inflight[-self.max_lead - 1][0])
         if self.batch is None or not self.batch.n:
