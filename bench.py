@@ -49,6 +49,8 @@ def kernel_name(var):
     """variant code of irr_amd.conv's KernelTimer -> (kernel template instantiation, its MFMA roof in fp32 TFLOP/s)"""
     if var == 109001:
         return ("conv_x3s_kernel", X3_PEAK_TFLOPS)
+    if var == 209001:                      # the streaming kernel in its fp16x2 form (conv_x3s_kernel<EPI, 2>)
+        return ("conv_x3s_kernel", H2_PEAK_TFLOPS)
     if var >= 200000:
         c = var - 200000
         return (f"conv_x3_kernel<{c // 1000},{(c // 100) % 10},{(c // 10) % 10},{X3_PLANES.get(c % 10, 0)},2>", H2_PEAK_TFLOPS)

@@ -272,8 +272,9 @@ int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* gw, float* w
  *   stores into that slot (atomic max), so a chain of launches needs no separate pass over its activations.
  * Weights: irr_conv_pack_weights_h2 / _h2_sub = the x3 packers with two pieces per fragment; amax = device scalar >= max |w|
  * over every weight that goes into wq (one scale per packed matrix; its exponent is stored in the 16-B unit behind the last
- * fragment: irr_conv_h2_packed_bytes includes it).  irr_conv2d_h2_eligible: irr_conv2d_x3_eligible without the problems of the
- * streaming 32-channel kernel (those stay on bf16x3).  irr_conv2d_fwd_h2: contract of irr_conv2d_fwd_x3_splitk (ws nullable).
+ * fragment: irr_conv_h2_packed_bytes includes it).  irr_conv2d_h2_eligible: the code of irr_conv2d_x3_eligible (9001 = the
+ * streaming 32-channel kernel, which has the same two forms).  irr_conv2d_fwd_h2: contract of irr_conv2d_fwd_x3_splitk (ws
+ * nullable); irr_conv2d_fwd_h2_dual: contract of irr_conv2d_fwd_x3_dual (y_amax bounds y, the sum).
  * irr_conv2d_wgrad_h2: contract of irr_conv2d_wgrad_x3 (dil == 1) / irr_conv2d_wgrad_x3_dil (dil > 1), same scratch and fold. */
 int irr_amax_f32(const float* x, int B, long n, long bs, float* slot, void* stream);
 long irr_conv_h2_packed_bytes(int Cin, int Cout);
@@ -290,6 +291,10 @@ int irr_conv2d_fwd_h2(const float* x, const void* wq, const float* bias, const f
                       int lrelu, float alpha, int accumulate,
                       const float* mask, long mask_bs, int nmask, float* ws, long ws_elems,
                       const float* x_amax, int n_amax, float* y_amax, void* stream);
+int irr_conv2d_fwd_h2_dual(const float* x, const void* wq, const float* bias, const float* res, float* y, float* y2,
+                           int B, int Cin, int H, int W, int Cout, int dil,
+                           long x_bs, long y_bs, long res_bs, long y2_bs, int lrelu, float alpha,
+                           const float* x_amax, int n_amax, float* y_amax, void* stream);
 int irr_conv2d_wgrad_h2(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                         int B, int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs,
                         const float* x_amax, int nx, const float* gy_amax, int ng, void* stream);

@@ -113,7 +113,7 @@ def x3_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, di
 
 
 def h2_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, dil: int) -> int:
-    """non-zero: the problem runs on the fp16x2 form of conv_x3_kernel (MATH == "h2" and not a streaming-kernel problem)"""
+    """non-zero: the problem runs on the fp16x2 form of conv_x3_kernel / conv_x3s_kernel (9001: the streaming one)"""
     if MATH != "h2" or not x3_code(B, cin, H, W, cout, k, stride, dil):
         return 0
     return int(hip.lib().irr_conv2d_h2_eligible(B, cin, H, W, cout, k, stride, dil))
@@ -185,7 +185,7 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
         if h2:
             args, _xa = _h2_args(args, x, x_amax, y_amax)
         variant = (200000 if h2 else 100000) + code
-        LAUNCHES["fwd_h2" if h2 else "fwd_x3s" if code == 9001 else "fwd_x3"] += 1
+        LAUNCHES["fwd_x3s" if code == 9001 else "fwd_h2" if h2 else "fwd_x3"] += 1          # (fwd_x3s: the streaming kernel, either form)
     else:
         LAUNCHES["fwd_f32"] += 1
         wp = packed_weights(weight, False)
@@ -205,25 +205,38 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return out
 
 
-def conv_forward_skip(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], lrelu: bool, skip: torch.Tensor):
+def conv_forward_skip(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], lrelu: bool, skip: torch.Tensor,
+                      x_amax: Optional[Amax] = None, y_amax: Optional[Amax] = None):
     """(e, y) with e = act(conv3x3(x) + bias) and y = skip + e.  On the streaming 32-channel kernel both come out of ONE launch
-    (irr_conv2d_fwd_x3_dual); elsewhere e is computed and the sum is an elementwise pass."""
+    (irr_conv2d_fwd_x3_dual / _h2_dual); elsewhere e is computed and the sum is an elementwise pass.  x_amax / y_amax: as in
+    conv_forward (y_amax bounds y)."""
     B, cin, H, W = x.shape
     cout = weight.shape[0]
     if x3_code(B, cin, H, W, cout, 3, 1, 1) == 9001 and _planes_dense(skip) and not os.environ.get("IRR_X3S_NO_DUAL"):      # (A/B switch)
+        h2 = bool(h2_code(B, cin, H, W, cout, 3, 1, 1))
         e = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
         y = torch.empty_like(e)
-        wq = packed_weights_x3(weight, False)
+        wq = packed_weights_h2(weight, False) if h2 else packed_weights_x3(weight, False)
         LAUNCHES["fwd_x3s"] += 1
-        args = ("irr_conv2d_fwd_x3_dual", hip.ptr(x), hip.ptr(wq), hip.ptr(bias.detach() if bias is not None else None), hip.ptr(skip),
-                hip.ptr(y), hip.ptr(e), B, cin, H, W, cout, 1, hip.bs(x), hip.bs(y), hip.bs(skip), hip.bs(e), int(lrelu), 1.0, hip.stream())
+        args = ("irr_conv2d_fwd_h2_dual" if h2 else "irr_conv2d_fwd_x3_dual", hip.ptr(x), hip.ptr(wq),
+                hip.ptr(bias.detach() if bias is not None else None), hip.ptr(skip),
+                hip.ptr(y), hip.ptr(e), B, cin, H, W, cout, 1, hip.bs(x), hip.bs(y), hip.bs(skip), hip.bs(e), int(lrelu), 1.0)
+        if h2:
+            xa = x_amax if x_amax is not None else amax_measure(x)
+            args += (xa.ptr(), xa.n, y_amax.ptr() if y_amax is not None else None)
+        args += (hip.stream(),)
         if TIMER is None:
             hip.call(*args)
         else:
-            TIMER.wrap(100000 + 9001, 2.0 * B * H * W * cout * cin * 9, lambda: hip.call(*args))
+            TIMER.wrap((200000 if h2 else 100000) + 9001, 2.0 * B * H * W * cout * cin * 9, lambda: hip.call(*args))
+        if y_amax is not None and not h2:
+            amax_measure(y, y_amax)
         return e, y
-    e = conv_forward(x, weight, bias, 1, 1, lrelu)
-    return e, torch.add(skip, e)
+    e = conv_forward(x, weight, bias, 1, 1, lrelu, x_amax=x_amax)
+    y = torch.add(skip, e)
+    if y_amax is not None:
+        amax_measure(y, y_amax)
+    return e, y
 
 
 S2_GATHER_MAX_CIN = 96   # stride-2 3x3 data gradients with at most this many result channels use the 2x2-block kernel
@@ -276,7 +289,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
             if h2:
                 args, _ga = _h2_args(args, gy, gy_amax, gx_amax)
             variant = (200000 if h2 else 100000) + code
-            LAUNCHES["dgrad_h2" if h2 else "dgrad_x3s" if code == 9001 else "dgrad_x3"] += 1
+            LAUNCHES["dgrad_x3s" if code == 9001 else "dgrad_h2" if h2 else "dgrad_x3"] += 1
         else:
             LAUNCHES["dgrad_f32"] += 1
             wp = packed_weights(weight, True)

@@ -484,16 +484,23 @@ class _OccUpsampleFn(hip.Function):
         x_in = torch.empty(B, cpad, H, W, device=occ_up.device, dtype=torch.float32)
         cat_channels_into(x_in, (occ_up,) + tuple(parts[1:]), zero_tail=cpad - cin)
         w_first = _padded_cin(w_init, cpad) if cpad > cin else w_init
-        x_init = conv_forward(x_in, w_first, b_init, 1, 1, True, real_cin=cin)
+        # fp16x2 route: one amax slot per activation that a 32-channel conv (forward, or its weight gradient) reads -- slot 0: x_in
+        # (measured), 1 + i: x_i, 5 + i: t_(i+1); the launches that produce them fold their maxima in the epilogue
+        S = Amax.zeros(x_in.device, 8) if h2_code(B, w_r0.shape[1], H, W, w_r0.shape[0], 3, 1, 1) else None
+        sl = (lambda i: S.sub(i)) if S is not None else (lambda i: None)
+        if S is not None:
+            amax_measure(x_in, S.sub(0))
+        x_init = conv_forward(x_in, w_first, b_init, 1, 1, True, real_cin=cin, x_amax=sl(0), y_amax=sl(1))
         xs = [x_init]
         ts = []
-        for _ in range(3):
-            t = conv_forward(xs[-1], w_r0, b_r0, 1, 1, True)
+        for i in range(3):
+            t = conv_forward(xs[-1], w_r0, b_r0, 1, 1, True, x_amax=sl(1 + i), y_amax=sl(5 + i))
             ts.append(t)
-            xs.append(conv_forward(t, w_r1, b_r1, 1, 1, False, res=xs[-1], alpha=mul_const))
-        e, x2 = conv_forward_skip(xs[-1], w_end, b_end, True, x_init)
+            xs.append(conv_forward(t, w_r1, b_r1, 1, 1, False, res=xs[-1], alpha=mul_const, x_amax=sl(5 + i), y_amax=sl(2 + i)))
+        e, x2 = conv_forward_skip(xs[-1], w_end, b_end, True, x_init, x_amax=sl(4))
         o = conv_forward(x2, w_out, b_out, 1, 1, True)
         out = torch.add(o, occ_up)
+        ctx.amax = S
         ctx.mul_const = mul_const
         ctx.widths = widths
         ctx.wobjs = (w_init, w_r0, w_r1, w_end, w_out)
@@ -514,6 +521,12 @@ class _OccUpsampleFn(hip.Function):
         hw_ = x0.shape[2:]
         g_out = g_out if _planes_dense(g_out) else g_out.contiguous()
         z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)
+        # fp16x2 route: slots of the forward (S: 0 x_in, 1 + i x_i, 5 + i t_(i+1)) and one per gradient map of the backward
+        # (G: 0 gpre_e (measured), 1 the running g_x, 2 gpre_t; re-zeroed slots would cost launches, so every map gets its own)
+        S = ctx.amax
+        G = Amax.zeros(dev, 16) if S is not None else None
+        sl = (lambda i: S.sub(i)) if S is not None else (lambda i: None)
+        gl = (lambda i: G.sub(i)) if G is not None else (lambda i: None)
         # out = occ_up + lrelu(conv_out(x2))
         gpre_o = torch.empty_like(g_out)
         gb_out = z(w_out.shape[0])
@@ -531,38 +544,45 @@ class _OccUpsampleFn(hip.Function):
             hip.call("irr_conv2d_smallco_dgrad_dual_f32", hip.ptr(gpre_o), hip.ptr(w_out.detach().contiguous()), hip.ptr(gpre_e),
                      hip.ptr(g_x2), hip.ptr(e), B_, w_out.shape[1], H_, W_, 1, hip.bs(gpre_o), hip.bs(gpre_e), hip.bs(g_x2), hip.bs(e),
                      hip.stream())
-            gw_end, gb_end = wgrad_param(x3, gpre_e, w_end, b_end, 1, 1, want_bias=True)
+            if G is not None:
+                amax_measure(gpre_e, G.sub(0))
+            gw_end, gb_end = wgrad_param(x3, gpre_e, w_end, b_end, 1, 1, want_bias=True, x_amax=sl(4), gy_amax=gl(0))
         else:
             g_x2 = conv_dgrad(gpre_o, w_out, 1, 1, hw_)                      # (B,32,H,W); also the gradient of x_init via the skip
             gpre_e = torch.empty_like(g_x2)
             gb_end = z(w_end.shape[0])
             lrelu_bwd_bias(g_x2, e, True, gpre_e, gb_end)
-            gw_end, _ = wgrad_param(x3, gpre_e, w_end, None, 1, 1, want_bias=False)
-        g_x = conv_dgrad(gpre_e, w_end, 1, 1, hw_)                           # gradient w.r.t. x3
+            if G is not None:
+                amax_measure(gpre_e, G.sub(0))
+            gw_end, _ = wgrad_param(x3, gpre_e, w_end, None, 1, 1, want_bias=False, x_amax=sl(4), gy_amax=gl(0))
+        g_x = conv_dgrad(gpre_e, w_end, 1, 1, hw_, gy_amax=gl(0), gx_amax=gl(1))     # gradient w.r.t. x3
         # three residual blocks with shared weights: x_i = x_{i-1} + mc * conv_r1(t_i), t_i = lrelu(conv_r0(x_{i-1}))
         routed = _c.SIDE is not None and _c.SIDE.route(w_r0, b_r0) is not None
         acc_r0 = None if routed else (torch.zeros_like(w_r0), z(w_r0.shape[0]))
         acc_r1 = None if routed else (torch.zeros_like(w_r1), z(w_r1.shape[0]))
         xs = [x0, x1, x2r]
         ts = [t1, t2, t3]
+        gxs = 1                                                 # slot of the running g_x
         for i in (2, 1, 0):
-            wgrad_param(ts[i], g_x, w_r1, b_r1, 1, 1, alpha=mc, acc=acc_r1)
-            gpre_t = conv_dgrad(g_x, w_r1, 1, 1, hw_, mask=ts[i], nmask=ts[i].shape[1], alpha=mc)
-            wgrad_param(xs[i], gpre_t, w_r0, b_r0, 1, 1, acc=acc_r0)
+            wgrad_param(ts[i], g_x, w_r1, b_r1, 1, 1, alpha=mc, acc=acc_r1, x_amax=sl(5 + i), gy_amax=gl(gxs))
+            gpre_t = conv_dgrad(g_x, w_r1, 1, 1, hw_, mask=ts[i], nmask=ts[i].shape[1], alpha=mc, gy_amax=gl(gxs), gx_amax=gl(2 + 2 * i))
+            wgrad_param(xs[i], gpre_t, w_r0, b_r0, 1, 1, acc=acc_r0, x_amax=sl(1 + i), gy_amax=gl(2 + 2 * i))
             if i > 0:
-                g_x = conv_dgrad(gpre_t, w_r0, 1, 1, hw_, res=g_x)                # skip + branch in one launch
+                g_x = conv_dgrad(gpre_t, w_r0, 1, 1, hw_, res=g_x, gy_amax=gl(2 + 2 * i), gx_amax=gl(3 + 2 * i))      # skip + branch in one launch
+                gxs = 3 + 2 * i
             else:
                 # x_0 = x_init: add the x2 skip gradient (accumulate into g_x2) and apply init_conv's LeakyReLU'
-                conv_dgrad(gpre_t, w_r0, 1, 1, hw_, gx=g_x2, accumulate=True, res=g_x, mask=x0, nmask=x0.shape[1])
+                conv_dgrad(gpre_t, w_r0, 1, 1, hw_, gx=g_x2, accumulate=True, res=g_x, mask=x0, nmask=x0.shape[1],
+                           gy_amax=gl(2), gx_amax=gl(8))
         gw_r0, gb_r0 = acc_r0 if acc_r0 is not None else (None, None)
         gw_r1, gb_r1 = acc_r1 if acc_r1 is not None else (None, None)
         gpre_init = g_x2
         x_real = x_in[:, :cin] if x_in.shape[1] > cin else x_in
-        gw_init, gb_init = wgrad_param(x_real, gpre_init, w_init, b_init, 1, 1)
+        gw_init, gb_init = wgrad_param(x_real, gpre_init, w_init, b_init, 1, 1, x_amax=sl(0), gy_amax=gl(8))
         gparts = [None] * nparts
         if any(ctx.needs_input_grad[2:2 + nparts]):
             w_first = _padded_cin(w_init, x_in.shape[1]) if x_in.shape[1] > cin else w_init
-            g_xin = conv_dgrad(gpre_init, w_first, 1, 1, hw_, real_cin=cin)
+            g_xin = conv_dgrad(gpre_init, w_first, 1, 1, hw_, real_cin=cin, gy_amax=gl(8))
             c0 = 0
             for i, wd in enumerate(widths):
                 if ctx.needs_input_grad[2 + i]:

@@ -409,6 +409,9 @@ struct X3SArgs {
   int wCoT, wcot;               // co-tiles in the packed weights / the one this launch computes
   float* y2;                    // EPI 3: second output, the value before the residual is added
   long y2_bs;
+  const float* x_amax;          // NP == 2: as in X3Args
+  int n_amax;
+  float* y_amax;
 };
 
 // s_memtime trace points (IRR_X3S_TRACE=1 builds, tools/x3s_trace.py): block 7, lane 0 of every wave
@@ -425,15 +428,17 @@ struct X3SArgs {
 // 2: everything (residual, accumulate-into-output, LeakyReLU'-mask), 3: residual + a SECOND output y2 = the value before the
 // residual is added (y = res + y2; irr_conv2d_fwd_x3_dual).  The kernel is bound by the producer waves' VALU issue
 // slots (operand split + epilogue), so the plain layers do not pay for 24 operand loads and 5 unused VALU per output.
-template <int EPI>
+// NP: pieces per operand -- 3: bf16x3 (six products), 2: the fp16x2 form of x3_split.h (three products; operands scaled by the
+// powers of two derived from a.x_amax and the weight pack's trailer, accumulators scaled back when they are handed over).
+template <int EPI, int NP = 3>
 __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
   constexpr int PLANE_PIX = 352;                           // >= 10 x 34 halo patch
-  constexpr int CHUNK = 6 * PLANE_PIX;                     // 16-B units per chunk slot: [piece][g][pixel]
+  constexpr int CHUNK = 2 * NP * PLANE_PIX;                // 16-B units per chunk slot: [piece][g][pixel]
   constexpr int LW = 34;
-  constexpr int WUNITS = 18 * 3 * 64;                      // the complete pre-split weight set: [step][piece][lane] x 16 B
+  constexpr int WUNITS = 18 * NP * 64;                     // the complete pre-split weight set: [step][piece][lane] x 16 B
   extern __shared__ u32x4 lds[];
-  u32x4* const wl = lds;                                   // weights (54 KiB), loaded once per block
-  u32x4* const xl = lds + WUNITS;                          // two chunk slots (66 KiB)
+  u32x4* const wl = lds;                                   // weights (54 / 36 KiB), loaded once per block
+  u32x4* const xl = lds + WUNITS;                          // two chunk slots (66 / 44 KiB)
   float* const ol = (float*)(lds + WUNITS + 2 * CHUNK);    // accumulators of the finished tile: [32 co][256 px] fp32 (32 KiB)
 
   const int tid = threadIdx.x;
@@ -451,6 +456,13 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
   // residual, accumulate, mask, store) of tile n while the MFMA waves are already on tile n+1.
   // (the packed weights interleave the co-tiles of a layer: this launch keeps co-tile a.wcot of a.wCoT)
   for (int u = tid; u < WUNITS; u += 512) wl[u] = a.wq[((long)(u >> 6) * a.wCoT + a.wcot) * 64 + (u & 63)];
+  float sx = 1.f, unscale = 1.f;                           // h2: operand scale of x, and the factor that undoes both scales
+  if (NP == 2) {
+    const int ex = x3_h2_exp(x3_h2_amax(a.x_amax, a.n_amax));
+    const int ew = ((const int*)(a.wq + (long)18 * NP * a.wCoT * 64))[0];
+    sx = ldexpf(1.f, ex);
+    unscale = ldexpf(1.f, -ex - ew);                       // (|ex|, |ew| <= 96: the product of the two factors is a normal number)
+  }
   __syncthreads();
 
   // Roles by wave AGE: the instruction arbiter of a SIMD prefers its older wave, and a wave that streams MFMAs leaves the
@@ -510,11 +522,12 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = raw[c][e][px];
         u32x4 h, m, l;
-        split8(v, h, m, l);
+        if (NP == 2) split8_h2(v, sx, h, m);
+        else split8(v, h, m, l);
         if (su_act && lx >= 0 && lx < LW) {
           buf[lx] = h;
           buf[lx + 2 * PLANE_PIX] = m;
-          buf[lx + 4 * PLANE_PIX] = l;
+          if (NP == 3) buf[lx + 4 * PLANE_PIX] = l;
         }
       }
     };
@@ -550,6 +563,8 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
         }
       }
     };
+    float ymax = 0.f;                                        // NP == 2 with a.y_amax: max |stored value| of this thread
+    const bool want_amax = NP == 2 && a.y_amax != nullptr;
     f32x4 eacc[8];                                           // the finished tile's accumulators, copied out of the LDS stage
     auto epilogue_grab = [&]() {
 #pragma unroll
@@ -573,6 +588,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
           }
           o[px] = v;
         }
+        if (want_amax && co < a.Cout && evd != OOB) ymax = x3_amax_fold(x3_amax_fold(x3_amax_fold(x3_amax_fold(ymax, o[0]), o[1]), o[2]), o[3]);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, (int)((co < a.Cout && X3_ABL != 7 && X3_ABL != 10 && X3_ABL != 11) ? evd : OOB),
                                                (int)((uint32_t)e * hw4), 0);
         if (EPI == 3)
@@ -628,6 +644,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
     epilogue_loads(at_prev, tprev >= 0);
     epilogue_grab();
     epilogue_finish();
+    if (want_amax) x3_amax_publish(ymax, a.y_amax);
     return;
   }
 
@@ -649,22 +666,19 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
         // (the accumulator stage was released by the barrier that just passed: tile n-1's epilogue is done)
       }
       const u32x4* buf = xl + c * CHUNK;
-      u32x4 xb[2][2][3], wa[2][3];
+      u32x4 xb[2][2][NP], wa[2][NP];
       auto read_step = [&](int sel, int tap) {
         const int base = xidx0 + (tap / 3) * LW + (tap % 3);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) xb[sel][s][p] = (X3_ABL == 9 && tap > 0) ? xb[sel ^ 1][s][p] : buf[base + s * LW + 2 * p * PLANE_PIX];
+          for (int p = 0; p < NP; ++p) xb[sel][s][p] = (X3_ABL == 9 && tap > 0) ? xb[sel ^ 1][s][p] : buf[base + s * LW + 2 * p * PLANE_PIX];
         if (X3_ABL == 8 && tap > 0) {                       // ablation: the weight fragments of tap 0 for every tap (no LDS reads)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) wa[sel][p] = wa[sel ^ 1][p];
-        } else if (X3_ABL == 9 && tap > 0) {                // ablation: the B fragments of tap 0 for every tap
-#pragma unroll
-          for (int p = 0; p < 3; ++p) wa[sel][p] = wl[((c * 9 + tap) * 3 + p) * 64 + lane];
+          for (int p = 0; p < NP; ++p) wa[sel][p] = wa[sel ^ 1][p];
         } else {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) wa[sel][p] = wl[((c * 9 + tap) * 3 + p) * 64 + lane];
+          for (int p = 0; p < NP; ++p) wa[sel][p] = wl[((c * 9 + tap) * NP + p) * 64 + lane];
         }
       };
       read_step(0, 0);
@@ -673,18 +687,27 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
         const int cur = tap & 1;
         if (tap + 1 < 9) read_step(cur ^ 1, tap + 1);
         __builtin_amdgcn_sched_barrier(0);
-        acc0 = mma(wa[cur][2], xb[cur][0][0], acc0);        // lo * hi
-        acc1 = mma(wa[cur][2], xb[cur][1][0], acc1);
-        acc0 = mma(wa[cur][0], xb[cur][0][2], acc0);        // hi * lo
-        acc1 = mma(wa[cur][0], xb[cur][1][2], acc1);
-        acc0 = mma(wa[cur][1], xb[cur][0][1], acc0);        // mid * mid
-        acc1 = mma(wa[cur][1], xb[cur][1][1], acc1);
-        acc0 = mma(wa[cur][1], xb[cur][0][0], acc0);        // mid * hi
-        acc1 = mma(wa[cur][1], xb[cur][1][0], acc1);
-        acc0 = mma(wa[cur][0], xb[cur][0][1], acc0);        // hi * mid
-        acc1 = mma(wa[cur][0], xb[cur][1][1], acc1);
-        acc0 = mma(wa[cur][0], xb[cur][0][0], acc0);        // hi * hi
-        acc1 = mma(wa[cur][0], xb[cur][1][0], acc1);
+        if constexpr (NP == 2) {
+          acc0 = mma_h(wa[cur][1], xb[cur][0][0], acc0);    // lo * hi
+          acc1 = mma_h(wa[cur][1], xb[cur][1][0], acc1);
+          acc0 = mma_h(wa[cur][0], xb[cur][0][1], acc0);    // hi * lo
+          acc1 = mma_h(wa[cur][0], xb[cur][1][1], acc1);
+          acc0 = mma_h(wa[cur][0], xb[cur][0][0], acc0);    // hi * hi
+          acc1 = mma_h(wa[cur][0], xb[cur][1][0], acc1);
+        } else {
+          acc0 = mma(wa[cur][NP - 1], xb[cur][0][0], acc0);   // lo * hi
+          acc1 = mma(wa[cur][NP - 1], xb[cur][1][0], acc1);
+          acc0 = mma(wa[cur][0], xb[cur][0][NP - 1], acc0);   // hi * lo
+          acc1 = mma(wa[cur][0], xb[cur][1][NP - 1], acc1);
+          acc0 = mma(wa[cur][1], xb[cur][0][1], acc0);        // mid * mid
+          acc1 = mma(wa[cur][1], xb[cur][1][1], acc1);
+          acc0 = mma(wa[cur][1], xb[cur][0][0], acc0);        // mid * hi
+          acc1 = mma(wa[cur][1], xb[cur][1][0], acc1);
+          acc0 = mma(wa[cur][0], xb[cur][0][1], acc0);        // hi * mid
+          acc1 = mma(wa[cur][0], xb[cur][1][1], acc1);
+          acc0 = mma(wa[cur][0], xb[cur][0][0], acc0);        // hi * hi
+          acc1 = mma(wa[cur][0], xb[cur][1][0], acc1);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -695,7 +718,9 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = (r & 3) + 8 * (r >> 2) + 4 * g;
-        ol[co * 256 + (row0 + s) * 32 + j] = s ? acc1[r] : acc0[r];
+        float v = s ? acc1[r] : acc0[r];
+        if (NP == 2) v *= unscale;                          // back to the operands' own scale (an exact power of two)
+        ol[co * 256 + (row0 + s) * 32 + j] = v;
       }
   }
   __syncthreads();                                          // final barrier (pairs with the producers')
@@ -985,10 +1010,11 @@ extern "C" int irr_conv2d_x3_eligible(int B, int Cin, int H, int W, int Cout, in
   return p.ct * 1000 + p.pg * 100 + p.t.nt * 10 + (p.plane == 352 ? 1 : p.plane == 616 ? 2 : 3);
 }
 
-// the fp16x2 form takes what conv_x3_kernel takes; the problems of the streaming 32-channel kernel stay on bf16x3 (code 0 here)
+// the fp16x2 form takes what the bf16x3 kernels take (9001: the streaming 32-channel kernel; IRR_X3S_NO_H2: A/B switch that keeps
+// that one on bf16x3)
 extern "C" int irr_conv2d_h2_eligible(int B, int Cin, int H, int W, int Cout, int k, int stride, int dil) {
   const int code = irr_conv2d_x3_eligible(B, Cin, H, W, Cout, k, stride, dil);
-  return code == 9001 ? 0 : code;
+  return (code == 9001 && IRR_ENV_FLAG("IRR_X3S_NO_H2")) ? 0 : code;
 }
 
 // finishes a K-split launch: y = epilogue(sum over the slices of part[kz][b][co][pixel])  (same order of operations as the
@@ -1035,7 +1061,7 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
                        float* y_amax = nullptr) {
   if (!x || !wq || !y || B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1) return IRR_EINVAL;
   if (y2 && (!res || accumulate || mask || !x3s_ok(B, Cin, H, W, Cout, dil))) return IRR_EINVAL;      // second output: streaming kernel only
-  if (np == 2 && (!x_amax || n_amax <= 0 || x3s_ok(B, Cin, H, W, Cout, dil))) return IRR_EINVAL;
+  if (np == 2 && (!x_amax || n_amax <= 0)) return IRR_EINVAL;
   if (x3s_ok(B, Cin, H, W, Cout, dil)) {
     X3SArgs s;
     s.wq = (const u32x4*)wq; s.bias = bias;
@@ -1052,15 +1078,21 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
     s.dbg = dbg_buf;
     g_x3s_dbg = dbg_buf;
 #endif
-    constexpr size_t lds_bytes = (18 * 3 * 64 + 2 * 6 * 352) * 16 + 32 * 256 * 4;
+    constexpr size_t lds3 = (18 * 3 * 64 + 2 * 6 * 352) * 16 + 32 * 256 * 4, lds2 = (18 * 2 * 64 + 2 * 4 * 352) * 16 + 32 * 256 * 4;
+    const size_t lds_bytes = np == 2 ? lds2 : lds3;
     static bool attr_set = false;
     if (!attr_set) {
-      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
       attr_set = true;
     }
+    s.x_amax = x_amax; s.n_amax = n_amax; s.y_amax = y_amax;
     // every operand is addressed through 32-bit byte voffsets below the 2 GiB out-of-range marker
     long bsmax = x_bs > y_bs ? x_bs : y_bs;
     if (res && res_bs > bsmax) bsmax = res_bs;
@@ -1090,10 +1122,13 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
         s.nmask = nmask - (int)co0 < 0 ? 0 : (nmask - (int)co0 > 32 ? 32 : nmask - (int)co0);
         s.y2 = y2 ? y2 + (long)b0 * y2_bs + co0 * hw_ : nullptr;
         const int epi = (s.accumulate || s.mask) ? 2 : s.res ? (s.y2 ? 3 : 1) : 0;
-        if (epi == 3) hipLaunchKernelGGL(conv_x3s_kernel<3>, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
-        else if (epi == 0) hipLaunchKernelGGL(conv_x3s_kernel<0>, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
-        else if (epi == 1) hipLaunchKernelGGL(conv_x3s_kernel<1>, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
-        else hipLaunchKernelGGL(conv_x3s_kernel<2>, dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
+#define X3S_GO(E) do { if (np == 2) hipLaunchKernelGGL((conv_x3s_kernel<E, 2>), dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s); \
+                      else hipLaunchKernelGGL((conv_x3s_kernel<E, 3>), dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s); } while (0)
+        if (epi == 3) X3S_GO(3);
+        else if (epi == 0) X3S_GO(0);
+        else if (epi == 1) X3S_GO(1);
+        else X3S_GO(2);
+#undef X3S_GO
         IRR_LAUNCH_CHECK();
       }
     }
@@ -1187,4 +1222,13 @@ extern "C" int irr_conv2d_fwd_h2(const float* x, const void* wq, const float* bi
                                  long ws_elems, const float* x_amax, int n_amax, float* y_amax, void* stream) {
   return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, accumulate, mask, mask_bs, nmask,
                      ws, ws_elems, stream, nullptr, 0, 2, x_amax, n_amax, y_amax);
+}
+
+// irr_conv2d_fwd_x3_dual on the fp16x2 form (y_amax bounds y, the sum)
+extern "C" int irr_conv2d_fwd_h2_dual(const float* x, const void* wq, const float* bias, const float* res, float* y, float* y2, int B,
+                                      int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, long y2_bs,
+                                      int lrelu, float alpha, const float* x_amax, int n_amax, float* y_amax, void* stream) {
+  if (!y2 || !res) return IRR_EINVAL;
+  return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, 0, nullptr, 0, 0, nullptr, 0, stream,
+                     y2, y2_bs, 2, x_amax, n_amax, y_amax);
 }
