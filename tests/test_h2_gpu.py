@@ -187,3 +187,46 @@ def test_dense_estimator_and_chain_nodes_on_h2(h2_everywhere):
     assert C.LAUNCHES["fwd_h2"] >= 8 and C.LAUNCHES["dense_column_h2"] >= 4 and C.LAUNCHES["wgrad_h2"] >= 7 and C.LAUNCHES["dgrad_h2"] >= 3, dict(C.LAUNCHES)
     for i, (a, b) in enumerate(zip(got, ref)):
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-30, i
+
+
+S_CASES = [(32, 32, 2, 40, 64), (16, 32, 1, 24, 96), (27, 32, 1, 32, 60), (32, 64, 1, 16, 96), (32, 24, 1, 23, 64)]   # (Cin, Cout, B, H, W)
+
+
+@pytest.mark.parametrize("rng", RANGES)
+@pytest.mark.parametrize("case", S_CASES, ids=[f"{c[0]}to{c[1]}_{c[3]}x{c[4]}" for c in S_CASES])
+def test_streaming_kernel_on_h2_is_fp32_faithful(case, rng, h2_everywhere):
+    """conv_x3s_kernel<EPI, 2> (the 32-channel streaming kernel in its fp16x2 form): every epilogue variant -- plain + fused output
+    magnitude, residual, second output, data gradient with accumulate + mask -- against fp64, ragged tiles, Cin < 32, two co-tiles."""
+    from irr_amd import conv as C
+    cin, cout, B, H, W = case
+    x, w, gy = _operands((cin, cout, 1, B, H, W), rng)
+    assert C.h2_code(B, cin, H, W, cout, 3, 1, 1) == 9001
+    g = torch.Generator().manual_seed(5)
+    b = torch.linspace(-1, 1, cout) * float(x.abs().mean()) * 0.1
+    res = torch.randn(B, cout, H, W, generator=g) * float(x.abs().mean())
+    conv = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    lre = F.leaky_relu(conv, 0.1)
+    gref = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=1)
+    gres = torch.randn(B, cin, H, W, generator=g) * float(gref.abs().mean())
+    mask = torch.randn(B, cin, H, W, generator=g)
+    dref = (gres.double() + gref) * torch.where(mask > 0, 1.0, 0.1).double()
+    err = {}
+    for m in ("f32", "h2"):
+        C.set_math(m)
+        xc, wc, gc = x.cuda(), w.cuda(), gy.cuda()
+        xa = C.amax_measure(xc) if m == "h2" else None
+        ya = C.Amax.zeros(xc.device, 1)
+        y = C.conv_forward(xc, wc, b.cuda(), 1, 1, True, x_amax=xa, y_amax=ya)
+        assert ya.slots[ya.first].item() == y.abs().max().item()
+        y1 = C.conv_forward(xc, wc, b.cuda(), 1, 1, False, res=res.cuda(), alpha=0.1, x_amax=xa)
+        e, y2 = C.conv_forward_skip(xc, wc, b.cuda(), True, res.cuda(), x_amax=xa)
+        gx = gres.cuda()
+        ga = C.Amax.zeros(xc.device, 1)
+        C.conv_dgrad(gc, wc, 1, 1, (H, W), gx=gx, accumulate=True, mask=mask.cuda(), nmask=cin, gx_amax=ga)
+        assert ga.slots[ga.first].item() == gx.abs().max().item()
+        err[m] = (_rel(y, lre), _rel(y1, res.double() + 0.1 * conv), _rel(e, lre), _rel(y2, res.double() + lre), _rel(gx, dref))
+    assert C.LAUNCHES["fwd_x3s"] == 3, dict(C.LAUNCHES)
+    for i, what in enumerate(("plain", "residual", "second output", "sum output", "data gradient")):
+        if i == 4 and not C.LAUNCHES["dgrad_x3s"]:
+            continue
+        assert err["h2"][i] <= max(4 * err["f32"][i], 2e-6) and err["h2"][i] <= 5e-6, (what, err)
