@@ -26,6 +26,7 @@ python tools/rocpd_traffic_json.py $F $W > $OUT/hbm_traffic.json
 rm -rf $OUT/pf $OUT/pw
 IRR_CONV_MATH=f32 python bench.py --no-cpu-baseline --no-secondary --no-extra-legs > $OUT/${TAG}_bench_math_f32.json 2>> $OUT/${TAG}_bench.err
 IRR_CONV_MATH=x3 python bench.py --no-cpu-baseline --no-secondary --no-extra-legs > $OUT/${TAG}_bench_math_x3.json 2>> $OUT/${TAG}_bench.err
+IRR_X3S_NO_H2=1 python bench.py --no-cpu-baseline --no-secondary --no-extra-legs > $OUT/${TAG}_bench_x3s_bf16x3.json 2>> $OUT/${TAG}_bench.err
 IRR_LANE_MAX_LEAD=1 python bench.py --no-cpu-baseline --no-secondary --no-extra-legs > $OUT/${TAG}_bench_bounded_lead.json 2>> $OUT/${TAG}_bench.err
 # 4. the second crop of north_star (per-GPU share of configs[4]): kernel stats + PMC passes of its own
 python bench.py --no-cpu-baseline --no-extra-legs --batch 8 --height 448 --width 1024 > $OUT/${TAG}_bench_448x1024_bs8.json 2>> $OUT/${TAG}_bench.err
@@ -44,6 +45,7 @@ python tools/corr_bench.py 2>/dev/null > $OUT/${TAG}_corr_bench_run.txt
 python tools/warp_bench.py 2>/dev/null > $OUT/${TAG}_warp_bench.txt
 python tools/wx3_check.py 2>/dev/null > $OUT/${TAG}_wgrad_x3_microbench.txt
 python tools/h2_check.py 2>/dev/null > $OUT/${TAG}_h2_check.txt
+python tools/x3s_h2_check.py 2>/dev/null > $OUT/${TAG}_x3s_h2_check.txt
 python tools/lane_race_probe.py 12 2>/dev/null > $OUT/${TAG}_lane_probe.txt
 IRR_CONV_MATH=x3 python tools/lane_race_probe.py 24 2>/dev/null > $OUT/${TAG}_lane_probe_x3.txt
 python tools/pair_probe.py 2>/dev/null > $OUT/${TAG}_pair_probe.txt
