@@ -112,11 +112,25 @@ def x3_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, di
 
 
 
+# The streaming 32-channel kernel has the fp16x2 form too (conv_x3s_kernel<EPI, 2>, +5.1 % on the step, parity-green), but it is OFF
+# by default: with it, `bench.py --gpus 2` on ONE shared GPU (tests/test_ddp_gpu.py) ended in a NaN loss in 4 of 5 runs -- never in a
+# single process, never with two independent processes, not with the magnitudes measured by separate passes instead of the kernel's
+# epilogue (3 of 3) -- and the cause was not found before the end of round 4 (profiles/NOTES.md C.5).  IRR_X3S_H2=1 / set_x3s_h2(True).
+X3S_H2 = bool(int(os.environ.get("IRR_X3S_H2", "0")))
+
+
+def set_x3s_h2(on: bool) -> bool:
+    global X3S_H2
+    old, X3S_H2 = X3S_H2, bool(on)
+    return old
+
+
 def h2_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, dil: int) -> int:
-    """non-zero: the problem runs on the fp16x2 form of conv_x3_kernel / conv_x3s_kernel (9001: the streaming one)"""
+    """non-zero: the problem runs on the fp16x2 form of conv_x3_kernel / conv_x3s_kernel (9001: the streaming one, see X3S_H2)"""
     if MATH != "h2" or not x3_code(B, cin, H, W, cout, k, stride, dil):
         return 0
-    return int(hip.lib().irr_conv2d_h2_eligible(B, cin, H, W, cout, k, stride, dil))
+    code = int(hip.lib().irr_conv2d_h2_eligible(B, cin, H, W, cout, k, stride, dil))
+    return 0 if (code == 9001 and not X3S_H2) else code
 
 
 from .conv_pack import packed_weights_h2, packed_weights_x3  # noqa: E402,F401
@@ -140,6 +154,38 @@ def _call_conv(args) -> None:
             hip.call("irr_conv2d_fwd_x3_splitk", *args[1:-1], ws.data_ptr(), n, args[-1])
             return
     hip.call(*args)
+
+
+_CHECK_FINITE = os.environ.get("IRR_CONV_CHECK_FINITE", "")       # debugging aid: finiteness check behind every conv launch -- "1":
+                                                                  # synchronising, raises at once; "async": device-side flags, read by
+                                                                  # dump_finite_log() (irr_amd.train calls it when the loss is NaN)
+_FINITE_LOG = []
+
+
+def dump_finite_log(limit: int = 8) -> None:
+    import sys
+    torch.cuda.synchronize()
+    bad = [(i, e) for i, e in enumerate(_FINITE_LOG) if not bool(e[1])]
+    print(f"[finite log] {len(_FINITE_LOG)} conv launches logged, {len(bad)} with a non-finite output; first:", file=sys.stderr)
+    for i, (what, flag, slots, stats) in bad[:limit]:
+        print(f"  #{i} {what}; amax slots {[None if s is None else s.tolist() for s in slots]}; max|out| / non-finite count {stats.tolist()}", file=sys.stderr)
+        if i > 0:
+            w0, f0, s0, st0 = _FINITE_LOG[i - 1]
+            print(f"     previous launch #{i - 1} {w0}: finite {bool(f0)}, slots {[None if s is None else s.tolist() for s in s0]}, max|out| {st0.tolist()}", file=sys.stderr)
+
+
+def _check_finite(what, out, *slots):
+    if _CHECK_FINITE == "async":
+        fin = torch.isfinite(out)
+        stats = torch.stack([torch.where(fin, out, torch.zeros_like(out)).abs().max(), (~fin).sum().float()])
+        _FINITE_LOG.append((what, fin.all(), [None if a is None else a.slots[a.first:a.first + a.n].clone() for a in slots], stats))
+        if len(_FINITE_LOG) > 20000:
+            del _FINITE_LOG[:10000]
+        return
+    if not torch.isfinite(out).all():
+        vals = [None if a is None else a.slots[a.first:a.first + a.n].tolist() for a in slots]
+        raise FloatingPointError(f"{what}: non-finite output {tuple(out.shape)}, amax slots {vals}, "
+                                 f"non-finite {int((~torch.isfinite(out)).sum())} of {out.numel()}")
 
 
 def _h2_args(x3_args, x, x_amax, y_amax):
@@ -182,8 +228,9 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                 hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, dil,
                 hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
                 int(lrelu), float(alpha), int(accumulate), None, 0, 0, hip.stream())
+        measure_y = h2 and code == 9001 and y_amax is not None and bool(os.environ.get("IRR_X3S_NO_FUSED_AMAX"))   # (diagnosis switch)
         if h2:
-            args, _xa = _h2_args(args, x, x_amax, y_amax)
+            args, _xa = _h2_args(args, x, x_amax, None if measure_y else y_amax)
         variant = (200000 if h2 else 100000) + code
         LAUNCHES["fwd_x3s" if code == 9001 else "fwd_h2" if h2 else "fwd_x3"] += 1          # (fwd_x3s: the streaming kernel, either form)
     else:
@@ -200,8 +247,10 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
         if variant is None:
             variant = hip.lib().irr_conv2d_fwd_variant(B, cout, oh, ow, k)
         TIMER.wrap(variant, 2.0 * B * oh * ow * cout * (real_cin or cin) * k * k, lambda: _call_conv(args))
-    if y_amax is not None and not h2:
+    if y_amax is not None and (not h2 or (code == 9001 and os.environ.get("IRR_X3S_NO_FUSED_AMAX"))):
         amax_measure(out, y_amax)
+    if _CHECK_FINITE:
+        _check_finite(f"conv_forward {tuple(x.shape)} -> {cout} code {code} h2 {h2}", out, x_amax, y_amax)
     return out
 
 
@@ -287,7 +336,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                     dil, hip.bs(gy), hip.bs(gx), hip.bs(res) if res is not None else 0, 0, float(alpha),
                     int(accumulate), *margs, hip.stream())
             if h2:
-                args, _ga = _h2_args(args, gy, gy_amax, gx_amax)
+                args, _ga = _h2_args(args, gy, gy_amax, None if (code == 9001 and os.environ.get("IRR_X3S_NO_FUSED_AMAX")) else gx_amax)
             variant = (200000 if h2 else 100000) + code
             LAUNCHES["dgrad_x3s" if code == 9001 else "dgrad_h2" if h2 else "dgrad_x3"] += 1
         else:
@@ -323,8 +372,10 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
             gx += tmp
         if mask is not None and nmask > 0:
             gx[:, :nmask] *= torch.where(mask[:, :nmask] > 0, 1.0, 0.1)
-    if gx_amax is not None and not h2:
+    if gx_amax is not None and (not h2 or (code == 9001 and os.environ.get("IRR_X3S_NO_FUSED_AMAX"))):
         amax_measure(gx, gx_amax)
+    if _CHECK_FINITE:
+        _check_finite(f"conv_dgrad {tuple(gy.shape)} -> {cin} dil {dil} stride {stride} h2 {h2}", gx, gy_amax, gx_amax)
     return gx
 
 

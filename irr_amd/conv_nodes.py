@@ -527,11 +527,16 @@ class _OccUpsampleFn(hip.Function):
         G = Amax.zeros(dev, 16) if S is not None else None
         sl = (lambda i: S.sub(i)) if S is not None else (lambda i: None)
         gl = (lambda i: G.sub(i)) if G is not None else (lambda i: None)
+        _wg = wgrad_param
+        if os.environ.get("IRR_OCCUP_NO_WGRAD_SLOTS"):           # (diagnosis switch: the node's weight gradients stay on bf16x3)
+            wgrad_param_ = lambda *a, **k: _wg(*a, **{kk: vv for kk, vv in k.items() if kk not in ("x_amax", "gy_amax")})
+        else:
+            wgrad_param_ = _wg
         # out = occ_up + lrelu(conv_out(x2))
         gpre_o = torch.empty_like(g_out)
         gb_out = z(w_out.shape[0])
         lrelu_bwd_bias(g_out, o, True, gpre_o, gb_out)                       # 1-channel tensor
-        gw_out, _ = wgrad_param(x2, gpre_o, w_out, None, 1, 1, want_bias=False)
+        gw_out, _ = wgrad_param_(x2, gpre_o, w_out, None, 1, 1, want_bias=False)
         # x2 = x_init + e, e = lrelu(conv_end(x3)): the gradient of x2 is needed raw (g_x2: the skip into x_init) and multiplied by
         # LeakyReLU'(e) (gpre_e: into res_end_conv).  Both come out of the out_convs data-gradient launch where its quad kernel
         # applies (one pass less over two 32-channel full-resolution maps); the bias gradient then rides on the wgrad launch.
@@ -546,7 +551,7 @@ class _OccUpsampleFn(hip.Function):
                      hip.stream())
             if G is not None:
                 amax_measure(gpre_e, G.sub(0))
-            gw_end, gb_end = wgrad_param(x3, gpre_e, w_end, b_end, 1, 1, want_bias=True, x_amax=sl(4), gy_amax=gl(0))
+            gw_end, gb_end = wgrad_param_(x3, gpre_e, w_end, b_end, 1, 1, want_bias=True, x_amax=sl(4), gy_amax=gl(0))
         else:
             g_x2 = conv_dgrad(gpre_o, w_out, 1, 1, hw_)                      # (B,32,H,W); also the gradient of x_init via the skip
             gpre_e = torch.empty_like(g_x2)
@@ -554,7 +559,7 @@ class _OccUpsampleFn(hip.Function):
             lrelu_bwd_bias(g_x2, e, True, gpre_e, gb_end)
             if G is not None:
                 amax_measure(gpre_e, G.sub(0))
-            gw_end, _ = wgrad_param(x3, gpre_e, w_end, None, 1, 1, want_bias=False, x_amax=sl(4), gy_amax=gl(0))
+            gw_end, _ = wgrad_param_(x3, gpre_e, w_end, None, 1, 1, want_bias=False, x_amax=sl(4), gy_amax=gl(0))
         g_x = conv_dgrad(gpre_e, w_end, 1, 1, hw_, gy_amax=gl(0), gx_amax=gl(1))     # gradient w.r.t. x3
         # three residual blocks with shared weights: x_i = x_{i-1} + mc * conv_r1(t_i), t_i = lrelu(conv_r0(x_{i-1}))
         routed = _c.SIDE is not None and _c.SIDE.route(w_r0, b_r0) is not None
@@ -564,9 +569,9 @@ class _OccUpsampleFn(hip.Function):
         ts = [t1, t2, t3]
         gxs = 1                                                 # slot of the running g_x
         for i in (2, 1, 0):
-            wgrad_param(ts[i], g_x, w_r1, b_r1, 1, 1, alpha=mc, acc=acc_r1, x_amax=sl(5 + i), gy_amax=gl(gxs))
+            wgrad_param_(ts[i], g_x, w_r1, b_r1, 1, 1, alpha=mc, acc=acc_r1, x_amax=sl(5 + i), gy_amax=gl(gxs))
             gpre_t = conv_dgrad(g_x, w_r1, 1, 1, hw_, mask=ts[i], nmask=ts[i].shape[1], alpha=mc, gy_amax=gl(gxs), gx_amax=gl(2 + 2 * i))
-            wgrad_param(xs[i], gpre_t, w_r0, b_r0, 1, 1, acc=acc_r0, x_amax=sl(1 + i), gy_amax=gl(2 + 2 * i))
+            wgrad_param_(xs[i], gpre_t, w_r0, b_r0, 1, 1, acc=acc_r0, x_amax=sl(1 + i), gy_amax=gl(2 + 2 * i))
             if i > 0:
                 g_x = conv_dgrad(gpre_t, w_r0, 1, 1, hw_, res=g_x, gy_amax=gl(2 + 2 * i), gx_amax=gl(3 + 2 * i))      # skip + branch in one launch
                 gxs = 3 + 2 * i
@@ -578,7 +583,7 @@ class _OccUpsampleFn(hip.Function):
         gw_r1, gb_r1 = acc_r1 if acc_r1 is not None else (None, None)
         gpre_init = g_x2
         x_real = x_in[:, :cin] if x_in.shape[1] > cin else x_in
-        gw_init, gb_init = wgrad_param(x_real, gpre_init, w_init, b_init, 1, 1, x_amax=sl(0), gy_amax=gl(8))
+        gw_init, gb_init = wgrad_param_(x_real, gpre_init, w_init, b_init, 1, 1, x_amax=sl(0), gy_amax=gl(8))
         gparts = [None] * nparts
         if any(ctx.needs_input_grad[2:2 + nparts]):
             w_first = _padded_cin(w_init, x_in.shape[1]) if x_in.shape[1] > cin else w_init

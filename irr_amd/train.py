@@ -95,6 +95,8 @@ class TrainStep:
             _conv.SIDE.join()
         if copied is not None:                    # the value left the device long ago: this wait does not stall the pipeline
             copied.synchronize()
+            if math.isnan(float(self._loss_host)) and _conv._CHECK_FINITE == "async":
+                _conv.dump_finite_log()
             assert not math.isnan(float(self._loss_host)), "training_loss is NaN"
         self.optimizer.step()
         _conv.WEIGHT_EPOCH[0] += 1                # every packed weight copy is stale now: they are refreshed by ONE launch

@@ -4,6 +4,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from irr_amd import conv as C
 
+C.set_x3s_h2(True)                                       # (off by default: conv.X3S_H2)
+
 torch.manual_seed(0)
 B, H, W = int(os.environ.get("B", 4)), 384, 448
 dev = "cuda"
