@@ -117,6 +117,8 @@ def x3_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, di
 # single process, never with two independent processes, not with the magnitudes measured by separate passes instead of the kernel's
 # epilogue (3 of 3) -- and the cause was not found before the end of round 4 (profiles/NOTES.md C.5).  IRR_X3S_H2=1 / set_x3s_h2(True).
 X3S_H2 = bool(int(os.environ.get("IRR_X3S_H2", "0")))
+_X3S_NO_FUSED_AMAX = bool(os.environ.get("IRR_X3S_NO_FUSED_AMAX"))     # diagnosis switch of NOTES C.5: the streaming kernel's output
+                                                                       # magnitude by a separate pass instead of its epilogue
 
 
 def set_x3s_h2(on: bool) -> bool:
@@ -228,7 +230,7 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                 hip.ptr(res), hip.ptr(out), B, cin, H, W, cout, dil,
                 hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
                 int(lrelu), float(alpha), int(accumulate), None, 0, 0, hip.stream())
-        measure_y = h2 and code == 9001 and y_amax is not None and bool(os.environ.get("IRR_X3S_NO_FUSED_AMAX"))   # (diagnosis switch)
+        measure_y = h2 and code == 9001 and y_amax is not None and _X3S_NO_FUSED_AMAX
         if h2:
             args, _xa = _h2_args(args, x, x_amax, None if measure_y else y_amax)
         variant = (200000 if h2 else 100000) + code
@@ -247,7 +249,7 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
         if variant is None:
             variant = hip.lib().irr_conv2d_fwd_variant(B, cout, oh, ow, k)
         TIMER.wrap(variant, 2.0 * B * oh * ow * cout * (real_cin or cin) * k * k, lambda: _call_conv(args))
-    if y_amax is not None and (not h2 or (code == 9001 and os.environ.get("IRR_X3S_NO_FUSED_AMAX"))):
+    if y_amax is not None and (not h2 or (code == 9001 and _X3S_NO_FUSED_AMAX)):
         amax_measure(out, y_amax)
     if _CHECK_FINITE:
         _check_finite(f"conv_forward {tuple(x.shape)} -> {cout} code {code} h2 {h2}", out, x_amax, y_amax)
@@ -336,7 +338,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                     dil, hip.bs(gy), hip.bs(gx), hip.bs(res) if res is not None else 0, 0, float(alpha),
                     int(accumulate), *margs, hip.stream())
             if h2:
-                args, _ga = _h2_args(args, gy, gy_amax, None if (code == 9001 and os.environ.get("IRR_X3S_NO_FUSED_AMAX")) else gx_amax)
+                args, _ga = _h2_args(args, gy, gy_amax, None if (code == 9001 and _X3S_NO_FUSED_AMAX) else gx_amax)
             variant = (200000 if h2 else 100000) + code
             LAUNCHES["dgrad_x3s" if code == 9001 else "dgrad_h2" if h2 else "dgrad_x3"] += 1
         else:
@@ -372,7 +374,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
             gx += tmp
         if mask is not None and nmask > 0:
             gx[:, :nmask] *= torch.where(mask[:, :nmask] > 0, 1.0, 0.1)
-    if gx_amax is not None and (not h2 or (code == 9001 and os.environ.get("IRR_X3S_NO_FUSED_AMAX"))):
+    if gx_amax is not None and (not h2 or (code == 9001 and _X3S_NO_FUSED_AMAX)):
         amax_measure(gx, gx_amax)
     if _CHECK_FINITE:
         _check_finite(f"conv_dgrad {tuple(gy.shape)} -> {cin} dil {dil} stride {stride} h2 {h2}", gx, gy_amax, gx_amax)
