@@ -167,6 +167,12 @@ _FINITE_LOG = []
 def dump_finite_log(limit: int = 8) -> None:
     import sys
     torch.cuda.synchronize()
+    if _CHECK_FINITE == "slots":                                   # entries: (what, measured max |t|, fused slot)
+        bad = [(i, w, float(m), float(s)) for i, (w, m, s) in enumerate(_FINITE_LOG) if not float(s) >= float(m)]
+        print(f"[slot log] {len(_FINITE_LOG)} tensors logged, {len(bad)} whose fused slot is below the measured magnitude (or not finite):", file=sys.stderr)
+        for i, w, m, s in bad[:limit * 4]:
+            print(f"  #{i} {w}: measured {m:.6e}, slot {s:.6e}", file=sys.stderr)
+        return
     bad = [(i, e) for i, e in enumerate(_FINITE_LOG) if not bool(e[1])]
     print(f"[finite log] {len(_FINITE_LOG)} conv launches logged, {len(bad)} with a non-finite output; first:", file=sys.stderr)
     for i, (what, flag, slots, stats) in bad[:limit]:
@@ -251,7 +257,7 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
         TIMER.wrap(variant, 2.0 * B * oh * ow * cout * (real_cin or cin) * k * k, lambda: _call_conv(args))
     if y_amax is not None and (not h2 or (code == 9001 and _X3S_NO_FUSED_AMAX)):
         amax_measure(out, y_amax)
-    if _CHECK_FINITE:
+    if _CHECK_FINITE and _CHECK_FINITE != "slots":
         _check_finite(f"conv_forward {tuple(x.shape)} -> {cout} code {code} h2 {h2}", out, x_amax, y_amax)
     return out
 
@@ -376,7 +382,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
             gx[:, :nmask] *= torch.where(mask[:, :nmask] > 0, 1.0, 0.1)
     if gx_amax is not None and (not h2 or (code == 9001 and _X3S_NO_FUSED_AMAX)):
         amax_measure(gx, gx_amax)
-    if _CHECK_FINITE:
+    if _CHECK_FINITE and _CHECK_FINITE != "slots":
         _check_finite(f"conv_dgrad {tuple(gy.shape)} -> {cin} dil {dil} stride {stride} h2 {h2}", gx, gy_amax, gx_amax)
     return gx
 

@@ -500,6 +500,11 @@ class _OccUpsampleFn(hip.Function):
         e, x2 = conv_forward_skip(xs[-1], w_end, b_end, True, x_init, x_amax=sl(4))
         o = conv_forward(x2, w_out, b_out, 1, 1, True)
         out = torch.add(o, occ_up)
+        if S is not None and _c._CHECK_FINITE == "slots":        # diagnosis (NOTES C.5): fused magnitudes against a pass over the tensors
+            for name, t, i in (("x_in", x_in, 0), ("x0", xs[0], 1), ("x1", xs[1], 2), ("x2", xs[2], 3), ("x3", xs[3], 4),
+                               ("t1", ts[0], 5), ("t2", ts[1], 6), ("t3", ts[2], 7)):
+                _c._FINITE_LOG.append((f"occ_upsample {tuple(t.shape)} {name}", torch.linalg.vector_norm(t, ord=float("inf")),
+                                       S.slots[S.first + i].clone()))
         ctx.amax = S
         ctx.mul_const = mul_const
         ctx.widths = widths
@@ -561,6 +566,12 @@ class _OccUpsampleFn(hip.Function):
                 amax_measure(gpre_e, G.sub(0))
             gw_end, _ = wgrad_param_(x3, gpre_e, w_end, None, 1, 1, want_bias=False, x_amax=sl(4), gy_amax=gl(0))
         g_x = conv_dgrad(gpre_e, w_end, 1, 1, hw_, gy_amax=gl(0), gx_amax=gl(1))     # gradient w.r.t. x3
+        def _slog(name, t, i):                                  # diagnosis (NOTES C.5), see forward
+            if G is not None and _c._CHECK_FINITE == "slots":
+                _c._FINITE_LOG.append((f"occ_upsample backward {tuple(t.shape)} {name}", torch.linalg.vector_norm(t, ord=float("inf")),
+                                       G.slots[G.first + i].clone()))
+        _slog("gpre_e", gpre_e, 0)
+        _slog("g_x3", g_x, 1)
         # three residual blocks with shared weights: x_i = x_{i-1} + mc * conv_r1(t_i), t_i = lrelu(conv_r0(x_{i-1}))
         routed = _c.SIDE is not None and _c.SIDE.route(w_r0, b_r0) is not None
         acc_r0 = None if routed else (torch.zeros_like(w_r0), z(w_r0.shape[0]))
@@ -571,16 +582,19 @@ class _OccUpsampleFn(hip.Function):
         for i in (2, 1, 0):
             wgrad_param_(ts[i], g_x, w_r1, b_r1, 1, 1, alpha=mc, acc=acc_r1, x_amax=sl(5 + i), gy_amax=gl(gxs))
             gpre_t = conv_dgrad(g_x, w_r1, 1, 1, hw_, mask=ts[i], nmask=ts[i].shape[1], alpha=mc, gy_amax=gl(gxs), gx_amax=gl(2 + 2 * i))
+            _slog(f"gpre_t{i}", gpre_t, 2 + 2 * i)
             wgrad_param_(xs[i], gpre_t, w_r0, b_r0, 1, 1, acc=acc_r0, x_amax=sl(1 + i), gy_amax=gl(2 + 2 * i))
             if i > 0:
                 g_x = conv_dgrad(gpre_t, w_r0, 1, 1, hw_, res=g_x, gy_amax=gl(2 + 2 * i), gx_amax=gl(3 + 2 * i))      # skip + branch in one launch
                 gxs = 3 + 2 * i
+                _slog(f"g_x{i}", g_x, gxs)
             else:
                 # x_0 = x_init: add the x2 skip gradient (accumulate into g_x2) and apply init_conv's LeakyReLU'
                 conv_dgrad(gpre_t, w_r0, 1, 1, hw_, gx=g_x2, accumulate=True, res=g_x, mask=x0, nmask=x0.shape[1],
                            gy_amax=gl(2), gx_amax=gl(8))
         gw_r0, gb_r0 = acc_r0 if acc_r0 is not None else (None, None)
         gw_r1, gb_r1 = acc_r1 if acc_r1 is not None else (None, None)
+        _slog("gpre_init", g_x2, 8)
         gpre_init = g_x2
         x_real = x_in[:, :cin] if x_in.shape[1] > cin else x_in
         gw_init, gb_init = wgrad_param_(x_real, gpre_init, w_init, b_init, 1, 1, x_amax=sl(0), gy_amax=gl(8))

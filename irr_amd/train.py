@@ -95,7 +95,7 @@ class TrainStep:
             _conv.SIDE.join()
         if copied is not None:                    # the value left the device long ago: this wait does not stall the pipeline
             copied.synchronize()
-            if math.isnan(float(self._loss_host)) and _conv._CHECK_FINITE == "async":
+            if math.isnan(float(self._loss_host)) and _conv._CHECK_FINITE in ("async", "slots"):
                 _conv.dump_finite_log()
             assert not math.isnan(float(self._loss_host)), "training_loss is NaN"
         self.optimizer.step()
