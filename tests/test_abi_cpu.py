@@ -63,3 +63,28 @@ def test_build_is_keyed_on_content_not_on_mtime(tmp_path):
         if open(stamp).read() != good:
             B.build(force=True, verbose=False)
     assert B.built_hash() == B.source_hash()
+
+
+def test_streaming_kernel_h2_form_is_opt_in():
+    """Routing is host code: the streaming 32-channel problems report code 9001 to both eligibility functions of the library, and
+    irr_amd.conv keeps them on bf16x3 unless conv.X3S_H2 is switched on (DESIGN.md 5.2 / profiles/NOTES.md C.5)."""
+    from irr_amd import conv as C, hip
+    old_math = C.MATH
+    C.set_math("h2")
+    try:
+        shape = (64, 32, 384, 448, 32, 3, 1, 1)               # B, Cin, H, W, Cout, k, stride, dil: a full-resolution 32 -> 32 layer
+        assert hip.lib().irr_conv2d_x3_eligible(*shape) == 9001 and hip.lib().irr_conv2d_h2_eligible(*shape) == 9001
+        assert C.x3_code(*shape) == 9001
+        old = C.set_x3s_h2(False)
+        try:
+            assert C.h2_code(*shape) == 0
+            C.set_x3s_h2(True)
+            assert C.h2_code(*shape) == 9001
+            big = (64, 128, 96, 112, 128, 3, 1, 1)            # a conv_x3_kernel problem is on the fp16x2 form either way
+            assert C.h2_code(*big) == C.x3_code(*big) != 0
+            C.set_x3s_h2(False)
+            assert C.h2_code(*big) == C.x3_code(*big)
+        finally:
+            C.set_x3s_h2(old)
+    finally:
+        C.set_math(old_math)
