@@ -510,10 +510,12 @@ def main():
                                        "before_backward (.item(), as the reference)"},
                "loss": head["loss"],
                "conv_math": C.MATH,
+               "x3s_h2": bool(C.X3S_H2),                   # the streaming 32-channel kernel's fp16x2 form (opt-in: IRR_X3S_H2=1)
                "conv_math_note": {"h2": "fp32 tensors in HBM; the MFMA convs split every operand, scaled by a power of two from max|.| of its "
                                         "tensor, into two fp16 pieces (23 significant bits) and accumulate three piece products in fp32 "
                                         "(v_mfma_f32_32x32x16_f16); error against fp64 = the fp32-MFMA kernels' (profiles/r4_h2_check.txt, "
-                                        "tests/test_h2_gpu.py); IRR_CONV_MATH=x3: bf16x3 / six products, =f32: fp32 MFMA",
+                                        "tests/test_h2_gpu.py); the streaming 32-channel kernel stays on bf16x3 unless IRR_X3S_H2=1; "
+                                        "IRR_CONV_MATH=x3: bf16x3 / six products everywhere, =f32: fp32 MFMA",
                                   "x3": "fp32 tensors in HBM; the MFMA convs split every operand into three bf16 pieces and accumulate six "
                                         "piece products in fp32", "f32": "fp32 MFMA everywhere"}.get(C.MATH),
                "launches_per_step": head["routing"],
