@@ -46,18 +46,21 @@ X3_PLANES = {1: 352, 2: 616, 3: 640}
 
 
 def kernel_name(var):
-    """variant code of irr_amd.conv's KernelTimer -> (kernel template instantiation, its MFMA roof in fp32 TFLOP/s)"""
-    if var == 109001:
-        return ("conv_x3s_kernel", X3_PEAK_TFLOPS)
-    if var == 209001:                      # the streaming kernel in its fp16x2 form (conv_x3s_kernel<EPI, 2>)
-        return ("conv_x3s_kernel", H2_PEAK_TFLOPS)
+    """variant code of irr_amd.conv's KernelTimer -> (the kernel's template instantiation SPELLED AS rocprofv3 PRINTS IT, so that the
+    line's ``roofline.kernel`` is a row of profiles/*_kernel_stats.txt; its MFMA roof in fp32 TFLOP/s; "hbm" | "mfma" = what bounds it)"""
+    if var >= 100000 and 9010 <= var % 100000 <= 9013:          # the streaming 32-channel kernel, one instantiation per epilogue form
+        np_ = 2 if var >= 200000 else 3
+        return (f"conv_x3s_kernel<{var % 10}, {np_}>", H2_PEAK_TFLOPS if np_ == 2 else X3_PEAK_TFLOPS, "hbm")
     if var >= 200000:
         c = var - 200000
-        return (f"conv_x3_kernel<{c // 1000},{(c // 100) % 10},{(c // 10) % 10},{X3_PLANES.get(c % 10, 0)},2>", H2_PEAK_TFLOPS)
+        return (f"conv_x3_kernel<{c // 1000}, {(c // 100) % 10}, {(c // 10) % 10}, {X3_PLANES.get(c % 10, 0)}, 2>", H2_PEAK_TFLOPS, "mfma")
     if var >= 100000:
         c = var - 100000
-        return (f"conv_x3_kernel<{c // 1000},{(c // 100) % 10},{(c // 10) % 10},{X3_PLANES.get(c % 10, 0)},3>", X3_PEAK_TFLOPS)
-    return (f"conv_fwd_kernel<{var // 100},{(var // 10) % 10},{var % 10}>", FP32_MFMA_PEAK_TFLOPS)
+        return (f"conv_x3_kernel<{c // 1000}, {(c // 100) % 10}, {(c // 10) % 10}, {X3_PLANES.get(c % 10, 0)}, 3>", X3_PEAK_TFLOPS, "mfma")
+    return (f"conv_fwd_kernel<{var // 100}, {(var // 10) % 10}, {var % 10}>", FP32_MFMA_PEAK_TFLOPS, "mfma")
+
+
+HBM_PEAK_TBPS = 8.0                    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 CONV_GFLOP_PER_PAIR = {(384, 448): 1088.4, (448, 1024): 2902.5}   # SURVEY.md 8(d): 3x forward conv FLOPs
 SECONDARY = (8, 448, 1024)             # per-GPU share of BASELINE configs[4] (Sintel-shaped 448x1024, bs64 on 8 GPUs)
 SECONDARY_STEPS = 5
@@ -76,6 +79,27 @@ def cpu_model():
         pass
     import platform
     return platform.processor() or "unknown"
+
+
+def physical_cores():
+    """physical cores of the host (sockets x cores per socket from /proc/cpuinfo; half the logical CPUs as a fallback)"""
+    try:
+        seen = set()
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
 
 
 def synthetic_batch(batch, height, width, seed, device):
@@ -120,9 +144,15 @@ def cpu_baseline(height, width, quick=False):
     out = []
     for bp, thr in legs:
         out.append({"batch": bp, "threads": thr, "pairs_per_s": round(_cpu_leg(O, height, width, bp, thr), 4)})
+    phys = physical_cores()
+    if not quick and phys > best_thr:
+        # BASELINE.md section 3 asks for the all-physical-cores figure: ONE timed step after one warm-up (bounded: this graph gets
+        # SLOWER with more threads, so the leg is a record, not a contender -- ~30 s at 0.07 pairs/s on 128 cores)
+        out.append({"batch": 2, "threads": phys, "pairs_per_s": round(_cpu_leg(O, height, width, 2, phys, warm=1, timed=1), 4),
+                    "note": "all physical cores, 1 warm-up + 1 timed step"})
     top = max(out, key=lambda r: r["pairs_per_s"])
     return {"value": top["pairs_per_s"], "unit": "image-pairs/s", "cores": top["threads"], "kind": "port",
-            "host_cpus": ncpu, "cpu_model": cpu_model(), "legs": out,
+            "host_cpus": ncpu, "physical_cores": phys, "cpu_model": cpu_model(), "legs": out,
             "sample": f"oracle train step (fwd+loss+bwd+Adam) at {height}x{width}: 2 warm-up + 5 timed steps per leg, median step "
                       f"time; legs = (batch, torch threads) {[(r['batch'], r['threads']) for r in out]}; value = the fastest "
                       f"leg (batch {top['batch']}, {top['threads']} threads; {ncpu} host CPUs visible, more threads are slower)"}
@@ -335,59 +365,62 @@ def main():
         ach = st["flops"] / st["seconds"] / 1e12
         tot_f = sum(s["flops"] for s in summ.values())
         tot_s = sum(s["seconds"] for s in summ.values())
-        kname, peak = kernel_name(var)
-        roof = {"bound": "mfma", "kernel": kname,
-                "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None,
-                "peak_note": ("algorithmic fp32 FLOPs (2*MACs); the fp16x2 form of conv_x3 issues 3 fp16 MFMA products per fp32 product, "
-                              "so its roof is the dense fp16 MFMA peak 2500 / 3 = 833.3 TFLOP/s" if peak == H2_PEAK_TFLOPS else
-                              "algorithmic fp32 FLOPs (2*MACs); conv_x3 issues 6 bf16 MFMA products per fp32 product, "
-                              "so its roof is the dense bf16 MFMA peak 2500 / 6 = 416.7 TFLOP/s" if peak != FP32_MFMA_PEAK_TFLOPS
-                              else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+        kname, peak, bound = kernel_name(var)
+        mfma_note = ("algorithmic fp32 FLOPs (2*MACs); the fp16x2 form issues 3 fp16 MFMA products per fp32 product, "
+                     "so its roof is the dense fp16 MFMA peak 2500 / 3 = 833.3 TFLOP/s" if peak == H2_PEAK_TFLOPS else
+                     "algorithmic fp32 FLOPs (2*MACs); the bf16x3 form issues 6 bf16 MFMA products per fp32 product, "
+                     "so its roof is the dense bf16 MFMA peak 2500 / 6 = 416.7 TFLOP/s" if peak != FP32_MFMA_PEAK_TFLOPS
+                     else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)")
+        excl = ({"achieved": round(st["fwd_flops"] / st["fwd_seconds"] / 1e12, 2),
+                 "frac": round(st["fwd_flops"] / st["fwd_seconds"] / 1e12 / peak, 4),
+                 "launches": st["fwd_calls"],
+                 "avg_launch_us": round(st["fwd_seconds"] / st["fwd_calls"] * 1e6, 2)} if st["fwd_calls"] else None)
+        if bound == "hbm":
+            # the streaming 32-channel kernel: priced against HBM with the ALGORITHMIC bytes of its launches (input map
+            # + output map + every residual / accumulate / mask / second-output map, each once); the MFMA view stays as a side key
+            gbps = st["bytes"] / st["seconds"] / 1e9
+            roof = {"bound": "hbm", "kernel": kname, "achieved": round(gbps, 1), "peak": HBM_PEAK_TBPS * 1e3, "unit": "GB/s",
+                    "frac": round(gbps / (HBM_PEAK_TBPS * 1e3), 4), "traffic": None,
+                    "bytes_per_launch": st["bytes"] / st["calls"],
+                    "peak_note": "algorithmic bytes per launch (every operand / result map once) / HIP-event duration against 8 TB/s of HBM3E",
+                    "mfma_view": {"achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                                  "note": mfma_note},
+                    "exclusive": ({"achieved": round(st["fwd_bytes"] / st["fwd_seconds"] / 1e9, 1),
+                                   "frac": round(st["fwd_bytes"] / st["fwd_seconds"] / 1e9 / (HBM_PEAK_TBPS * 1e3), 4),
+                                   "launches": st["fwd_calls"], "avg_launch_us": round(st["fwd_seconds"] / st["fwd_calls"] * 1e6, 2)}
+                                  if st["fwd_calls"] else None)}
+        else:
+            roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None, "peak_note": mfma_note, "exclusive": excl}
+        roof.update({
                 "launches": st["calls"], "avg_launch_us": round(st["seconds"] / st["calls"] * 1e6, 2),
                 "flop_per_launch": st["flops"] / st["calls"],
                 "concurrent_lanes": 1 if a.no_async_wgrad else 2,
                 "timed_steps": steps,
                 "timing": f"HIP events on the launch stream around every conv launch of {steps} steps of the timed region (every "
-                          f"{max(1, a.timer_every)}-th step, starting with the first)",
+                          f"{max(1, a.timer_every)}-th step, starting with the first); kernel = the template instantiation as rocprofv3 "
+                          f"prints it (profiles/*_kernel_stats.txt)",
                 "note": ("durations include time-sharing the chip with the asynchronous weight-gradient lane "
                          "(second HIP stream) during backward; 'exclusive' = the forward-pass launches of the same "
                          "kernel, which run alone") if not a.no_async_wgrad else "single stream",
-                "exclusive": ({"achieved": round(st["fwd_flops"] / st["fwd_seconds"] / 1e12, 2),
-                               "frac": round(st["fwd_flops"] / st["fwd_seconds"] / 1e12 / peak, 4),
-                               "launches": st["fwd_calls"],
-                               "avg_launch_us": round(st["fwd_seconds"] / st["fwd_calls"] * 1e6, 2)}
-                              if st["fwd_calls"] else None),
                 "all_conv_fwd_dgrad": {"achieved": round(tot_f / tot_s / 1e12, 2), "seconds_per_step": round(tot_s / steps, 5),
                                        "flops_per_step": tot_f / steps},
                 "by_kernel_all": {kernel_name(v)[0]: {"launches": s_["calls"], "achieved": round(s_["flops"] / s_["seconds"] / 1e12, 2),
-                                                      "avg_launch_us": round(s_["seconds"] / s_["calls"] * 1e6, 2)}
+                                                      "avg_launch_us": round(s_["seconds"] / s_["calls"] * 1e6, 2),
+                                                      "algorithmic_GBps": round(s_["bytes"] / s_["seconds"] / 1e9, 1)}
                                   for v, s_ in summ.items()},
                 "by_kernel": {kernel_name(v)[0]: {"launches": s_["calls"], "ms_per_step": round(s_["seconds"] / steps * 1e3, 2),
                                                   "achieved": round(s_["flops"] / s_["seconds"] / 1e12, 1)}
-                              for v, s_ in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:6]}}
-        if kname == "conv_x3s_kernel":
-            # the 32-channel streaming kernel is bandwidth-bound: 72 FLOP per algorithmic byte for a 32 -> 32 layer
-            roof["bandwidth_view"] = {"bound": "hbm", "algorithmic_TBps": round(ach / 72.0, 3), "exclusive_algorithmic_TBps":
-                                      round(st["fwd_flops"] / st["fwd_seconds"] / 1e12 / 72.0, 3) if st["fwd_seconds"] > 0 else None,
-                                      "peak_TBps": 8.0, "note": "in + out maps of a 32 -> 32 layer = FLOPs / 72; residual / mask / accumulate operands "
-                                      "come on top (PMC: profiles/hbm_traffic.json)"}
+                              for v, s_ in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:6]}})
         # HBM bytes per launch of that kernel from the committed PMC passes (profiles/hbm_traffic*.json: separate --pmc FETCH_SIZE /
         # WRITE_SIZE runs of THIS command, FETCH x2 gfx950 correction).  PMC counters cannot be collected from inside the process,
         # so the bytes are only reported when the json was measured on a library built from the very sources that are loaded now.
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILES[(height, width, batch_pairs)])))
-            k = roof["kernel"].replace(",", ", ")
+            k = roof["kernel"]
             if tr.get("_source_hash") != B_.source_hash() or B_.built_hash() != B_.source_hash():
                 roof["traffic_source"] = (f"stale: {TRAFFIC_FILES[(height, width, batch_pairs)]} was measured on sources "
                                           f"{tr.get('_source_hash')}, the library is built from {B_.source_hash()}")
-            elif k == "conv_x3s_kernel" and any(n.startswith("conv_x3s_kernel<") for n in tr):
-                # (the timer does not distinguish the streaming kernel's epilogue variants: launch-weighted mean over them)
-                ent = [v for n, v in tr.items() if n.startswith("conv_x3s_kernel<")]
-                nl = sum(v["launches"] for v in ent)
-                roof["traffic"] = round(sum((v["fetch_MB_per_launch_corrected"] + v["write_MB_per_launch"]) * v["launches"] for v in ent) / nl * 1e6)
-                roof["traffic_source"] = (f"profiles/{TRAFFIC_FILES[(height, width, batch_pairs)]} (rocprofv3 PMC passes over this "
-                                          f"command, launch-weighted mean over the kernel's epilogue variants, sources {tr['_source_hash']})")
             elif k in tr:
                 roof["traffic"] = round((tr[k]["fetch_MB_per_launch_corrected"] + tr[k]["write_MB_per_launch"]) * 1e6)
                 roof["traffic_source"] = (f"profiles/{TRAFFIC_FILES[(height, width, batch_pairs)]} (rocprofv3 PMC passes over this "
@@ -431,6 +464,18 @@ def main():
         extra["without_kernel_timer"] = {"value": round(nt["value"], 3), "ms_per_step": round(nt["dt"] / 5 * 1e3, 3), "steps": 5,
                                          "note": "same process, same step, KernelTimer off (the headline's timed region records two "
                                                  "HIP events around every conv launch for the roofline object)"}
+    if world == 1 and not a.no_extra_legs and a.harness == "own" and C.MATH == "h2":
+        # the range-free fall-back arithmetic beside the headline: 5 steps of the same workload, same process, with every
+        # split-operand conv on the bf16x3 form (three bf16 pieces, six products: 24 significant bits whatever the operand range)
+        C.set_math("x3")
+        try:
+            x3r = run(make_step, a.batch, a.height, a.width, 5, 1, False)
+        finally:
+            C.set_math("h2")
+        extra["conv_math_x3"] = {"value": round(x3r["value"], 3), "unit": "image-pairs/s", "ms_per_step": round(x3r["dt"] / 5 * 1e3, 3),
+                                 "steps": 5, "warmup": 1, "loss": x3r["loss"],
+                                 "note": "IRR_CONV_MATH=x3 / conv.set_math('x3'): bf16x3 split operands everywhere (no operand scaling, "
+                                         "no amax slots); same model, same batches"}
     if world == 1 and not a.no_extra_legs and a.harness == "own" and not a.no_async_wgrad and not a.no_kernel_timer:
         # (1) kernel quality without lane time-sharing: 3 steps with the weight gradients on the main stream, same process
         arena.disable_async_wgrad()
@@ -441,8 +486,9 @@ def main():
             kn = head["roofline"]["kernel"]
             k_ss = ss["roofline"]["by_kernel_all"].get(kn)
             if k_ss is not None:
+                ach_ss = k_ss["algorithmic_GBps"] if head["roofline"]["bound"] == "hbm" else k_ss["achieved"]
                 head["roofline"]["single_stream"] = {
-                    "achieved": k_ss["achieved"], "frac": round(k_ss["achieved"] / head["roofline"]["peak"], 4),
+                    "achieved": ach_ss, "frac": round(ach_ss / head["roofline"]["peak"], 4),
                     "avg_launch_us": k_ss["avg_launch_us"], "launches": k_ss["launches"], "ms_per_step": round(ss["dt"] / 3 * 1e3, 3),
                     "note": "3 timed steps of the same workload with the weight-gradient launches on the main stream "
                             "(GradArena.enable_direct_wgrad): no second kernel shares the chip"}
@@ -495,7 +541,8 @@ def main():
         own = a.harness == "own"
         out = {"metric": "image-pairs/sec fwd+bwd IRR-PWC 384x448 bs32", "value": round(value, 3), "unit": "image-pairs/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(head["dt"] / a.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": {"h2": "f32 (fp16x2 split operands)", "x3": "f32 (bf16x3 split operands)"}.get(C.MATH, "f32"), "data": "synthetic",
                "config": {"workload": workload_name("configs[2]" if (a.height, a.width) == (384, 448) else "(other crop)",
                                                     a.batch, a.height, a.width).replace("synthetic", "FlyingChairsOcc-shaped synthetic"),
                           "pairs_per_gpu": a.batch, "global_batch": a.batch * world, "height": a.height, "width": a.width,
@@ -511,11 +558,14 @@ def main():
                "loss": head["loss"],
                "conv_math": C.MATH,
                "x3s_h2": bool(C.X3S_H2),                   # the streaming 32-channel kernel's fp16x2 form (opt-in: IRR_X3S_H2=1)
-               "conv_math_note": {"h2": "fp32 tensors in HBM; the MFMA convs split every operand, scaled by a power of two from max|.| of its "
-                                        "tensor, into two fp16 pieces (23 significant bits) and accumulate three piece products in fp32 "
-                                        "(v_mfma_f32_32x32x16_f16); error against fp64 = the fp32-MFMA kernels' (profiles/r4_h2_check.txt, "
-                                        "tests/test_h2_gpu.py); the streaming 32-channel kernel stays on bf16x3 unless IRR_X3S_H2=1; "
-                                        "IRR_CONV_MATH=x3: bf16x3 / six products everywhere, =f32: fp32 MFMA",
+               "conv_math_note": {"h2": "fp32 tensors in HBM, fp32 accumulation and results; the MFMA convs split every operand, scaled by a "
+                                        "power of two from max|.| of its tensor, into two fp16 pieces and accumulate three piece products "
+                                        "(v_mfma_f32_32x32x16_f16).  The activation-side low piece is stored x 2^11 (its partner, the "
+                                        "weight-side high piece, x 2^-11 in registers): 22-23 significant bits for every ELEMENT within "
+                                        "2^29 (5e8 : 1) of its tensor's maximum, absolute 2^-36 of the scaled range below -- regional "
+                                        "tests in tests/test_h2_gpu.py (quiet samples / rows / channels at 1e-5 ... 1e-7); the weight "
+                                        "gradient's gy-role operand keeps the plain pair (2^17 : 1).  'conv_math_x3' = the same step on "
+                                        "bf16x3 (range-free, 24 bits); IRR_CONV_MATH=f32: fp32 MFMA",
                                   "x3": "fp32 tensors in HBM; the MFMA convs split every operand into three bf16 pieces and accumulate six "
                                         "piece products in fp32", "f32": "fp32 MFMA everywhere"}.get(C.MATH),
                "launches_per_step": head["routing"],

@@ -275,7 +275,13 @@ int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* gw, float* w
  * fragment: irr_conv_h2_packed_bytes includes it).  irr_conv2d_h2_eligible: the code of irr_conv2d_x3_eligible (9001 = the
  * streaming 32-channel kernel, which has the same two forms).  irr_conv2d_fwd_h2: contract of irr_conv2d_fwd_x3_splitk (ws
  * nullable); irr_conv2d_fwd_h2_dual: contract of irr_conv2d_fwd_x3_dual (y_amax bounds y, the sum).
- * irr_conv2d_wgrad_h2: contract of irr_conv2d_wgrad_x3 (dil == 1) / irr_conv2d_wgrad_x3_dil (dil > 1), same scratch and fold. */
+ * irr_conv2d_wgrad_h2: contract of irr_conv2d_wgrad_x3 (dil == 1) / irr_conv2d_wgrad_x3_dil (dil > 1), same scratch and fold.
+ * Dynamic range (ABI 7): the activation-side operand of irr_conv2d_fwd_h2 / _dual (x, or gy of a data gradient) is carried as
+ * hi + 2^-11 lo' with the low piece scaled UP by 2^11 -- 22-23 significant bits for every ELEMENT within 2^29 (5e8) of the
+ * tensor's maximum, absolute 2^-36 of the scaled range below; the weight side multiplies its high piece by 2^-11 in registers
+ * (exact within 2^18 of the matrix maximum).  The weight gradient has two activation operands: the one in the kernel's x role
+ * gets the scaled-up low piece (2^28 : 1), the other the plain pair (2^17 : 1 at full precision, absolute 2^-25 of its scale
+ * below); irr_conv2d_wgrad_h2_robust_side says which is which for a problem (1: x, 0: gy). */
 int irr_amax_f32(const float* x, int B, long n, long bs, float* slot, void* stream);
 long irr_conv_h2_packed_bytes(int Cin, int Cout);
 int irr_conv_pack_weights_h2(const float* w, void* wq, int Cin, int Cout, int transpose, const float* amax, void* stream);
@@ -295,6 +301,7 @@ int irr_conv2d_fwd_h2_dual(const float* x, const void* wq, const float* bias, co
                            int B, int Cin, int H, int W, int Cout, int dil,
                            long x_bs, long y_bs, long res_bs, long y2_bs, int lrelu, float alpha,
                            const float* x_amax, int n_amax, float* y_amax, void* stream);
+int irr_conv2d_wgrad_h2_robust_side(int B, int Cin, int H, int W, int Cout, int dil);
 int irr_conv2d_wgrad_h2(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                         int B, int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs,
                         const float* x_amax, int nx, const float* gy_amax, int ng, void* stream);

@@ -42,7 +42,9 @@ class KernelTimer:
         self.active = bool(on)
         self.steps += 1 if on else 0
 
-    def wrap(self, variant: int, flops: float, launch, phase: str = "fwd"):
+    def wrap(self, variant: int, flops: float, launch, phase: str = "fwd", nbytes: float = 0.0):
+        """nbytes: ALGORITHMIC bytes of the launch (every operand map read once, every result map written once) -- what an
+        HBM-bound kernel's roofline is priced with"""
         if not self.active:
             launch()
             return
@@ -50,26 +52,28 @@ class KernelTimer:
         s.record()
         launch()
         e.record()
-        self.records.append((variant, flops, s, e, phase))
+        self.records.append((variant, flops, s, e, phase, nbytes))
 
     def summary(self):
         """{variant: {calls, flops, seconds, fwd_calls, fwd_flops, fwd_seconds}} -- the fwd_* entries cover only the
         forward-pass launches, which never share the chip with the asynchronous weight-gradient lane."""
         torch.cuda.synchronize()
         agg = {}
-        for variant, flops, s, e, phase in self.records:
-            a = agg.setdefault(variant, [0, 0.0, 0.0, 0, 0.0, 0.0])
+        for variant, flops, s, e, phase, nbytes in self.records:
+            a = agg.setdefault(variant, [0, 0.0, 0.0, 0, 0.0, 0.0, 0.0, 0.0])
             dt = s.elapsed_time(e) * 1e-3
             a[0] += 1
             a[1] += flops
             a[2] += dt
+            a[6] += nbytes
             if phase == "fwd":
                 a[3] += 1
                 a[4] += flops
                 a[5] += dt
+                a[7] += nbytes
         self.records.clear()
         return {v: {"calls": a[0], "flops": a[1], "seconds": a[2], "fwd_calls": a[3], "fwd_flops": a[4],
-                    "fwd_seconds": a[5]} for v, a in agg.items()}
+                    "fwd_seconds": a[5], "bytes": a[6], "fwd_bytes": a[7]} for v, a in agg.items()}
 
 
 TIMER: Optional[KernelTimer] = None
@@ -99,6 +103,17 @@ def set_math(name: str) -> None:
 
 
 _X3_ENV_DONE = [False]
+
+
+def x3s_variant(h2: bool, res, accumulate: bool, masked: bool, dual: bool = False) -> int:
+    """KernelTimer key of a conv_x3s_kernel<EPI, NP> launch: 1/2 00000 + 9010 + EPI (the launcher's choice, csrc/conv_x3.hip:
+    2 = accumulate / mask, 3 = second output, 1 = residual, 0 = plain) -- rocprofv3 lists the instantiations separately, so does the timer"""
+    epi = 2 if (accumulate or masked) else (3 if dual else 1) if res is not None else 0
+    return (200000 if h2 else 100000) + 9010 + epi
+
+
+def _map_bytes(B: int, H: int, W: int, *channels) -> float:
+    return 4.0 * B * H * W * sum(channels)
 
 
 def x3_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, dil: int) -> int:
@@ -239,7 +254,7 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
         measure_y = h2 and code == 9001 and y_amax is not None and _X3S_NO_FUSED_AMAX
         if h2:
             args, _xa = _h2_args(args, x, x_amax, None if measure_y else y_amax)
-        variant = (200000 if h2 else 100000) + code
+        variant = x3s_variant(h2, res, accumulate, False) if code == 9001 else (200000 if h2 else 100000) + code
         LAUNCHES["fwd_x3s" if code == 9001 else "fwd_h2" if h2 else "fwd_x3"] += 1          # (fwd_x3s: the streaming kernel, either form)
     else:
         LAUNCHES["fwd_f32"] += 1
@@ -254,7 +269,8 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     else:
         if variant is None:
             variant = hip.lib().irr_conv2d_fwd_variant(B, cout, oh, ow, k)
-        TIMER.wrap(variant, 2.0 * B * oh * ow * cout * (real_cin or cin) * k * k, lambda: _call_conv(args))
+        TIMER.wrap(variant, 2.0 * B * oh * ow * cout * (real_cin or cin) * k * k, lambda: _call_conv(args),
+                   nbytes=_map_bytes(B, H, W, cin) + _map_bytes(B, oh, ow, cout * (1 + (res is not None) + bool(accumulate))))
     if y_amax is not None and (not h2 or (code == 9001 and _X3S_NO_FUSED_AMAX)):
         amax_measure(out, y_amax)
     if _CHECK_FINITE and _CHECK_FINITE != "slots":
@@ -285,7 +301,8 @@ def conv_forward_skip(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
         if TIMER is None:
             hip.call(*args)
         else:
-            TIMER.wrap((200000 if h2 else 100000) + 9001, 2.0 * B * H * W * cout * cin * 9, lambda: hip.call(*args))
+            TIMER.wrap(x3s_variant(h2, skip, False, False, dual=True), 2.0 * B * H * W * cout * cin * 9, lambda: hip.call(*args),
+                       nbytes=_map_bytes(B, H, W, cin, 3 * cout))
         if y_amax is not None and not h2:
             amax_measure(y, y_amax)
         return e, y
@@ -345,7 +362,8 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                     int(accumulate), *margs, hip.stream())
             if h2:
                 args, _ga = _h2_args(args, gy, gy_amax, None if (code == 9001 and _X3S_NO_FUSED_AMAX) else gx_amax)
-            variant = (200000 if h2 else 100000) + code
+            variant = (x3s_variant(h2, res, accumulate, mask is not None and nmask > 0) if code == 9001
+                       else (200000 if h2 else 100000) + code)
             LAUNCHES["dgrad_x3s" if code == 9001 else "dgrad_h2" if h2 else "dgrad_x3"] += 1
         else:
             LAUNCHES["dgrad_f32"] += 1
@@ -359,7 +377,9 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         else:
             if variant is None:
                 variant = hip.lib().irr_conv2d_fwd_variant(B, cin, H, W, k)
-            TIMER.wrap(variant, 2.0 * B * H * W * cout * (real_cin or cin) * k * k, lambda: _call_conv(args), "dgrad")
+            TIMER.wrap(variant, 2.0 * B * H * W * cout * (real_cin or cin) * k * k, lambda: _call_conv(args), "dgrad",
+                       nbytes=_map_bytes(B, oh, ow, cout) + _map_bytes(B, H, W, cin * (1 + (res is not None) + bool(accumulate))
+                                                                       + (min(nmask, cin) if mask is not None else 0)))
     elif stride == 2 and k == 3 and dil == 1 and H == 2 * oh and W == 2 * ow and cout >= 2 and cin > S2_GATHER_MAX_CIN:
         # transposed stride-2 conv == stride-1 conv (flipped weights) of the zero-interleaved gradient
         z = torch.zeros(B, cout, H, W, device=gy.device, dtype=torch.float32)

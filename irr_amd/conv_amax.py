@@ -7,6 +7,7 @@ A slot is filled either by the producing launch itself (``y_amax`` of irr_conv2d
 pass over the tensor (``measure``: irr_amax_f32, HBM-bound)."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -14,8 +15,7 @@ import torch
 from . import hip
 from .conv_pack import LAUNCHES
 
-
-POOL_SLOTS = 4096
+POOL_SLOTS = int(os.environ.get("IRR_AMAX_POOL", "4096"))      # (environment: diagnosis switch, profiles/NOTES.md C.5)
 _POOLS = {}
 
 
@@ -36,8 +36,16 @@ class Amax:
             return Amax(torch.zeros(n, device=device, dtype=torch.float32), 0, n)
         key = device.index if device.index is not None else torch.cuda.current_device()
         pool = _POOLS.get(key)
+        cur = torch.cuda.current_stream(device)
         if pool is None or pool[1] + n > POOL_SLOTS:
-            pool = _POOLS[key] = [torch.zeros(POOL_SLOTS, device=device, dtype=torch.float32), 0]
+            t = torch.zeros(POOL_SLOTS, device=device, dtype=torch.float32)
+            filled = torch.cuda.Event()
+            filled.record(cur)                                  # the fill is ordered on THIS stream only
+            pool = _POOLS[key] = [t, 0, cur, filled]
+        elif pool[2] != cur:
+            # slots handed to a node on ANOTHER stream (a branch stream, a warm-up side stream): nothing else orders their first
+            # use after the pool's zero fill -- a slot could be maxed before the fill lands, or zeroed after
+            cur.wait_event(pool[3])
         first = pool[1]
         pool[1] += n
         return Amax(pool[0], first, n)

@@ -95,6 +95,31 @@ class WgradSide:
         # runtime.py:188-189) the first launch of a backward pass registers join() as a FINAL CALLBACK of that pass: it runs on
         # the thread that called backward(), on its current stream, once the whole graph has been executed.
         self._join_queued = False
+        # Drop-in route (irr_amd.harness): parameters that received a routed contribution since the last join, and a hook called at
+        # the end of join() with them -- the harness re-attaches ``.grad`` there when the caller cleared the gradients BETWEEN forward
+        # and backward (``out = model(x); opt.zero_grad(); loss.backward()``: torch's set_to_none leaves ``.grad`` None while the
+        # lane has accumulated into the arena slice, and a stock optimizer would silently skip the parameter)
+        self._routed = {}
+        self.on_join = None
+
+    def abandon(self):
+        """Forget everything a backward pass that RAISED left behind (autograd skips its final callbacks then, so nobody joined):
+        queued launches, pending contribution reports, fold jobs whose partial images belong to the failed pass, and the sticky
+        ``_join_queued`` flag that would keep every later backward pass from queueing its join.  The caller (irr_amd.harness, at the
+        start of the next training forward pass) re-zeroes / re-adopts the arena afterwards."""
+        self._queued = []
+        self._pending = []
+        self._routed = {}
+        if self.batch is not None:
+            self.batch.n, self.batch.keep, self.batch.targets = 0, [], set()
+        self._join_queued = False
+        if not self.inline:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self._inflight.clear()
+
+    def stale(self) -> bool:
+        """True when a previous backward pass ended without its join (it raised): see abandon()"""
+        return self._join_queued or bool(self._queued) or bool(self._pending) or (self.batch is not None and self.batch.n > 0)
 
     def _view(self, p_):
         hit = self.views.get(id(p_))
@@ -180,6 +205,10 @@ class WgradSide:
         model code around the node does with the same gradient tensor (``a = a + b`` feeding two nodes,
         models/pwcnet_irr*.py)."""
         self._queue_join()
+        if self.on_join is not None:
+            for p_ in params:
+                if p_ is not None:
+                    self._routed[id(p_)] = p_
         if self.batch is not None and gw is not None:
             # a batch folds into each gradient at most once, and holds at most cap jobs: queued launches count
             if (self.batch.full_for(gw) or any(q[3] == gw.data_ptr() for q in self._queued)
@@ -203,8 +232,15 @@ class WgradSide:
         self._join_queued = False               # (also after a backward pass that raised before its final callbacks ran)
         self.flush()
         if self.inline:
+            self._after_join()
             return
         torch.cuda.current_stream().wait_stream(self.stream)
         self._inflight.clear()                   # later work on the current stream is ordered after the lane
+        self._after_join()
+
+    def _after_join(self):
+        if self.on_join is not None and self._routed:
+            routed, self._routed = self._routed, {}
+            self.on_join(list(routed.values()))
 
 

@@ -278,10 +278,11 @@ class _DenseEstimatorFn(hip.Function):
             if use_x3[k_]:
                 args = ("irr_conv2d_fwd_x3", hip.ptr(G), hip.ptr(packs[k_]), None, None, hip.ptr(G[:, t0:t1]), B, t0, H, W,
                         t1 - t0, 1, hip.bs(G), hip.bs(G), 0, 0, 1.0, 1, *margs, hip.stream())
-                variant = 100000 + x3_code(B, t0, H, W, t1 - t0, 3, 1, 1)
+                code = x3_code(B, t0, H, W, t1 - t0, 3, 1, 1)
+                variant = (_c.x3s_variant(use_x3[k_] == 2, None, True, nm > 0) if code == 9001
+                           else (200000 if use_x3[k_] == 2 else 100000) + code)
                 if use_x3[k_] == 2:
                     args, _ = _h2_args(args, G[:, :t0], Gs.sub(0, k_ + 1), Gs.sub(k_ + 1) if not last else None)
-                    variant += 100000
             else:
                 args = ("irr_conv2d_fwd_f32", hip.ptr(G), hip.ptr(packs[k_]), None, None, hip.ptr(G[:, t0:t1]), B, t0, H, W,
                         t1 - t0, H, W, 3, 1, 1, hip.bs(G), hip.bs(G), 0, 0, 1.0, 1, *margs, hip.stream())
@@ -289,7 +290,8 @@ class _DenseEstimatorFn(hip.Function):
             if _c.TIMER is None:
                 _call_conv(args)
             else:
-                _c.TIMER.wrap(variant, 2.0 * B * H * W * t0 * (t1 - t0) * 9, lambda: _call_conv(args), "dgrad")
+                _c.TIMER.wrap(variant, 2.0 * B * H * W * t0 * (t1 - t0) * 9, lambda: _call_conv(args), "dgrad",
+                              nbytes=4.0 * B * H * W * (t0 + 2 * (t1 - t0) + nm))
             if not last:                                   # G[:, t0:t1] is now the pre-activation gradient of conv(4-k_)
                 i = 3 - k_
                 if Gs is not None and use_x3[k_] != 2:

@@ -44,19 +44,26 @@ __device__ __forceinline__ unsigned irr_xcd_order(unsigned lin, unsigned total) 
 // without the asynchronous weight-gradient lane -- where the caching allocator recycles blocks inside the capture, so the zero-filled
 // buffer is usually memory that an earlier kernel of the same graph has just read -- drifted by ~1e-2 over ten replays with the
 // memset in the warp backward and is exact with this kernel in its place.  (IRR_ZERO_MEMSET=1: hipMemsetAsync again, A/B.)
-__global__ __launch_bounds__(256) static void irr_zero_kernel(uint32_t* __restrict__ p, size_t n16, size_t nbytes) {
+__global__ __launch_bounds__(256) static void irr_zero_kernel(unsigned char* __restrict__ p, size_t head, size_t n16, size_t nbytes) {
+  // [p, p + head): bytes before the first 16-B boundary; then n16 aligned 16-B units; then the tail -- any alignment, any size
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-  if (i < n16) ((u4*)p)[i] = u4{0u, 0u, 0u, 0u};
-  if (i == 0)
-    for (size_t k = n16 * 16; k < nbytes; ++k) ((unsigned char*)p)[k] = 0;
+  if (i < n16) ((u4*)(p + head))[i] = u4{0u, 0u, 0u, 0u};
+  if (i == 0) {
+    for (size_t k = 0; k < head; ++k) p[k] = 0;
+    for (size_t k = head + n16 * 16; k < nbytes; ++k) p[k] = 0;
+  }
 }
 
 static inline hipError_t irr_zero_async(void* ptr, size_t nbytes, hipStream_t st) {
   if (nbytes == 0) return hipSuccess;
-  if (IRR_ENV_FLAG("IRR_ZERO_MEMSET") || ((uintptr_t)ptr & 15)) return hipMemsetAsync(ptr, 0, nbytes, st);
-  const size_t n16 = nbytes / 16;
+  if (IRR_ENV_FLAG("IRR_ZERO_MEMSET")) return hipMemsetAsync(ptr, 0, nbytes, st);
+  // (round 5: an unaligned pointer used to fall back to hipMemsetAsync -- the memset node this kernel exists to avoid; the head and
+  // the tail are scalar stores of thread 0 now)
+  size_t head = (16 - ((uintptr_t)ptr & 15)) & 15;
+  if (head > nbytes) head = nbytes;
+  const size_t n16 = (nbytes - head) / 16;
   const size_t blocks = n16 ? (n16 + 255) / 256 : 1;
-  hipLaunchKernelGGL(irr_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)ptr, n16, nbytes);
+  hipLaunchKernelGGL(irr_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned char*)ptr, head, n16, nbytes);
   return hipGetLastError();
 }

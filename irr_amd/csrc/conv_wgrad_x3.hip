@@ -280,11 +280,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
         const float v0 = mraw[r];
         uint32_t hp, mp, lp = 0;
         if (H2) {
-          const float a0 = v0 * sx;
-          const _Float16 hh = (_Float16)a0;
-          const _Float16 ll = (_Float16)(a0 - (float)hh);
-          hp = __builtin_bit_cast(unsigned short, hh);
-          mp = __builtin_bit_cast(unsigned short, ll);
+          split1_h2<true>(v0, sx, hp, mp);
         } else {
           hp = pk_bf16(v0, 0.f);
           float r0 = v0 - lo_f(hp);
@@ -315,7 +311,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
 #if WX3_ABL == 1
         h = __builtin_bit_cast(u32x4, xraw[r][0]); m = __builtin_bit_cast(u32x4, xraw[r][1]); l = h; (void)v;
 #else
-        if (H2) split8_h2(v, sx, h, m);
+        if (H2) split8_h2<true>(v, sx, h, m);      // x role: low piece x 2^11 (x3_split.h, "Range")
         else split8(v, h, m, l);
 #endif
         const int slot = (row0 + RU_RR(xu[r]) + RING) % RING;      // rows >= -1
@@ -391,9 +387,11 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
         rb[sel] = xs[xi + MG];
       }
     };
+    u32x4 afdn;                                            // H2: af[0] * 2^-11
     auto read_a = [&](int ki) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) read_a1(ki, p);
+      if (H2) afdn = h2_hi_down(af[0]);
     };
     read_a(0);
     read_b(0, 0);
@@ -432,9 +430,11 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
       for (int pa = NP - 1; pa >= 0; --pa) {
         if (pa + q > (WX3_ABL == 20 ? 1 : NP - 1)) continue;      // (ablation 20, timing only: three products of two pieces)
         if constexpr (H2) {
-          acc[dy * 3 + 0] = mma_h(af[pa], fm, acc[dy * 3 + 0]);
-          acc[dy * 3 + 1] = mma_h(af[pa], o, acc[dy * 3 + 1]);
-          acc[dy * 3 + 2] = mma_h(af[pa], fp, acc[dy * 3 + 2]);
+          // (q == 1: the x fragments are the scaled-up low pieces -- their partner is the gy high piece times 2^-11)
+          const u32x4 ap = q == 1 ? afdn : af[pa];
+          acc[dy * 3 + 0] = mma_h(ap, fm, acc[dy * 3 + 0]);
+          acc[dy * 3 + 1] = mma_h(ap, o, acc[dy * 3 + 1]);
+          acc[dy * 3 + 2] = mma_h(ap, fp, acc[dy * 3 + 2]);
         } else {
           acc[dy * 3 + 0] = mma(af[pa], fm, acc[dy * 3 + 0]);
           acc[dy * 3 + 1] = mma(af[pa], o, acc[dy * 3 + 1]);
@@ -856,6 +856,24 @@ extern "C" int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* g
   return wgrad_x3_dil_impl(x, gy, gw, ws, gbias, alpha, B, Cin, H, W, Cout, dil, x_bs, gy_bs, nullptr, 0, nullptr, 0, stream);
 }
 
+// which operand runs in the kernel's x role: the launches of wgrad_x3_impl exchange the roles for some channel counts (see there)
+static bool wx3_roles_exchanged(int Cin, int Cout) {
+  const int cot = (Cout + 31) / 32, cit = (Cin + 31) / 32;
+  const bool ksplit = cot == 1 && Cin <= 32;
+  const bool k4 = (cot == 1 && Cin > 32 && Cin <= 64) || (cot == 2 && Cin <= 32);
+  const bool sw4 = !IRR_ENV_FLAG("IRR_WX3_NO_SW4") && !ksplit && !k4 &&
+                   ((cot == 3 && cit >= 4) || (cot == 1 && (cit + 7) / 8 * 8 * 5 >= (cit + 3) / 4 * 4 * 6));
+  return (cot == 1 && !ksplit) || sw4;
+}
+
+// 1: x, 0: gy is the operand whose fp16x2 pair carries the scaled-up low piece (2^28 : 1 of its tensor's range at full
+// precision, x3_split.h "Range") in irr_conv2d_wgrad_h2 for this problem -- the kernel's x role; the other operand keeps the plain
+// pair (2^17 : 1, absolute 2^-25 of the tensor's scale below).  Dilated launches never exchange the roles.
+extern "C" int irr_conv2d_wgrad_h2_robust_side(int B, int Cin, int H, int W, int Cout, int dil) {
+  (void)B; (void)H; (void)W;
+  return (dil > 1 || !wx3_roles_exchanged(Cin, Cout)) ? 1 : 0;
+}
+
 static int wgrad_x3_impl(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
                          int Cin, int H, int W, int Cout, long x_bs, long gy_bs, const float* x_amax, int nx,
                          const float* g_amax, int ng, void* stream) {
@@ -878,6 +896,7 @@ static int wgrad_x3_impl(const float* x, const float* gy, float* gw, float* ws, 
   const bool sw4 = !IRR_ENV_FLAG("IRR_WX3_NO_SW4") && !ksplit && !k4 &&
                    ((cot == 3 && cit >= 4) || (cot == 1 && (cit + 7) / 8 * 8 * 5 >= (cit + 3) / 4 * 4 * 6));   // (the eight-wave column pads >= 1.2 x as much)
   const bool swapped = (cot == 1 && !ksplit) || sw4;
+  if (swapped != wx3_roles_exchanged(Cin, Cout)) return IRR_EINVAL;          // (one rule, stated twice: keep them together)
   WX3Args a;
   a.ws = ws; a.gbias = swapped ? nullptr : gbias; a.xbias = swapped ? gbias : nullptr; a.alpha = alpha;
   a.H = H; a.W = W;

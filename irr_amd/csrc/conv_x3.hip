@@ -233,7 +233,7 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       u32x4 h, m, l;
-      if (NP == 2) split8_h2(raw[r], sx, h, m);
+      if (NP == 2) split8_h2<true>(raw[r], sx, h, m);     // low piece x 2^11 (x3_split.h, "Range")
       else split8(raw[r], h, m, l);
       if (swidx[r] >= 0) {
         lds[swidx[r]] = h;
@@ -255,6 +255,8 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
         }
         __builtin_amdgcn_sched_barrier(0);
         const int toff = (tap / 3) * LW * dy + (tap % 3) * d;
+        u32x4 wdn;                                          // NP == 2: this tap's high weight piece times 2^-11 (pairs with the scaled-up low piece of x)
+        if (NP == 2) wdn = h2_hi_down(wa[slot][0]);
         u32x4 xb[2][NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) xb[0][p] = lds[xidx[0] + toff + 2 * p * PLANE_PIX];
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
           f32x16 t = acc[s];
           if constexpr (NP == 2) {
             t = mma_h(wa[slot][1], xb[cur][0], t);    // lo * hi
-            t = mma_h(wa[slot][0], xb[cur][1], t);    // hi * lo
+            t = mma_h(wdn, xb[cur][1], t);            // (hi * 2^-11) * (lo * 2^11)
             t = mma_h(wa[slot][0], xb[cur][0], t);    // hi * hi
           } else {
             if (X3_ABL != 20) {                       // ablation 20 (timing only): three products of two pieces
@@ -456,12 +458,13 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
   // residual, accumulate, mask, store) of tile n while the MFMA waves are already on tile n+1.
   // (the packed weights interleave the co-tiles of a layer: this launch keeps co-tile a.wcot of a.wCoT)
   for (int u = tid; u < WUNITS; u += 512) wl[u] = a.wq[((long)(u >> 6) * a.wCoT + a.wcot) * 64 + (u & 63)];
-  float sx = 1.f, unscale = 1.f;                           // h2: operand scale of x, and the factor that undoes both scales
+  float sx = 1.f, inv_x = 1.f, inv_w = 1.f;                // h2: operand scale of x, and the two factors that undo both scales
   if (NP == 2) {
     const int ex = x3_h2_exp(x3_h2_amax(a.x_amax, a.n_amax));
     const int ew = ((const int*)(a.wq + (long)18 * NP * a.wCoT * 64))[0];
     sx = ldexpf(1.f, ex);
-    unscale = ldexpf(1.f, -ex - ew);                       // (|ex|, |ew| <= 96: the product of the two factors is a normal number)
+    inv_x = ldexpf(1.f, -ex);                              // (applied one after the other, as in conv_x3_kernel: |ex + ew| can reach 192,
+    inv_w = ldexpf(1.f, -ew);                              //  beyond the fp32 exponent range -- ONE factor 2^-(ex+ew) flushed to zero for tiny tensors)
   }
   __syncthreads();
 
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = raw[c][e][px];
         u32x4 h, m, l;
-        if (NP == 2) split8_h2(v, sx, h, m);
+        if (NP == 2) split8_h2<true>(v, sx, h, m);
         else split8(v, h, m, l);
         if (su_act && lx >= 0 && lx < LW) {
           buf[lx] = h;
@@ -688,10 +691,11 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
         if (tap + 1 < 9) read_step(cur ^ 1, tap + 1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NP == 2) {
+          const u32x4 wdn = h2_hi_down(wa[cur][0]);         // (the MFMA waves have slack: four v_pk_mul_f16 per tap)
           acc0 = mma_h(wa[cur][1], xb[cur][0][0], acc0);    // lo * hi
           acc1 = mma_h(wa[cur][1], xb[cur][1][0], acc1);
-          acc0 = mma_h(wa[cur][0], xb[cur][0][1], acc0);    // hi * lo
-          acc1 = mma_h(wa[cur][0], xb[cur][1][1], acc1);
+          acc0 = mma_h(wdn, xb[cur][0][1], acc0);           // (hi * 2^-11) * (lo * 2^11)
+          acc1 = mma_h(wdn, xb[cur][1][1], acc1);
           acc0 = mma_h(wa[cur][0], xb[cur][0][0], acc0);    // hi * hi
           acc1 = mma_h(wa[cur][0], xb[cur][1][0], acc1);
         } else {
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int co = (r & 3) + 8 * (r >> 2) + 4 * g;
         float v = s ? acc1[r] : acc0[r];
-        if (NP == 2) v *= unscale;                          // back to the operands' own scale (an exact power of two)
+        if (NP == 2) v = (v * inv_x) * inv_w;               // back to the operands' own scale (two exact powers of two)
         ol[co * 256 + (row0 + s) * 32 + j] = v;
       }
   }

@@ -18,6 +18,10 @@ the same machinery ``bench.py``'s own step uses, without any change on the calle
 * the asynchronous weight-gradient lane (``irr_amd.conv.WgradSide``) accumulating straight into those slices; the lane joins
   the caller's stream by itself at the end of every backward pass (final callback of the autograd engine), so
   ``optimizer.step()`` -- any ``torch.optim`` optimizer -- reads complete gradients;
+  Gradients cleared BETWEEN forward and backward (``out = model(x); opt.zero_grad(); loss.backward()``) are re-attached at that
+  join (``GradArena.readopt_routed``); a backward pass that raised is cleaned up at the next forward pass (``WgradSide.abandon``).
+  Not supported on this route: ``torch.autograd.grad(loss, parameters)`` -- the routed gradients bypass autograd and come back as
+  None; use ``IRR_AUTO_LANE=0`` (or ``harness.set_enabled(False)``) for that.
 * weight-pack caches that notice in-place parameter updates through the tensors' version counters and refresh all packed
   copies with ONE launch (``irr_amd.conv._announce_rewrite``).
 
@@ -113,8 +117,14 @@ def auto_install(model: torch.nn.Module) -> None:
             return
         arena.enable_async_wgrad()             # (installs the lane as conv.SIDE)
         arena._side_lane.auto = True
+        arena._side_lane.on_join = arena.readopt_routed       # gradients cleared between forward and backward (module docstring)
         weakref.finalize(model, _drop_lane, arena._side_lane)
     elif _conv.SIDE is not arena._side_lane:
         _conv.SIDE = arena._side_lane
     if not capturing:
+        lane = arena._side_lane
+        if lane is not None and lane.stale():
+            # the previous backward pass raised (OOM, an assertion in a hook): autograd skipped its final callbacks, so the lane
+            # was never joined and still holds launches / fold jobs of the failed pass
+            lane.abandon()
         arena.adopt_grads()

@@ -11,12 +11,36 @@ the GPU pipeline between forward and backward)
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
 
 from . import conv as _conv
+
+
+_GRAD_FINITE_LOG = bool(os.environ.get("IRR_GRAD_FINITE_LOG"))
+_GRAD_STEP = [0]
+
+
+def _grad_finite_report(module) -> None:
+    """IRR_GRAD_FINITE_LOG=1 (diagnosis switch): after backward + gradient sync, list the parameters whose gradient holds a non-finite
+    value (one device-side reduction per parameter, one host read per step) -- the first step that prints names the layer in which a
+    NaN / inf entered the optimisation step."""
+    import sys
+    named = [(n, p) for n, p in module.named_parameters() if p.grad is not None]
+    flags = torch.stack([torch.isfinite(p.grad).all() for _, p in named])
+    amax = torch.stack([p.grad.abs().max() for _, p in named])
+    _GRAD_STEP[0] += 1
+    if not bool(flags.all()):
+        bad = [(n, float(a)) for (n, _), f, a in zip(named, flags.tolist(), amax.tolist()) if not f]
+        good = [n for (n, _), f in zip(named, flags.tolist()) if f]
+        print(f"[grad log] step {_GRAD_STEP[0]}: {len(bad)} of {len(named)} gradients non-finite; FINITE: " + ", ".join(good[:40]),
+              file=sys.stderr, flush=True)
+    elif os.environ.get("IRR_GRAD_FINITE_LOG") == "2":
+        top = sorted(((float(a), n) for (n, _), a in zip(named, amax.tolist())), reverse=True)[:3]
+        print(f"[grad log] step {_GRAD_STEP[0]}: all finite, largest |g| {top}", file=sys.stderr, flush=True)
 
 
 class ModelAndLoss(nn.Module):
@@ -93,6 +117,8 @@ class TrainStep:
             # weight gradients routed past autograd (enable_async_wgrad / enable_direct_wgrad) are complete only after the lane's
             # deferred folds have run and the lane is joined: without a grad_sync (= GradArena.sync) that happens here
             _conv.SIDE.join()
+        if _GRAD_FINITE_LOG:                      # diagnosis (profiles/NOTES.md C.5): which parameter's gradient is the first non-finite one
+            _grad_finite_report(self.model_and_loss)
         if copied is not None:                    # the value left the device long ago: this wait does not stall the pipeline
             copied.synchronize()
             if math.isnan(float(self._loss_host)) and _conv._CHECK_FINITE in ("async", "slots"):

@@ -232,3 +232,104 @@ def test_streaming_kernel_on_h2_is_fp32_faithful(case, rng, h2_everywhere):
         if i == 4 and not C.LAUNCHES["dgrad_x3s"]:
             continue
         assert err["h2"][i] <= max(4 * err["f32"][i], 2e-6) and err["h2"][i] <= 5e-6, (what, err)
+
+
+# ---- regional dynamic range: an error confined to a QUIET part of a tensor is invisible to max|err| / max|ref|
+# over the whole output, so these cases look at the quiet part alone, relative to ITS OWN range ---------------------------------
+RATIOS = [1e-5, 1e-6, 1e-7]
+
+
+def _quiet(t, region, ratio, dil):
+    """scale half of t (B, C, H, W) by ``ratio``; returns (t, index of the quiet part of a same-shaped-in-(B, H, W) result that no
+    loud operand element reaches through a 3x3 dilation-``dil`` window)"""
+    t = t.clone()
+    B, _, H, W = t.shape
+    if region == "samples":
+        t[B // 2:] *= ratio
+        return t, (slice(B // 2, B), slice(None), slice(None), slice(None))
+    t[:, :, H // 2:] *= ratio
+    return t, (slice(None), slice(None), slice(H // 2 + dil, H), slice(None))
+
+
+@pytest.mark.parametrize("ratio", RATIOS)
+@pytest.mark.parametrize("region", ["samples", "rows"])
+@pytest.mark.parametrize("case", H2_CASES, ids=[f"{c[0]}to{c[1]}d{c[2]}_{c[4]}x{c[5]}" for c in H2_CASES])
+def test_h2_quiet_regions_keep_fp32_accuracy(case, region, ratio, h2_everywhere):
+    """Half the samples / half the image rows of the activation-side operand are 1e-5 ... 1e-7 of the rest: the forward result and
+    the data gradient OF THE QUIET HALF, relative to the quiet half's own max |ref|, stay within 4x the fp32-MFMA kernels' error
+    (the plain fp16 pair of round 4 was 2x / 18x / 140x worse there; the scaled-up low piece of x3_split.h carries 2^29 : 1)."""
+    from irr_amd import conv as C
+    cin, cout, dil, B, H, W = case
+    B = max(B, 2)
+    x, w, gy = _operands((cin, cout, dil, B, H, W), "unit")
+    xq, qi = _quiet(x, region, ratio, dil)
+    gq, _ = _quiet(gy, region, ratio, dil)
+    ref = F.conv2d(xq.double(), w.double(), None, padding=dil, dilation=dil)[qi]
+    gref = torch.nn.grad.conv2d_input(x.shape, w.double(), gq.double(), padding=dil, dilation=dil)[qi]
+    assert ref.numel() > 0 and ref.abs().max() < 1e-3 * F.conv2d(xq.double(), w.double(), None, padding=dil, dilation=dil).abs().max()
+    err = {}
+    for m in ("f32", "h2"):
+        C.set_math(m)
+        xc, wc, gc = xq.cuda(), w.cuda(), gq.cuda()
+        y = C.conv_forward(xc, wc, None, 1, dil, False)
+        gx = C.conv_dgrad(gc, wc, 1, dil, (H, W))
+        err[m] = (_rel(y[qi], ref), _rel(gx[qi], gref))
+    assert C.LAUNCHES["fwd_h2"] == 1, dict(C.LAUNCHES)
+    for i, what in enumerate(("forward", "data gradient")):
+        if i == 1 and not C.LAUNCHES["dgrad_h2"]:
+            continue
+        assert err["h2"][i] <= max(4 * err["f32"][i], 1e-6), (what, region, ratio, err)
+
+
+@pytest.mark.parametrize("ratio", RATIOS)
+@pytest.mark.parametrize("case", S_CASES, ids=[f"{c[0]}to{c[1]}_{c[3]}x{c[4]}" for c in S_CASES])
+def test_streaming_kernel_quiet_regions_keep_fp32_accuracy(case, ratio, h2_everywhere):
+    """the same for conv_x3s_kernel<EPI, 2> (quiet image rows)"""
+    from irr_amd import conv as C
+    cin, cout, B, H, W = case
+    x, w, _ = _operands((cin, cout, 1, B, H, W), "unit")
+    xq, qi = _quiet(x, "rows", ratio, 1)
+    ref = F.conv2d(xq.double(), w.double(), None, padding=1)[qi]
+    err = {}
+    for m in ("f32", "h2"):
+        C.set_math(m)
+        y = C.conv_forward(xq.cuda(), w.cuda(), None, 1, 1, False)
+        err[m] = _rel(y[qi], ref)
+    assert C.LAUNCHES["fwd_x3s"] == 1, dict(C.LAUNCHES)
+    assert err["h2"] <= max(4 * err["f32"], 1e-6), (ratio, err)
+
+
+@pytest.mark.parametrize("ratio", RATIOS)
+@pytest.mark.parametrize("side", ["x_channels", "gy_channels"])
+@pytest.mark.parametrize("case", H2_CASES[:7] + H2_CASES[9:], ids=[f"{c[0]}to{c[1]}d{c[2]}_{c[4]}x{c[5]}" for c in H2_CASES[:7] + H2_CASES[9:]])
+def test_h2_weight_gradient_of_quiet_channels(case, side, ratio, h2_everywhere):
+    """For the weight gradient the sample / pixel axes are the SUMMATION axis (a quiet sample is as invisible in the fp32 sum as in
+    ours); what has its own output region is a quiet CHANNEL: half the input channels of x (columns of dW) or half the channels of
+    gy (rows of dW) scaled by 1e-5 ... 1e-7.  The operand in the kernel's x role carries the scaled-up low piece (2^28 : 1), the one
+    in its gy role the plain pair (2^17 : 1 at full precision, absolute 2^-25 of the tensor's scale below): the x-role side must
+    stay within 4x of the fp32-MFMA kernel at every ratio, the gy-role side within 4x down to 1e-5 and within the documented
+    absolute bound (2^-24 of the tensor maximum per element: 40x fp32 at 1e-6, 400x at 1e-7) below."""
+    from irr_amd import conv as C, hip
+    cin, cout, dil, B, H, W = case
+    x, w, gy = _operands(case, "unit")
+    if side == "x_channels":
+        x[:, cin // 2:] *= ratio
+        qi = (slice(None), slice(cin // 2, cin))
+    else:
+        gy[:, cout // 2:] *= ratio
+        qi = (slice(cout // 2, cout), slice(None))
+    wref = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), padding=dil, dilation=dil)[qi]
+    err = {}
+    for m in ("f32", "h2"):
+        C.set_math(m)
+        xc, gc = x.cuda(), gy.cuda()
+        xa, ga = (C.amax_measure(xc), C.amax_measure(gc)) if m == "h2" else (None, None)
+        gw = C.conv_wgrad(xc, gc, w.shape, 1, dil, x_amax=xa, gy_amax=ga)
+        err[m] = _rel(gw[qi], wref)
+    if not C.LAUNCHES["wgrad_h2"]:
+        pytest.skip("this shape's weight gradient does not run on the fp16x2 kernel")
+    robust = bool(hip.lib().irr_conv2d_wgrad_h2_robust_side(B, cin, H, W, cout, dil)) == (side == "x_channels")
+    if robust or ratio >= 1e-5:
+        assert err["h2"] <= max(4 * err["f32"], 1e-6), (side, ratio, err)
+    else:
+        assert err["h2"] <= max(4 * err["f32"], 2.0 ** -24 / ratio * 8), (side, ratio, err)

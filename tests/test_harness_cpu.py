@@ -96,3 +96,53 @@ def test_kernel_timer_samples_steps():
     t.begin_step(False)
     t.wrap(1, 1.0, lambda: calls.append("a"))    # inactive step: the launch runs, no events are created (no GPU needed)
     assert calls == ["a"] and t.records == [] and t.steps == 0
+
+
+def test_gradients_cleared_between_forward_and_backward_are_reattached():
+    """``out = model(x); opt.zero_grad(); loss.backward(); opt.step()`` -- torch's zero_grad sets ``.grad`` to None
+    AFTER the forward pass adopted the arena views; the lane still accumulates into the arena slices and hands autograd None, so
+    without the end-of-backward re-adoption a stock optimizer would skip the parameter.  Host logic only (inline lane, CPU tensors)."""
+    from irr_amd import conv as C, ddp
+    m = _toy()
+    arena = ddp.GradArena(m.named_parameters())
+    lane = C.WgradSide([(p, p.grad) for _, p in arena.order], inline=True)
+    lane.batch = None
+    lane.on_join = arena.readopt_routed
+    w, b = m[0].weight, m[0].bias
+    w2 = m[1].weight
+    for p in m.parameters():                     # the caller's zero_grad() after the forward pass
+        p.grad = None
+    gw, gb = lane.route(w, b)
+
+    def fake_wgrad():                            # what a routed weight-gradient launch does: accumulate into the arena slices
+        gw.add_(2.0)
+        gb.add_(3.0)
+    lane.launch(fake_wgrad, (), (w, b), gw=None)
+    w2.grad = torch.full_like(w2, 5.0)           # a gradient autograd delivered itself (a contribution that did not take the lane)
+    g2, _ = lane.route(w2, None)
+    lane.launch(lambda: g2.add_(1.0), (), (w2, None), gw=None)
+    assert w.grad is None
+    lane.join()
+    assert w.grad is not None and arena._inside(w.grad) and float(w.grad.min()) == 2.0 and float(b.grad.min()) == 3.0
+    assert arena._inside(w2.grad) and float(w2.grad.min()) == 6.0          # routed 1.0 + foreign 5.0, now one arena view
+    assert m[1].bias.grad is None                # never routed in this pass: left alone
+    lane.join()                                  # nothing routed since: a no-op
+    assert float(w.grad.min()) == 2.0
+
+
+def test_lane_is_cleaned_up_after_a_backward_pass_that_raised():
+    """autograd skips its final callbacks when backward raises, so ``_join_queued`` stayed True for ever (no later
+    pass queued its join) and the failed pass's queued launches / fold jobs leaked into the next step.  ``stale()`` / ``abandon()``
+    are what irr_amd.harness calls at the start of the next training forward pass."""
+    from irr_amd import conv as C, ddp
+    m = _toy()
+    arena = ddp.GradArena(m.named_parameters())
+    lane = C.WgradSide([(p, p.grad) for _, p in arena.order], inline=True)
+    lane.batch = None
+    assert not lane.stale()
+    lane._join_queued = True                     # a backward pass queued its join, then raised before the callback ran
+    lane._pending.append((m[0].weight, None))
+    lane._queued.append((lambda: None, (), (m[0].weight, None), 0))
+    assert lane.stale()
+    lane.abandon()
+    assert not lane.stale() and lane._queued == [] and lane._pending == [] and not lane._join_queued

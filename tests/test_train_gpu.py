@@ -147,6 +147,83 @@ def test_reference_training_loop_drops_in(golden_dir):
     assert C.SIDE is None
 
 
+def test_zero_grad_after_forward_and_failed_backward_under_the_auto_lane(golden_dir):
+    """ADVICE r4.  (1) A foreign loop that clears the gradients AFTER the forward pass -- ``out = model(x); opt.zero_grad();
+    loss.backward(); opt.step()`` -- must train exactly like the reference's ordering (zero_grad first): same three-step check
+    against the imported reference.  (2) A backward pass that raises leaves the lane un-joined; the next step must start clean
+    (no stale launches folded into the new step, later passes still join): its result equals a fresh model's."""
+    import irr_amd
+    from irr_amd import conv as C, harness
+    from irr_amd.train import ModelAndLoss
+    from oracle import irr_pwc_oracle as O
+    from train3_check import problems
+    g = np.load(os.path.join(golden_dir, "train3_B2_128x192.npz"))
+    assert C.SIDE is None, "a previous test left its lane installed"
+
+    def build():
+        m = irr_amd.PWCNet(_args(2), mask_threshold=0.9999)
+        m.load_state_dict(O.synthetic_params(0), strict=True)
+        m = m.cuda().train()
+        mal = ModelAndLoss(_args(2), m, irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(_args(2))).train()
+        return m, mal, torch.optim.Adam(mal.parameters(), lr=1e-4, weight_decay=4e-4)
+
+    m, mal, optimizer = build()
+    try:
+        def step(example_dict):
+            for key, t in example_dict.items():
+                t.requires_grad_("input" in key)
+            loss_dict, output_dict = mal(example_dict)
+            optimizer.zero_grad()                                  # AFTER the forward pass: .grad = None on every parameter
+            loss_dict["total_loss"].backward()
+            assert all(p.grad is not None for p in m.parameters())
+            optimizer.step()
+            return loss_dict, output_dict, 2
+        bad = problems(g, *_three_steps(step, m, g))
+        assert bad == [], bad
+        assert harness.installed(m)
+    finally:
+        harness.uninstall(m)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g_):
+            raise RuntimeError("boom")
+
+    finals = []
+    for fail_first in (False, True):
+        m, mal, optimizer = build()
+        try:
+            b0 = _batch(2, 128, 192, 1234)
+            if fail_first:
+                optimizer.zero_grad()
+                # the raising node sits on the image side: the whole decoder backward (lane launches) runs before it
+                x1 = b0["input1"].clone().requires_grad_(True)
+                ld2, _ = mal({**b0, "input1": Boom.apply(x1)})
+                with pytest.raises(RuntimeError, match="boom"):
+                    ld2["total_loss"].backward()
+                assert C.SIDE is not None and C.SIDE.stale()
+            grads = []
+            for seed in (1234, 99):                                # two clean passes: the second proves later passes still join
+                optimizer.zero_grad()
+                ld, _ = mal(_batch(2, 128, 192, seed))
+                assert not C.SIDE.stale()
+                ld["total_loss"].backward()
+                torch.cuda.synchronize()
+                grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters()})
+            finals.append(grads)
+        finally:
+            harness.uninstall(m)
+    for k in range(2):
+        for n in finals[0][k]:
+            a, b = finals[0][k][n], finals[1][k][n]
+            assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12, (k, n)     # (a stale fold would double a gradient)
+    assert C.SIDE is None
+
+
 def test_fused_adam_is_an_optimizer_with_lr_schedule():
     """FusedAdam under the reference's scheduler (configuration.py:579-608 builds torch.optim.lr_scheduler.MultiStepLR on the
     optimizer; scripts/IRR-PWC_flyingChairsOcc.sh:24-26: milestones [54, 72, 90], gamma 0.5): three steps with a milestone after
