@@ -302,7 +302,7 @@ def main():
     def run(make_step, batch_pairs, height, width, steps, warmup, timed_kernels):
         """W untimed + exactly K timed train steps of one workload -> dict(dt, value, loss, routing, roofline)"""
         step = make_step(batch_pairs)
-        batches = [synthetic_batch(batch_pairs, height, width, 1234 + rank + 1000 * i, device) for i in range(NBATCHES)]
+        batches = [synthetic_batch(batch_pairs, height, width, 1234 + rank + int(os.environ.get("IRR_BENCH_SEED_OFFSET", "0")) + 1000 * i, device) for i in range(NBATCHES)]   # (offset: diagnosis switch -- another rank's batches in a single process)
         marks = [] if os.environ.get("IRR_BENCH_STEPTIMES") else None      # diagnostic: per-step GPU time (events, no extra syncs)
 
         def mark():

@@ -325,20 +325,24 @@ int irr_conv2d_smallci_wgrad_f32(const float* x, const float* gy, float* gw, flo
  * replaces the MFMA launch with K = 9*Cout of irr_conv2d_fwd_f32 (transposed pack) for these layers. */
 int irr_conv2d_smallco_dgrad_f32(const float* gy, const float* w, float* gx, const float* mask,
                                  int B, int Cin, int H, int W, int Cout, int dil,
-                                 long gy_bs, long gx_bs, long mask_bs, int nmask, int accumulate, void* stream);
+                                 long gy_bs, long gx_bs, long mask_bs, int nmask, int accumulate,
+                                 float* amax, int amax_channels, void* stream);
+/* (ABI 7) amax (nullable): *amax = max(*amax, max |gx[:, :amax_channels]| as stored) -- the amax slot of the fp16x2 launches that
+ * consume those channels (the DenseNet backward's first gradient slice), folded in the same pass. */
 /* Both forms of the same data gradient from one pass (Cout = 1, dilation 1, W % 4 == 0, batch strides multiples of 4; IRR_EINVAL
  * otherwise): gx_raw = conv_transpose(gy, w) and gx = gx_raw * LeakyReLU'(mask) over all Cin channels.  OccUpsampleNetwork's backward
  * (models/irr_modules.py:54-55: x = x_init + res_end_conv(x); out_convs(x)) needs the gradient of that sum raw (skip) and masked. */
 int irr_conv2d_smallco_dgrad_dual_f32(const float* gy, const float* w, float* gx, float* gx_raw, const float* mask,
                                       int B, int Cin, int H, int W, int Cout,
-                                      long gy_bs, long gx_bs, long raw_bs, long mask_bs, void* stream);
+                                      long gy_bs, long gx_bs, long raw_bs, long mask_bs, float* amax, void* stream);
+/* (ABI 7) amax (nullable): *amax = max(*amax, max |gx|) (the masked form). */
 
 
 /* gpre = gy * (y>0 ? 1 : 0.1) (if lrelu) ; gbias[co] += sum gpre (gbias nullable, accumulated).
- * gpre may alias gy. */
+ * gpre may alias gy.  amax (nullable, ABI 7): *amax = max(*amax, max |gpre|) -- the amax slot of the fp16x2 launches that read gpre. */
 int irr_lrelu_bwd_bias_f32(const float* gy, const float* y, float* gpre, float* gbias,
                            int B, int C, int HW, long gy_bs, long y_bs, long gpre_bs,
-                           int lrelu, void* stream);
+                           int lrelu, float* amax, void* stream);
 
 /* strided data-gradient for the stride-2 pyramid convs (gather form):
  * gx[b,ci,iy,ix] = sum_{co,tap : iy = oy*stride + (ty-pad)*dil ...} w[co][ci][tap] * gy[b,co,oy,ox] */
@@ -434,6 +438,12 @@ typedef struct IrrCatPart {
   int reserved;
 } IrrCatPart;
 int irr_cat_channels_f32(float* dst, long dst_bs, const void* parts, int nparts, int B, long hw, void* stream);
+/* the same + *amax = max(*amax, max |value written|): the consumer's fp16x2 input magnitude without a pass over the buffer (ABI 7) */
+/* out[b, 0:n) = x[b, 0:n) + y[b, 0:n) for B samples of n contiguous floats with independent batch strides (elements); out may
+ * alias x or y.  The sum of a channel-slice view and a dense tensor in the backward passes (models/irr_modules.py:55-56 skip,
+ * models/pwc_modules.py:169-170 head) as one coalesced pass instead of ATen's strided-iterator kernel (ABI 7). */
+int irr_add_planes_f32(float* out, const float* x, const float* y, int B, long n, long out_bs, long x_bs, long y_bs, void* stream);
+int irr_cat_channels_amax_f32(float* dst, long dst_bs, const void* parts, int nparts, int B, long hw, float* amax, void* stream);
 
 /* ---- fused Adam over one flat arena ------------------------------------------------------------------
  * torch.optim.Adam semantics (runtime.py:189; lr 1e-4, weight_decay 4e-4 as L2-in-gradient,

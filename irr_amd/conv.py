@@ -127,11 +127,12 @@ def x3_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, di
 
 
 
-# The streaming 32-channel kernel has the fp16x2 form too (conv_x3s_kernel<EPI, 2>, +5.1 % on the step, parity-green), but it is OFF
-# by default: with it, `bench.py --gpus 2` on ONE shared GPU (tests/test_ddp_gpu.py) ended in a NaN loss in 4 of 5 runs -- never in a
-# single process, never with two independent processes, not with the magnitudes measured by separate passes instead of the kernel's
-# epilogue (3 of 3) -- and the cause was not found before the end of round 4 (profiles/NOTES.md C.5).  IRR_X3S_H2=1 / set_x3s_h2(True).
-X3S_H2 = bool(int(os.environ.get("IRR_X3S_H2", "0")))
+# The streaming 32-channel kernel (conv_x3s_kernel<EPI, NP>) in its fp16x2 form: ON by default since round 5 (+5 % on the step).
+# Round 4 shipped it off: with the PLAIN low pieces of that round, `bench.py --gpus 2` on ONE shared GPU ended in a NaN loss in about
+# every second run -- never in a single process.  Round 5 (profiles/NOTES.md C.5, profiles/r5_nan_ab.txt): same box, alternating
+# libraries, the plain-low-piece build 7 of 8 runs NaN, the scaled-low-piece build (x3_split.h "Range") 0 of 31.
+# IRR_X3S_H2=0 / set_x3s_h2(False): the bf16x3 form.
+X3S_H2 = bool(int(os.environ.get("IRR_X3S_H2", "1")))
 _X3S_NO_FUSED_AMAX = bool(os.environ.get("IRR_X3S_NO_FUSED_AMAX"))     # diagnosis switch of NOTES C.5: the streaming kernel's output
                                                                        # magnitude by a separate pass instead of its epilogue
 
@@ -321,12 +322,13 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                gx: Optional[torch.Tensor] = None, accumulate: bool = False,
                mask: Optional[torch.Tensor] = None, nmask: int = 0,
                res: Optional[torch.Tensor] = None, alpha: float = 1.0, real_cin: Optional[int] = None,
-               gy_amax: Optional[Amax] = None, gx_amax: Optional[Amax] = None) -> torch.Tensor:
+               gy_amax: Optional[Amax] = None, gx_amax: Optional[Amax] = None, amax_channels: Optional[int] = None) -> torch.Tensor:
     """gx (+)= conv_transpose(gy, weight); gy must already carry the activation derivative.
     mask/nmask: afterwards gx[:, :nmask] *= LeakyReLU'(mask[:, :nmask]) in the same launch (mask = the saved
     activation that produced this conv's input), i.e. gx comes out as a PRE-activation gradient.
     res/alpha: gx = res + alpha * conv_transpose(...) (residual branches: the skip gradient is added in the epilogue).
-    gy_amax / gx_amax: as x_amax / y_amax of conv_forward (gx_amax bounds the COMPLETE gx: res, accumulate and mask included)."""
+    gy_amax / gx_amax: as x_amax / y_amax of conv_forward (gx_amax bounds the COMPLETE gx: res, accumulate and mask included).
+    amax_channels (Cout <= 2 heads only): gx_amax bounds gx[:, :amax_channels] instead of all of gx."""
     B, cout, oh, ow = gy.shape
     cout_w, cin, k, _ = weight.shape
     assert cout == cout_w
@@ -341,10 +343,11 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         # tiny-Cout heads: a pure HBM stream over the Cin-channel gradient buffer (VALU kernel, csrc/conv_small.hip)
         wc = weight.detach().contiguous()
         LAUNCHES["dgrad_smallco"] += 1
+        # gx_amax here bounds gx[:, :amax_channels] (default: all of gx), folded by the same pass
+        nam = cin if amax_channels is None else int(amax_channels)
         hip.call("irr_conv2d_smallco_dgrad_f32", hip.ptr(gy), hip.ptr(wc), hip.ptr(gx), margs[0], B, cin, H, W, cout, dil,
-                 hip.bs(gy), hip.bs(gx), margs[1], margs[2], int(accumulate), hip.stream())
-        if gx_amax is not None:
-            amax_measure(gx, gx_amax)
+                 hip.bs(gy), hip.bs(gx), margs[1], margs[2], int(accumulate),
+                 gx_amax.ptr() if gx_amax is not None else None, nam if gx_amax is not None else 0, hip.stream())
         return gx
     if stride == 1 and cout == 1:
         # the MFMA kernel consumes input channels in pairs: give the single-channel gradient a zero partner
@@ -469,5 +472,5 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
 SIDE: Optional[WgradSide] = None
 
 # the autograd nodes (import at the end: they use the primitives above and read SIDE / TIMER through this module)
-from .conv_nodes import (CAT_MAX_PARTS, _ConvBlock, _ConvChainFn, _DenseEstimatorFn, _OccUpsampleFn, _planes_dense, cat_channels_into,  # noqa: E402,F401
+from .conv_nodes import (CAT_MAX_PARTS, _ConvBlock, _ConvChainFn, _DenseEstimatorFn, _OccUpsampleFn, _planes_dense, cat_channels, cat_channels_into,  # noqa: E402,F401
                          conv_block, conv_chain, dense_estimator, lrelu_bwd_bias, occ_upsample_net, wgrad_param)

@@ -207,8 +207,16 @@ class WgradSide:
         self._queue_join()
         if self.on_join is not None:
             for p_ in params:
-                if p_ is not None:
+                if p_ is not None and id(p_) not in self._routed:
                     self._routed[id(p_)] = p_
+                    v_ = self._view(p_)
+                    g_ = p_.grad
+                    if v_ is not None and (g_ is None or g_.data_ptr() != v_.data_ptr()):
+                        # first routed contribution of this pass and ``.grad`` is no longer the arena view the forward pass
+                        # adopted: the caller cleared the gradients AFTER forward (and autograd may have delivered a fresh tensor
+                        # since).  What the slice still holds is the PREVIOUS step's gradient -- zero it on the current stream
+                        # (the lane waits for this point before it launches)
+                        v_.zero_()
         if self.batch is not None and gw is not None:
             # a batch folds into each gradient at most once, and holds at most cap jobs: queued launches count
             if (self.batch.full_for(gw) or any(q[3] == gw.data_ptr() for q in self._queued)

@@ -53,12 +53,13 @@ def _dgrad_h2(gy_shape, weight, stride: int, dil: int) -> bool:
 
 
 def lrelu_bwd_bias(gy: torch.Tensor, y: Optional[torch.Tensor], lrelu: bool, gpre: Optional[torch.Tensor],
-                   gbias: Optional[torch.Tensor]) -> None:
-    """gpre = gy * LeakyReLU'(y) (y = the activated output); gbias += sum over (b, h, w) of gpre."""
+                   gbias: Optional[torch.Tensor], amax: Optional[Amax] = None) -> None:
+    """gpre = gy * LeakyReLU'(y) (y = the activated output); gbias += sum over (b, h, w) of gpre; amax: a slot that receives
+    max |gpre| from the same pass."""
     B, C, H, W = gy.shape
     hip.call("irr_lrelu_bwd_bias_f32", hip.ptr(gy), hip.ptr(y) if lrelu else None, hip.ptr(gpre), hip.ptr(gbias),
              B, C, H * W, hip.bs(gy), hip.bs(y) if lrelu else 0, hip.bs(gpre) if gpre is not None else 0,
-             int(lrelu), hip.stream())
+             int(lrelu), amax.ptr() if amax is not None else None, hip.stream())
 
 
 # ----------------------------------------------------------------------------------------------
@@ -101,13 +102,16 @@ class _ConvBlock(hip.Function):
         gb = torch.zeros(cout, device=gy.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         want_w = ctx.needs_input_grad[1]
         bias_in_wgrad = gb is not None and want_w and not lrelu      # no elementwise pass needed at all
+        need_ga = (ctx.x_amax is not None and want_w) or (ctx.needs_input_grad[0] and _dgrad_h2(g.shape, weight, stride, dil))
+        ga = None
         if lrelu or (gb is not None and not bias_in_wgrad):
             gpre = torch.empty_like(g) if lrelu else None
-            lrelu_bwd_bias(g, act, lrelu, gpre, gb)                  # mask and bias gradient in one HBM pass
+            if need_ga:
+                ga = Amax.zeros(g.device, 1)                          # max |pre-activation gradient|: folded by the same pass
+            lrelu_bwd_bias(g, act, lrelu, gpre, gb, amax=ga)          # mask and bias gradient in one HBM pass
             if lrelu:
                 g = gpre
-        ga = None
-        if (ctx.x_amax is not None and want_w) or (ctx.needs_input_grad[0] and _dgrad_h2(g.shape, weight, stride, dil)):
+        if need_ga and ga is None:
             ga = amax_measure(g)
         gx = conv_dgrad(g, ctx.weight_obj, stride, dil, x.shape[2:], gy_amax=ga) if ctx.needs_input_grad[0] else None
         gw = None
@@ -127,10 +131,11 @@ class _CatPart(ctypes.Structure):
 CAT_MAX_PARTS = 8            # IRR_CAT_MAX_PARTS
 
 
-def cat_channels_into(dst: torch.Tensor, parts, zero_tail: int = 0) -> None:
+def cat_channels_into(dst: torch.Tensor, parts, zero_tail: int = 0, amax: Optional[Amax] = None) -> None:
     """dst[:, :sum(channels)] = cat(parts, dim=1) (+ ``zero_tail`` zero channels behind them) in ONE launch
     (irr_cat_channels_f32) -- dst is a channel-slice view of the consumer's buffer.  Parts whose planes are not dense are made
-    contiguous first."""
+    contiguous first.  amax: a slot that receives max |.| of everything written (irr_cat_channels_amax_f32: the copy folds the
+    magnitude the consumer's fp16x2 kernels need -- no separate pass over the buffer)."""
     B, _, H, W = dst.shape
     srcs = [p_ if _planes_dense(p_) else p_.contiguous() for p_ in parts]
     recs = [(hip.ptr(p_), p_.stride(0), int(p_.shape[1])) for p_ in srcs]
@@ -141,8 +146,59 @@ def cat_channels_into(dst: torch.Tensor, parts, zero_tail: int = 0) -> None:
         chunk = recs[i:i + CAT_MAX_PARTS]
         arr = (_CatPart * len(chunk))(*[_CatPart(s_, bs_, ch_, 0) for s_, bs_, ch_ in chunk])
         view = dst[:, c0:]
-        hip.call("irr_cat_channels_f32", hip.ptr(view), dst.stride(0), ctypes.addressof(arr), len(chunk), B, H * W, hip.stream())
+        if amax is not None:
+            hip.call("irr_cat_channels_amax_f32", hip.ptr(view), dst.stride(0), ctypes.addressof(arr), len(chunk), B, H * W, amax.ptr(),
+                     hip.stream())
+        else:
+            hip.call("irr_cat_channels_f32", hip.ptr(view), dst.stride(0), ctypes.addressof(arr), len(chunk), B, H * W, hip.stream())
         c0 += sum(ch_ for _, _, ch_ in chunk)
+
+
+class _CatChannelsFn(hip.Function):
+    """torch.cat(parts, dim=1) as ONE launch that also folds max |.| of what it writes into an amax slot (the input magnitude of the
+    fp16x2 conv chain that consumes the result: RefineFlow / RefineOcc, models/irr_modules.py:97-99, 134); backward hands out the
+    channel slices of the incoming gradient (views, no copies)."""
+
+    @staticmethod
+    def forward(ctx, slot, *parts):
+        B, _, H, W = parts[0].shape
+        widths = [int(p_.shape[1]) for p_ in parts]
+        out = torch.empty(B, sum(widths), H, W, device=parts[0].device, dtype=torch.float32)
+        cat_channels_into(out, parts, amax=slot)
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, c0 = [None], 0
+        for i, wd in enumerate(ctx.widths):
+            outs.append(g[:, c0:c0 + wd] if ctx.needs_input_grad[1 + i] else None)
+            c0 += wd
+        return tuple(outs)
+
+
+def cat_channels(parts, want_amax: bool = False) -> torch.Tensor:
+    """cat(parts, dim=1) on the device in one launch; want_amax: the result carries its magnitude (``_irr_amax``, read by conv_chain)"""
+    parts = tuple(parts)
+    if not all(p_.is_cuda and p_.dtype == torch.float32 for p_ in parts):
+        raise RuntimeError("irr_amd conv runs on the HIP device only (no CPU fallback)")
+    slot = Amax.zeros(parts[0].device, 1) if want_amax else None
+    out = _CatChannelsFn.apply(slot, *parts)
+    if slot is not None:
+        out.__dict__["_irr_amax"] = slot
+    return out
+
+
+def add_planes(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """x + y for two (B, C, H, W) tensors with dense planes, either of which may be a channel-slice view (irr_add_planes_f32: one
+    coalesced pass; ATen runs such a view through its strided-iterator kernel at a fraction of the bandwidth).  No autograd: for
+    the backward passes of the nodes below."""
+    if not (_planes_dense(x) and _planes_dense(y) and x.shape == y.shape):
+        return x + y
+    B, C, H, W = x.shape
+    out = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+    hip.call("irr_add_planes_f32", hip.ptr(out), hip.ptr(x), hip.ptr(y), B, C * H * W, hip.bs(out), hip.bs(x), hip.bs(y), hip.stream())
+    return out
 
 
 def _planes_dense(t: torch.Tensor) -> bool:
@@ -185,13 +241,12 @@ class _DenseEstimatorFn(hip.Function):
         ctot = 448 + cin0
         has_base = base is not None
         buf = torch.empty(B, ctot + (E if has_base else 0), H, W, device=parts[0].device, dtype=torch.float32)
-        cat_channels_into(buf[:, 448:], parts)
         # fp16x2 route: one amax slot per buffer part, in channel order [c5, c4, c3, c2, c1, x]; conv i+1 reads parts 5-i .. 5 and
-        # its launch folds the magnitude of its output into slot 4-i
+        # its launch folds the magnitude of its output into slot 4-i; the input part's comes out of the copy that assembles it
         S = None
         if _fwd_h2(buf[:, 448:ctot], ws[0], 1, 1):
             S = Amax.zeros(buf.device, 7)                        # (slot 6: the est slot behind the parts, when there is one)
-            amax_measure(buf[:, 448:ctot], S.sub(5))
+        cat_channels_into(buf[:, 448:], parts, amax=S.sub(5) if S is not None else None)
         off = 448
         for i in range(5):
             co = _DenseEstimatorFn.GROW[i]
@@ -236,7 +291,7 @@ class _DenseEstimatorFn(hip.Function):
         if g_out is not None:
             g_est = g_out if _planes_dense(g_out) else g_out.contiguous()
         if has_base:
-            g_est = G[:, ctot:] + g_est if g_est is not None else G[:, ctot:].clone()
+            g_est = add_planes(G[:, ctot:], g_est) if g_est is not None else G[:, ctot:].clone()
         grads_w = [None] * 6
         grads_b = [None] * 6
         # conv_last first: its data gradient touches every channel (K is tiny, the launch is memory-bound) and its
@@ -246,21 +301,23 @@ class _DenseEstimatorFn(hip.Function):
         # combined packed weight matrix, accumulates into G[:, T] once and applies LeakyReLU'(buf[:, T]) in the same
         # epilogue.  Versus layer-by-layer accumulation this replaces up to five small-K read-modify-write launches
         # per slice by a single large-K one.  Bias gradients ride on the wgrad launches.
-        if g_est is not None:
-            grads_w[5], grads_b[5] = wgrad_param(buf[:, :ctot], g_est, ctx.wobjs[5], ctx.bobjs[5], 1, 1)
-            conv_dgrad(g_est, ws[5], 1, 1, (H, W), gx=G[:, :ctot], accumulate=True, mask=buf[:, :ctot], nmask=32)
-        else:
-            lrelu_bwd_bias(G[:, :32], buf[:, :32], True, G[:, :32], None)
         use_x3 = [(2 if (h2_code(B, t0, H, W, t1 - t0, 3, 1, 1)) else 1) if x3_code(B, t0, H, W, t1 - t0, 3, 1, 1) else 0
                   for (t0, t1) in ((32, 96), (96, 192), (192, 320), (320, 448), (448, ctot))]
-        packs = _dense_column_packs(ctx.wobjs[:5], cin0, tuple(use_x3))
         # fp16x2 route: one amax slot per slice of G, in channel order [g5, g4, g3, g2, g1, gx]; column k reads slices 0 .. k and
-        # folds the magnitude of the slice it completes into slot k+1
+        # folds the magnitude of the slice it completes into slot k+1; slot 0 (the c5 slice) comes out of conv_last's data gradient
         S = ctx.amax
-        Gs = None
-        if S is not None or any(u == 2 for u in use_x3):
-            Gs = Amax.zeros(dev, 6)
-            amax_measure(G[:, :32], Gs.sub(0))
+        Gs = Amax.zeros(dev, 6) if (S is not None or any(u == 2 for u in use_x3)) else None
+        if g_est is not None:
+            grads_w[5], grads_b[5] = wgrad_param(buf[:, :ctot], g_est, ctx.wobjs[5], ctx.bobjs[5], 1, 1)
+            conv_dgrad(g_est, ws[5], 1, 1, (H, W), gx=G[:, :ctot], accumulate=True, mask=buf[:, :ctot], nmask=32,
+                       gx_amax=Gs.sub(0) if (Gs is not None and ws[5].shape[0] <= 2) else None, amax_channels=32)
+            if Gs is not None and ws[5].shape[0] > 2:
+                amax_measure(G[:, :32], Gs.sub(0))
+        else:
+            lrelu_bwd_bias(G[:, :32], buf[:, :32], True, G[:, :32], None)
+            if Gs is not None:
+                amax_measure(G[:, :32], Gs.sub(0))
+        packs = _dense_column_packs(ctx.wobjs[:5], cin0, tuple(use_x3))
         grads_w[4], grads_b[4] = wgrad_param(buf[:, 32:ctot], G[:, :32], ctx.wobjs[4], ctx.bobjs[4], 1, 1,
                                              x_amax=S.sub(1, 5) if S is not None else None,
                                              gy_amax=Gs.sub(0) if Gs is not None else None)   # conv5
@@ -403,10 +460,6 @@ class _ConvChainFn(hip.Function):
         gres = gy.clone() if (ctx.has_res and ctx.needs_input_grad[1]) else None
         dev = gy.device
         g = gy
-        if cfg[-1][2]:                                        # activation on the chain output: one pass on a small tensor
-            gpre = torch.empty_like(gy)
-            lrelu_bwd_bias(gy, a_last, True, gpre, None)
-            g = gpre
         grads = [None] * (2 * n)
         in_amax = ctx.in_amax
         # layer i wants the magnitude of ITS output gradient when its weight gradient (input slot known) or its data gradient runs on
@@ -420,9 +473,13 @@ class _ConvChainFn(hip.Function):
         need_g = [in_amax[i] is not None or ((i > 0 or ctx.needs_input_grad[0]) and _dgrad_h2(gshape[i], ws[i], cfg[i][0], cfg[i][1]))
                   for i in range(n)]
         gslots = Amax.zeros(dev, n) if any(need_g) else None
-        ga = None
-        if need_g[n - 1]:
-            ga = amax_measure(g, gslots.sub(n - 1))
+        ga = gslots.sub(n - 1) if need_g[n - 1] else None
+        if cfg[-1][2]:                                        # activation on the chain output: one pass on a small tensor,
+            gpre = torch.empty_like(gy)                       # which also folds max |pre-activation gradient| into its slot
+            lrelu_bwd_bias(gy, a_last, True, gpre, None, amax=ga)
+            g = gpre
+        elif ga is not None:
+            amax_measure(g, ga)
         for i in range(n - 1, -1, -1):
             stride, dil, _ = cfg[i]
             inp = acts[i - 1] if i > 0 else x
@@ -484,14 +541,12 @@ class _OccUpsampleFn(hip.Function):
         cin = sum(widths)
         cpad = 16 if (cin < 16 and x3_code(B, 16, H, W, w_init.shape[0], 3, 1, 1)) else cin
         x_in = torch.empty(B, cpad, H, W, device=occ_up.device, dtype=torch.float32)
-        cat_channels_into(x_in, (occ_up,) + tuple(parts[1:]), zero_tail=cpad - cin)
-        w_first = _padded_cin(w_init, cpad) if cpad > cin else w_init
         # fp16x2 route: one amax slot per activation that a 32-channel conv (forward, or its weight gradient) reads -- slot 0: x_in
-        # (measured), 1 + i: x_i, 5 + i: t_(i+1); the launches that produce them fold their maxima in the epilogue
+        # (folded by the copy that assembles it), 1 + i: x_i, 5 + i: t_(i+1); the launches that produce them fold their maxima in the epilogue
         S = Amax.zeros(x_in.device, 8) if h2_code(B, w_r0.shape[1], H, W, w_r0.shape[0], 3, 1, 1) else None
         sl = (lambda i: S.sub(i)) if S is not None else (lambda i: None)
-        if S is not None:
-            amax_measure(x_in, S.sub(0))
+        cat_channels_into(x_in, (occ_up,) + tuple(parts[1:]), zero_tail=cpad - cin, amax=sl(0))
+        w_first = _padded_cin(w_init, cpad) if cpad > cin else w_init
         x_init = conv_forward(x_in, w_first, b_init, 1, 1, True, real_cin=cin, x_amax=sl(0), y_amax=sl(1))
         xs = [x_init]
         ts = []
@@ -555,9 +610,7 @@ class _OccUpsampleFn(hip.Function):
             LAUNCHES["dgrad_smallco"] += 1
             hip.call("irr_conv2d_smallco_dgrad_dual_f32", hip.ptr(gpre_o), hip.ptr(w_out.detach().contiguous()), hip.ptr(gpre_e),
                      hip.ptr(g_x2), hip.ptr(e), B_, w_out.shape[1], H_, W_, 1, hip.bs(gpre_o), hip.bs(gpre_e), hip.bs(g_x2), hip.bs(e),
-                     hip.stream())
-            if G is not None:
-                amax_measure(gpre_e, G.sub(0))
+                     G.sub(0).ptr() if G is not None else None, hip.stream())      # (max |gpre_e| folded by the same pass)
             gw_end, gb_end = wgrad_param_(x3, gpre_e, w_end, b_end, 1, 1, want_bias=True, x_amax=sl(4), gy_amax=gl(0))
         else:
             g_x2 = conv_dgrad(gpre_o, w_out, 1, 1, hw_)                      # (B,32,H,W); also the gradient of x_init via the skip
@@ -610,7 +663,7 @@ class _OccUpsampleFn(hip.Function):
                     gparts[i] = g_xin[:, c0:c0 + wd]
                 c0 += wd
         if ctx.needs_input_grad[2]:                           # occ_up: channel 0 of the input AND the final skip
-            gparts[0] = g_out + gparts[0] if gparts[0] is not None else g_out
+            gparts[0] = add_planes(g_out, gparts[0]) if gparts[0] is not None else g_out
         return (None, None, *gparts, gw_init, gb_init, gw_r0, gb_r0, gw_r1, gb_r1, gw_end, gb_end, gw_out, gb_out)
 
 

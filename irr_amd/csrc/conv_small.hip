@@ -4,6 +4,7 @@
 // observation (v)); here every lane owns one output pixel (coalesced along x), weights are wave-uniform scalar
 // loads, and the 3x3 neighbourhood reads hit L1.  Same epilogue contract as irr_conv2d_fwd_f32.
 #include "common.h"
+#include "amax.h"
 #include <stdlib.h>
 
 namespace {
@@ -491,9 +492,11 @@ template <int NC>
 __global__ __launch_bounds__(256) void conv_smallco_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
                                                                 float* __restrict__ gx, const float* __restrict__ mask, int Cin,
                                                                 int H, int W, int dil, long gy_bs, long gx_bs, long mask_bs,
-                                                                int nmask, int accumulate, int ci_per_block) {
+                                                                int nmask, int accumulate, int ci_per_block,
+                                                                float* __restrict__ amax, int amax_channels) {
   const long hw = (long)H * W;
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float vmax = 0.f;                                          // max |stored value| over channels < amax_channels (amax slot of the fp16x2 consumers)
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * ci_per_block;
   const int c1 = min(Cin, c0 + ci_per_block);
@@ -521,8 +524,10 @@ __global__ __launch_bounds__(256) void conv_smallco_dgrad_kernel(const float* __
     float* dst = gx + (long)b * gx_bs + (long)ci * hw + p;
     if (accumulate) v += *dst;
     if (mask && ci < nmask) v *= irr_lrelu_grad(mask[(long)b * mask_bs + (long)ci * hw + p]);
+    if (ci < amax_channels) vmax = x3_amax_fold(vmax, v);
     *dst = v;
   }
+  if (amax && c0 < amax_channels) x3_amax_publish_block256(vmax, amax);      // (block-uniform condition; every thread arrives)
 }
 
 // Quad version (dilation 1, W % 4 == 0): a thread owns four adjacent pixels, keeps their 3 x 6 gy neighbourhood in
@@ -535,9 +540,11 @@ template <int NC, bool DUAL = false>
 __global__ __launch_bounds__(256) void conv_smallco_dgrad4_kernel(const float* __restrict__ gy, const float* __restrict__ w,
                                                                  float* __restrict__ gx, const float* __restrict__ mask, int Cin,
                                                                  int H, int W, long gy_bs, long gx_bs, long mask_bs, int nmask,
-                                                                 int accumulate, int ci_per_block, float* __restrict__ gx_raw = nullptr,
+                                                                 int accumulate, int ci_per_block, float* __restrict__ amax,
+                                                                 int amax_channels, float* __restrict__ gx_raw = nullptr,
                                                                  long raw_bs = 0) {
   constexpr int U = 4;
+  float vmax = 0.f;                                          // max |stored gx| over channels < amax_channels
   const long hw = (long)H * W;
   const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.z;
@@ -593,10 +600,13 @@ __global__ __launch_bounds__(256) void conv_smallco_dgrad4_kernel(const float* _
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] *= irr_lrelu_grad(mk[u][i]);
       }
+      if (qok && ci + u < c1 && ci + u < amax_channels)
+        vmax = x3_amax_fold(x3_amax_fold(x3_amax_fold(x3_amax_fold(vmax, v[0]), v[1]), v[2]), v[3]);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), xr,
                                              (int)(ci + u < c1 ? vp : SOOB), (int)((uint32_t)(ci + u) * hw4), 0);
     }
   }
+  if (amax && c0 < amax_channels) x3_amax_publish_block256(vmax, amax);      // (block-uniform condition; every thread arrives)
 }
 
 // Weight gradient of a layer with a TINY input-channel count (the first pyramid conv 3 -> 16, stride 2: a 32-wide MFMA
@@ -673,8 +683,9 @@ __global__ __launch_bounds__(256) void conv_smallci_wgrad_kernel(const float* __
 
 extern "C" int irr_conv2d_smallco_dgrad_f32(const float* gy, const float* w, float* gx, const float* mask, int B, int Cin,
                                             int H, int W, int Cout, int dil, long gy_bs, long gx_bs, long mask_bs, int nmask,
-                                            int accumulate, void* stream) {
+                                            int accumulate, float* amax, int amax_channels, void* stream) {
   if (!gy || !w || !gx || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 1 || Cout > 2 || dil < 1 || B > 65535) return IRR_EINVAL;
+  if (!amax) amax_channels = 0;
   const long hw = (long)H * W;
   const int pblocks = irr_cdiv(hw, 256);
   // enough blocks to fill the chip; every block re-reads the (tiny) gy neighbourhood once
@@ -693,19 +704,19 @@ extern "C" int irr_conv2d_smallco_dgrad_f32(const float* gy, const float* w, flo
     dim3 grid4(qblocks, irr_cdiv(Cin, cpb4), B);
     if (Cout == 1)
       hipLaunchKernelGGL((conv_smallco_dgrad4_kernel<1>), grid4, dim3(256), 0, st, gy, w, gx, mask, Cin, H, W, gy_bs, gx_bs, mask_bs,
-                         nmask, accumulate, cpb4);
+                         nmask, accumulate, cpb4, amax, amax_channels);
     else
       hipLaunchKernelGGL((conv_smallco_dgrad4_kernel<2>), grid4, dim3(256), 0, st, gy, w, gx, mask, Cin, H, W, gy_bs, gx_bs, mask_bs,
-                         nmask, accumulate, cpb4);
+                         nmask, accumulate, cpb4, amax, amax_channels);
     IRR_LAUNCH_CHECK();
     return 0;
   }
   if (Cout == 1)
     hipLaunchKernelGGL((conv_smallco_dgrad_kernel<1>), grid, dim3(256), 0, st, gy, w, gx, mask, Cin, H, W, dil, gy_bs, gx_bs, mask_bs,
-                       nmask, accumulate, cpb);
+                       nmask, accumulate, cpb, amax, amax_channels);
   else
     hipLaunchKernelGGL((conv_smallco_dgrad_kernel<2>), grid, dim3(256), 0, st, gy, w, gx, mask, Cin, H, W, dil, gy_bs, gx_bs, mask_bs,
-                       nmask, accumulate, cpb);
+                       nmask, accumulate, cpb, amax, amax_channels);
   IRR_LAUNCH_CHECK();
   return 0;
 }
@@ -715,7 +726,7 @@ extern "C" int irr_conv2d_smallco_dgrad_f32(const float* gy, const float* w, flo
 // irr_lrelu_bwd_bias_f32.
 extern "C" int irr_conv2d_smallco_dgrad_dual_f32(const float* gy, const float* w, float* gx, float* gx_raw, const float* mask, int B,
                                                  int Cin, int H, int W, int Cout, long gy_bs, long gx_bs, long raw_bs, long mask_bs,
-                                                 void* stream) {
+                                                 float* amax, void* stream) {
   if (!gy || !w || !gx || !gx_raw || !mask || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout != 1 || B > 65535) return IRR_EINVAL;
   if ((W & 3) || ((gy_bs | gx_bs | raw_bs | mask_bs) & 3)) return IRR_EINVAL;
   const long hw = (long)H * W;
@@ -726,7 +737,7 @@ extern "C" int irr_conv2d_smallco_dgrad_dual_f32(const float* gy, const float* w
   const int cpb4 = ((Cin + split4 - 1) / split4 + 3) / 4 * 4;
   dim3 grid4(qblocks, irr_cdiv(Cin, cpb4), B);
   hipLaunchKernelGGL((conv_smallco_dgrad4_kernel<1, true>), grid4, dim3(256), 0, (hipStream_t)stream, gy, w, gx, mask, Cin, H, W, gy_bs,
-                     gx_bs, mask_bs, Cin, 0, cpb4, gx_raw, raw_bs);
+                     gx_bs, mask_bs, Cin, 0, cpb4, amax, amax ? Cin : 0, gx_raw, raw_bs);
   IRR_LAUNCH_CHECK();
   return 0;
 }

@@ -14,6 +14,7 @@
 // interleaved with the MFMAs of the current stage.  Split-K partials are added with COALESCED fp32 atomics
 // into a [co][tap][ci] workspace (lanes = ci are contiguous) and then folded into dW[co][ci][tap].
 #include "common.h"
+#include "amax.h"
 #include "wgrad_reduce.h"
 #include <stdlib.h>
 
@@ -531,20 +532,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const IrrReduceJob J)
 __global__ __launch_bounds__(256) void lrelu_bwd_bias_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                             float* __restrict__ gpre, float* __restrict__ gbias,
                                                             int C, long HW, long gy_bs, long y_bs, long gpre_bs,
-                                                            int lrelu, int chunk) {
+                                                            int lrelu, int chunk, float* __restrict__ amax) {
   const int c = blockIdx.y, b = blockIdx.z;
   const long p0 = (long)blockIdx.x * chunk;
   const long p1 = min(HW, p0 + chunk);
   const float* g = gy + (long)b * gy_bs + (long)c * HW;
   const float* yy = y ? y + (long)b * y_bs + (long)c * HW : nullptr;
   float* o = gpre ? gpre + (long)b * gpre_bs + (long)c * HW : nullptr;
-  float s = 0.f;
+  float s = 0.f, m = 0.f;
   for (long p = p0 + threadIdx.x; p < p1; p += 256) {
     float v = g[p];
     if (lrelu) v *= irr_lrelu_grad(yy[p]);
     if (o) o[p] = v;
     s += v;
+    m = x3_amax_fold(m, v);
   }
+  if (amax) x3_amax_publish_block256(m, amax);              // max |gpre|: the amax slot of the fp16x2 launches that read it
   if (!gbias) return;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -738,13 +741,13 @@ extern "C" int irr_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
 }
 
 extern "C" int irr_lrelu_bwd_bias_f32(const float* gy, const float* y, float* gpre, float* gbias, int B, int C, int HW,
-                                      long gy_bs, long y_bs, long gpre_bs, int lrelu, void* stream) {
+                                      long gy_bs, long y_bs, long gpre_bs, int lrelu, float* amax, void* stream) {
   if (!gy || B <= 0 || C <= 0 || HW <= 0 || (lrelu && !y) || B > 65535 || C > 65535) return IRR_EINVAL;
-  if (!gpre && !gbias) return 0;
+  if (!gpre && !gbias && !amax) return 0;
   int chunk = 4096;
   dim3 grid(irr_cdiv(HW, chunk), C, B);
   hipLaunchKernelGGL(lrelu_bwd_bias_kernel, grid, dim3(256), 0, (hipStream_t)stream, gy, y, gpre, gbias, C, (long)HW,
-                     gy_bs, y_bs, gpre_bs, lrelu, chunk);
+                     gy_bs, y_bs, gpre_bs, lrelu, chunk, amax);
   IRR_LAUNCH_CHECK();
   return 0;
 }

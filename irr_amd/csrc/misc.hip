@@ -1,4 +1,5 @@
 #include "common.h"
+#include "amax.h"
 extern "C" int irr_abi_version(void) { return 7; }   // 7: the fp16x2 pairs of activation-side operands carry a scaled-up low piece (range 2^17 -> 2^29 per element; irr_conv2d_wgrad_h2_robust_side); 6: the streaming 32-channel kernel takes the fp16x2 form too (irr_conv2d_fwd_h2_dual); 5: fp16x2 ("h2") conv entry points + amax slots; 4: loss reductions take a partial-sum scratch (fixed summation order); 3: Adam scalars are doubles
 
 // ---- channel concatenation of up to IRR_CAT_MAX_PARTS tensors in ONE launch (include/irr_hip.h) ----------------------------
@@ -15,8 +16,10 @@ struct CatArgs {
   int n;
 };
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void cat_channels_kernel(float* __restrict__ dst, long dst_bs, const CatArgs a, long hw) {
+// AMAX: max |value written| (zero-fill parts included) folded into *amax -- the consumer of the buffer runs on the fp16x2 conv
+// kernels and needs the magnitude of its input: a separate pass over the buffer costs as much as this copy (round 5)
+template <bool VEC, bool AMAX>
+__global__ __launch_bounds__(256) void cat_channels_kernel(float* __restrict__ dst, long dst_bs, const CatArgs a, long hw, float* __restrict__ amax) {
   const int c = blockIdx.y, b = blockIdx.z;
   int part = 0;
 #pragma unroll
@@ -25,20 +28,29 @@ __global__ __launch_bounds__(256) void cat_channels_kernel(float* __restrict__ d
   const float* s = a.src[part] ? a.src[part] + (long)b * a.bs[part] + (long)c_local * hw : nullptr;
   float* d = dst + (long)b * dst_bs + (long)c * hw;
   const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (p0 >= hw) return;
   typedef float f4 __attribute__((ext_vector_type(4)));
-  if (VEC) {
-    *(f4*)(d + p0) = s ? *(const f4*)(s + p0) : f4{0.f, 0.f, 0.f, 0.f};
-  } else {
+  float m = 0.f;
+  if (p0 < hw) {
+    if (VEC) {
+      const f4 v = s ? *(const f4*)(s + p0) : f4{0.f, 0.f, 0.f, 0.f};
+      *(f4*)(d + p0) = v;
+      if (AMAX) m = x3_amax_fold(x3_amax_fold(x3_amax_fold(x3_amax_fold(m, v[0]), v[1]), v[2]), v[3]);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (p0 + i < hw) d[p0 + i] = s ? s[p0 + i] : 0.f;
+      for (int i = 0; i < 4; ++i)
+        if (p0 + i < hw) {
+          const float v = s ? s[p0 + i] : 0.f;
+          d[p0 + i] = v;
+          if (AMAX) m = x3_amax_fold(m, v);
+        }
+    }
   }
+  if (AMAX) x3_amax_publish_block256(m, amax);              // (every thread of the block arrives)
 }
 
 }  // namespace
 
-extern "C" int irr_cat_channels_f32(float* dst, long dst_bs, const void* parts, int nparts, int B, long hw, void* stream) {
+static int cat_channels_impl(float* dst, long dst_bs, const void* parts, int nparts, int B, long hw, float* amax, void* stream) {
   if (!dst || !parts || nparts < 1 || nparts > IRR_CAT_MAX_PARTS || B <= 0 || B > 65535 || hw <= 0) return IRR_EINVAL;
   const IrrCatPart* p = (const IrrCatPart*)parts;
   CatArgs a;
@@ -60,8 +72,64 @@ extern "C" int irr_cat_channels_f32(float* dst, long dst_bs, const void* parts, 
   a.n = nparts;
   if (c > 65535) return IRR_EINVAL;
   const dim3 grid(irr_cdiv(hw, 1024), c, B);
-  if (vec) hipLaunchKernelGGL(cat_channels_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dst, dst_bs, a, hw);
-  else hipLaunchKernelGGL(cat_channels_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dst, dst_bs, a, hw);
+  hipStream_t st = (hipStream_t)stream;
+  if (amax) {
+    if (vec) hipLaunchKernelGGL((cat_channels_kernel<true, true>), grid, dim3(256), 0, st, dst, dst_bs, a, hw, amax);
+    else hipLaunchKernelGGL((cat_channels_kernel<false, true>), grid, dim3(256), 0, st, dst, dst_bs, a, hw, amax);
+  } else {
+    if (vec) hipLaunchKernelGGL((cat_channels_kernel<true, false>), grid, dim3(256), 0, st, dst, dst_bs, a, hw, amax);
+    else hipLaunchKernelGGL((cat_channels_kernel<false, false>), grid, dim3(256), 0, st, dst, dst_bs, a, hw, amax);
+  }
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_cat_channels_f32(float* dst, long dst_bs, const void* parts, int nparts, int B, long hw, void* stream) {
+  return cat_channels_impl(dst, dst_bs, parts, nparts, B, hw, nullptr, stream);
+}
+
+// the same, and *amax = max(*amax, max |value written|) (an amax slot of the fp16x2 conv kernels: non-negative float, starts at 0)
+extern "C" int irr_cat_channels_amax_f32(float* dst, long dst_bs, const void* parts, int nparts, int B, long hw, float* amax, void* stream) {
+  if (!amax) return IRR_EINVAL;
+  return cat_channels_impl(dst, dst_bs, parts, nparts, B, hw, amax, stream);
+}
+
+// ---- out[b, :] = x[b, :] + y[b, :] for B samples of n plane-dense floats with independent batch strides ------------------------
+// The backward passes add a channel-slice VIEW of one tensor to a dense tensor in a few places (the occlusion channel of the
+// upsampler's input gradient + the skip gradient, the estimate slot of a DenseNet gradient buffer + the head's own gradient): as
+// ATen ops on a (B, n) view with a batch stride these run through the generic strided-iterator kernel at ~0.25 TB/s (0.55 ms for a
+// 44 MB full-resolution plane set; profiles/r4_op_census.txt); here they are one coalesced 16-B pass.  out may alias x or y.
+namespace {
+template <bool VEC>
+__global__ __launch_bounds__(256) void add_planes_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ y,
+                                                        long n, long out_bs, long x_bs, long y_bs) {
+  const int b = blockIdx.y;
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float* xb = x + (long)b * x_bs;
+  const float* yb = y + (long)b * y_bs;
+  float* ob = out + (long)b * out_bs;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  if (VEC) {
+    const f4 u = *(const f4*)(xb + i), v = *(const f4*)(yb + i);
+    f4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = u[e] + v[e];
+    *(f4*)(ob + i) = r;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i + e < n) ob[i + e] = xb[i + e] + yb[i + e];
+  }
+}
+}  // namespace
+
+extern "C" int irr_add_planes_f32(float* out, const float* x, const float* y, int B, long n, long out_bs, long x_bs, long y_bs, void* stream) {
+  if (!out || !x || !y || B <= 0 || B > 65535 || n <= 0) return IRR_EINVAL;
+  const bool vec = (n & 3) == 0 && ((out_bs | x_bs | y_bs) & 3) == 0 && ((((uintptr_t)out) | ((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+  const dim3 grid(irr_cdiv(n, 1024), B);
+  if (vec) hipLaunchKernelGGL(add_planes_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, out, x, y, n, out_bs, x_bs, y_bs);
+  else hipLaunchKernelGGL(add_planes_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, out, x, y, n, out_bs, x_bs, y_bs);
   IRR_LAUNCH_CHECK();
   return 0;
 }

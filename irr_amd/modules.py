@@ -191,6 +191,15 @@ def subtract_mean(t):
     return t - t.mean(dim=(2, 3), keepdim=True)
 
 
+def _refine_input(parts, first_conv):
+    """cat(parts, dim=1) in one launch; when the first conv of the stack runs on the fp16x2 kernels the copy also folds the input's
+    magnitude (no torch.cat + separate pass)"""
+    B, _, H, W = parts[0].shape
+    cin = sum(int(p_.shape[1]) for p_ in parts)
+    w = first_conv.weight
+    return C.cat_channels(parts, want_amax=bool(C.h2_code(B, cin, H, W, w.shape[0], w.shape[2], 1, 1)))
+
+
 class _Refine(nn.Module):
     def __init__(self, ch_in):
         super().__init__()
@@ -208,7 +217,7 @@ class RefineFlow(_Refine):
     def forward(self, flow, diff_img, feature, scale=(1.0, 1.0)):
         flow_m = subtract_mean(flow)
         norm2_img = torch.linalg.vector_norm(diff_img, ord=2, dim=1, keepdim=True)
-        feat = C.conv_chain(torch.cat([flow_m, norm2_img, feature], dim=1), list(self.convs))
+        feat = C.conv_chain(_refine_input((flow_m, norm2_img, feature), self.convs[0]), list(self.convs))
         return Fn.refine_tail(feat, flow, scale)
 
 
@@ -216,5 +225,5 @@ class RefineOcc(_Refine):
     """models/irr_modules.py:107-139."""
 
     def forward(self, occ, feat1, feat2):
-        feat = C.conv_chain(torch.cat([occ, feat1, feat2], dim=1), list(self.convs))
+        feat = C.conv_chain(_refine_input((occ, feat1, feat2), self.convs[0]), list(self.convs))
         return Fn.refine_tail(feat, occ, (1.0, 1.0))

@@ -36,7 +36,7 @@ def _grad_finite_report(module) -> None:
     if not bool(flags.all()):
         bad = [(n, float(a)) for (n, _), f, a in zip(named, flags.tolist(), amax.tolist()) if not f]
         good = [n for (n, _), f in zip(named, flags.tolist()) if f]
-        print(f"[grad log] step {_GRAD_STEP[0]}: {len(bad)} of {len(named)} gradients non-finite; FINITE: " + ", ".join(good[:40]),
+        print(f"[grad log] step {_GRAD_STEP[0]}: {len(bad)} of {len(named)} gradients non-finite; FINITE: " + " ".join(n.replace("_model.", "") for n in good),
               file=sys.stderr, flush=True)
     elif os.environ.get("IRR_GRAD_FINITE_LOG") == "2":
         top = sorted(((float(a), n) for (n, _), a in zip(named, amax.tolist())), reverse=True)[:3]

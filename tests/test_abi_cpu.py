@@ -65,10 +65,13 @@ def test_build_is_keyed_on_content_not_on_mtime(tmp_path):
     assert B.built_hash() == B.source_hash()
 
 
-def test_streaming_kernel_h2_form_is_opt_in():
+def test_streaming_kernel_h2_form_is_a_host_side_switch():
     """Routing is host code: the streaming 32-channel problems report code 9001 to both eligibility functions of the library, and
-    irr_amd.conv keeps them on bf16x3 unless conv.X3S_H2 is switched on (DESIGN.md 5.2 / profiles/NOTES.md C.5)."""
+    irr_amd.conv puts them on the fp16x2 form unless conv.X3S_H2 is switched off (default on since round 5: DESIGN.md 5.2 /
+    profiles/NOTES.md C.5)."""
     from irr_amd import conv as C, hip
+    import os
+    assert C.X3S_H2 == bool(int(os.environ.get("IRR_X3S_H2", "1")))
     old_math = C.MATH
     C.set_math("h2")
     try:

@@ -86,16 +86,18 @@ def test_bench_eight_ranks_share_one_gpu_over_gloo():
     env = _env()
     env["IRR_DDP_BACKEND"] = "gloo"
     env["OMP_NUM_THREADS"] = "2"
-    # Eight PROCESSES on one GPU are what this test has to make do with, and on this pool such a run dies in 15-25 % of the attempts
+    # Eight PROCESSES on one GPU are what this test has to make do with, and on this pool such a run dies in 7-25 % of the attempts
     # with "HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION" in one rank's queue -- the round-3 tree does the same (4 of 16 runs; 2 of 14 and 1 of
     # 14 for two trees of this round, tools/_flake notes in profiles/NOTES.md C.4), a single process never does.  That abort, and
-    # only that, is retried.
-    for attempt in range(4):
+    # only that, is retried (twice at most) and then REPORTED as an xfail.
+    aborted = 0
+    for attempt in range(3):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "2", "--batch", "1",
                             "--height", "128", "--width", "192", "--no-secondary", "--no-cpu-baseline", "--prealloc-gb", "0"],
                            env=env, capture_output=True, text=True, timeout=1500)
         if r.returncode == 0 or "HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION" not in r.stderr:
             break
+        aborted += 1
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-3000:]
@@ -104,3 +106,7 @@ def test_bench_eight_ranks_share_one_gpu_over_gloo():
     assert len(out["ranks"]["per_rank_ms_per_step"]) == 8 and max(out["ranks"]["per_rank_ms_per_step"]) == pytest.approx(out["ms_per_step"], rel=1e-3)
     log = [tuple(e[:2]) for e in out["ranks"]["bucket_launches_last_step"]]
     assert log == [(0, "backward"), (1, "backward"), (2, "backward")], out["ranks"]
+    if aborted:
+        # COUNTED, not hidden: the run that was validated above passed, but an earlier attempt died with the queue abort
+        pytest.xfail(f"{aborted} attempt(s) aborted with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION before the validated run (eight processes "
+                     f"on one GPU; profiles/NOTES.md C.4: the round-3 tree does the same, a single process never does)")

@@ -20,7 +20,7 @@ def h2_everywhere():
     from irr_amd import conv as C, hip
     old = hip.lib().irr_conv_x3_set_min_blocks(0)
     C.set_math("h2")
-    old_s = C.set_x3s_h2(True)                    # (the streaming kernel's fp16x2 form is off by default: conv.X3S_H2)
+    old_s = C.set_x3s_h2(True)                    # (the default since round 5; set explicitly: IRR_X3S_H2=0 runs of the suite)
     C.LAUNCHES.clear()
     yield
     hip.lib().irr_conv_x3_set_min_blocks(old)

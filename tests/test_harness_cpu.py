@@ -110,7 +110,8 @@ def test_gradients_cleared_between_forward_and_backward_are_reattached():
     lane.on_join = arena.readopt_routed
     w, b = m[0].weight, m[0].bias
     w2 = m[1].weight
-    for p in m.parameters():                     # the caller's zero_grad() after the forward pass
+    arena.flat.fill_(9.0)                        # the previous step's gradients are still in the arena ...
+    for p in m.parameters():                     # ... when the caller's zero_grad() comes after the forward pass
         p.grad = None
     gw, gb = lane.route(w, b)
 

@@ -11,6 +11,6 @@ for spec in "$@"; do
     ( export IRR_DDP_BACKEND=gloo IRR_X3S_H2=1; for kv in $envs; do export "$kv"; done
       timeout 300 python bench.py --gpus 2 --steps 2 --warmup 2 --batch 2 --no-cpu-baseline > /tmp/nh_o.txt 2> /tmp/nh_e.txt
       echo "run $i: rc=$? NaN=$(grep -c 'is NaN' /tmp/nh_e.txt) gradlog=$(grep -c 'grad log' /tmp/nh_e.txt)" ) | tee -a $OUT
-    grep -h "grad log\|slot log\|finite log\|  #" /tmp/nh_e.txt | cut -c1-400 | head -12 | tee -a $OUT
+    grep -h "grad log\|slot log\|finite log\|  #" /tmp/nh_e.txt | cut -c1-4000 | head -4 | tee -a $OUT
   done
 done
