@@ -55,6 +55,28 @@ class ReduceBatch:
 
 
 
+_MASKED_STREAMS = []      # (handles of CU-masked HIP streams: never destroyed, a process creates at most a few)
+
+
+def _lane_stream(dev):
+    """the lane's HIP stream.  IRR_LANE_CU_MASK=n (experiment switch, lane schedule (b) of VERDICT r4 item 4): a stream restricted to
+    n compute units (hipExtStreamCreateWithCUMask; the n lowest mask bits -- the driver deals them round-robin over the eight XCDs),
+    so that the lane FILLS a fixed share of the chip instead of time-slicing whole launches with the main stream."""
+    n = int(os.environ.get("IRR_LANE_CU_MASK", "0") or 0)
+    if n <= 0:
+        return torch.cuda.Stream(device=dev)
+    hiprt = ctypes.CDLL("libamdhip64.so")
+    words = (n + 31) // 32
+    mask = (ctypes.c_uint32 * words)(*[(0xffffffff if n >= 32 * (i + 1) else (1 << (n - 32 * i)) - 1) for i in range(words)])
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hiprt.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), mask)
+    if rc != 0 or not handle.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    _MASKED_STREAMS.append(handle)
+    return torch.cuda.ExternalStream(handle.value, device=dev)
+
+
 class WgradSide:
     """Asynchronous weight-gradient lane (training harness opt-in, see irr_amd.ddp.GradArena.enable_async_wgrad).
 
@@ -72,7 +94,7 @@ class WgradSide:
         # inline: no second stream -- the launches stay on the current stream, but still accumulate straight into the arena
         # (no per-use gradient tensors, no autograd accumulation adds, one batched fold): GradArena.enable_direct_wgrad()
         self.inline = inline
-        self.stream = None if inline else torch.cuda.Stream(device=dev)
+        self.stream = None if inline else _lane_stream(dev)
         # The references in _inflight are dropped only after the lane has passed the launch (marker) or after the current stream
         # has joined the lane, so the caching allocator can never hand the memory out early; Tensor.record_stream on top of that
         # makes the allocator record one (system-scope) event on the lane per freed tensor -- 500 per step (A/B switch: 1 = on)
@@ -101,6 +123,27 @@ class WgradSide:
         # lane has accumulated into the arena slice, and a stock optimizer would silently skip the parameter)
         self._routed = {}
         self.on_join = None
+        # hold() ... release(): launches issued in between are parked and handed to the lane only at release() -- a backward node
+        # whose main-stream kernels are bandwidth-bound persistent kernels (the OccUpsampleNetwork: conv_x3s_kernel ran +60 % per
+        # launch beside the lane's weight gradients of the same layers, profiles/r4_kernel_stats*.txt) keeps the chip to itself and its
+        # weight gradients run under the MFMA-bound levels that follow.  Not under DDP bucket counting (on_queue set).
+        self._hold = 0
+        self._held = []
+        self._queue_stream = None               # stream the launches in _queued were issued from
+
+    def hold(self):
+        if not self.inline and self.on_queue is None:
+            self._hold += 1
+            return True
+        return False
+
+    def release(self):
+        if self._hold > 0:
+            self._hold -= 1
+        if self._hold == 0 and self._held:
+            held, self._held = self._held, []
+            for item in held:
+                self.launch(*item)
 
     def abandon(self):
         """Forget everything a backward pass that RAISED left behind (autograd skips its final callbacks then, so nobody joined):
@@ -110,6 +153,7 @@ class WgradSide:
         self._queued = []
         self._pending = []
         self._routed = {}
+        self._held, self._hold = [], 0
         if self.batch is not None:
             self.batch.n, self.batch.keep, self.batch.targets = 0, [], set()
         self._join_queued = False
@@ -119,7 +163,8 @@ class WgradSide:
 
     def stale(self) -> bool:
         """True when a previous backward pass ended without its join (it raised): see abandon()"""
-        return self._join_queued or bool(self._queued) or bool(self._pending) or (self.batch is not None and self.batch.n > 0)
+        return (self._join_queued or bool(self._queued) or bool(self._pending) or bool(self._held)
+                or (self.batch is not None and self.batch.n > 0))
 
     def _view(self, p_):
         hit = self.views.get(id(p_))
@@ -137,7 +182,10 @@ class WgradSide:
         if not self._queued:
             return
         queued, self._queued = self._queued, []
-        main = torch.cuda.current_stream()
+        # (the stream the queued launches were ISSUED from: with IRR_BRANCH_STREAMS=1 backward nodes run on two streams, and a group
+        # must wait for the stream that produced its operands -- a group never mixes streams, see launch())
+        main = self._queue_stream if self._queue_stream is not None else torch.cuda.current_stream()
+        self._queue_stream = None
         ev = torch.cuda.Event()
         ev.record(main)
         self.stream.wait_event(ev)
@@ -205,6 +253,9 @@ class WgradSide:
         model code around the node does with the same gradient tensor (``a = a + b`` feeding two nodes,
         models/pwcnet_irr*.py)."""
         self._queue_join()
+        if self._hold > 0:
+            self._held.append((fn, tensors, params, gw))
+            return
         if self.on_join is not None:
             for p_ in params:
                 if p_ is not None and id(p_) not in self._routed:
@@ -230,6 +281,10 @@ class WgradSide:
             if self.on_queue is not None and params[0] is not None:
                 self.on_queue(*params)
             return
+        cur = torch.cuda.current_stream()
+        if self._queued and self._queue_stream is not None and self._queue_stream != cur:
+            self._kick()                                       # the parked launches were issued from another stream: hand them over first
+        self._queue_stream = cur
         self._queued.append((fn, tensors, params, gw.data_ptr() if gw is not None else 0))
         if len(self._queued) >= self.group:
             self._kick()
@@ -238,6 +293,9 @@ class WgradSide:
 
     def join(self):
         self._join_queued = False               # (also after a backward pass that raised before its final callbacks ran)
+        if self._held:                           # (a node raised between hold() and release())
+            self._hold = 0
+            self.release()
         self.flush()
         if self.inline:
             self._after_join()

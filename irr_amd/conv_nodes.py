@@ -515,6 +515,9 @@ def conv_chain(x, layers, res=None):
 # autograd: OccUpsampleNetwork (models/irr_modules.py:30-56) as ONE node
 # ----------------------------------------------------------------------------------------------
 
+_LANE_HOLD_OCCUP = os.environ.get("IRR_LANE_HOLD_OCCUP", "0") != "0"      # lane schedule (a) of VERDICT r4 item 4, profiles/r5_lane_schedules.txt
+
+
 class _OccUpsampleFn(hip.Function):
     """x_in -> init_conv -> 3 x [x += 0.1 * res_convs(x)] (shared weights) -> x_init + res_end_conv(x) -> out_convs + occ.
 
@@ -572,6 +575,16 @@ class _OccUpsampleFn(hip.Function):
 
     @staticmethod
     def backward(ctx, g_out):
+        # (IRR_LANE_HOLD_OCCUP: the node's weight-gradient launches reach the lane only when its data-gradient chain has been issued)
+        held = _c.SIDE.hold() if (_LANE_HOLD_OCCUP and _c.SIDE is not None) else False
+        try:
+            return _OccUpsampleFn._backward(ctx, g_out)
+        finally:
+            if held:
+                _c.SIDE.release()
+
+    @staticmethod
+    def _backward(ctx, g_out):
         x_in, x0, x1, x2r, x3, t1, t2, t3, e, x2, o = ctx.saved_tensors
         w_init, w_r0, w_r1, w_end, w_out = ctx.wobjs
         b_init, b_r0, b_r1, b_end, b_out = ctx.bobjs
