@@ -451,8 +451,8 @@ def main():
 
     head = run(make_step, a.batch, a.height, a.width, a.steps, a.warmup, not a.no_kernel_timer)
     # rank 0's bucket schedule of the last step: (bucket, where it was started, ms since zero_grad)
-    launch_log = ([(b_, w_, t_) for (b_, w_), t_ in zip(arena.launch_log, arena.launch_times)]
-                  if (arena is not None and world > 1) else None)
+    launch_rep = arena.launch_report() if (arena is not None and world > 1) else None
+    launch_log = launch_rep["bucket_launches"] if launch_rep is not None else None
     second = None
     if not a.no_secondary and (a.height, a.width) == (384, 448):
         second = run(make_step, SECONDARY[0], SECONDARY[1], SECONDARY[2], SECONDARY_STEPS, 2, not a.no_kernel_timer)
@@ -577,7 +577,11 @@ def main():
             out["roofline"].pop("by_kernel_all", None)
         if head["spread"] is not None:
             out["ranks"] = head["spread"]
-            out["ranks"]["bucket_launches_last_step"] = launch_log      # rank 0: (bucket, "backward" | "sync")
+            out["ranks"]["bucket_launches_last_step"] = launch_log      # rank 0: (bucket, "backward" | "sync", ms since zero_grad)
+            if launch_rep is not None:
+                # ms since zero_grad (host clock) at which the cost-volume gradient kernels of levels 4 .. 0 were issued: bucket 0's
+                # all-reduce is enqueued before the first of them, bucket 1's after the last (it is reduced under the pyramid's backward)
+                out["ranks"]["corr_backward_launches_ms"] = launch_rep["corr_backward_launches_ms"]
         if second is not None:
             gf2 = CONV_GFLOP_PER_PAIR[(SECONDARY[1], SECONDARY[2])]
             if second["roofline"] is not None:

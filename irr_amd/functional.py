@@ -9,6 +9,7 @@ from __future__ import annotations
 from typing import Optional
 
 import os
+import time
 
 import torch
 
@@ -47,6 +48,12 @@ def _need_cuda(*ts):
 # ----------------------------------------------------------------------------------------------
 # cost volume
 # ----------------------------------------------------------------------------------------------
+# host times (time.perf_counter) at which the cost-volume GRADIENT launches of the current backward pass were issued -- bench.py relates
+# the gradient buckets' all-reduce launches to them (north_star: "all-reduce ... overlapped with the backward correlation kernel");
+# cleared by whoever reads it (irr_amd.ddp.GradArena.zero_grad)
+CORR_BWD_LAUNCH_TIMES = []
+
+
 class _CostVolume(hip.Function):
     @staticmethod
     def forward(ctx, f1, f2, lrelu: bool, premasked: bool = False):
@@ -69,6 +76,8 @@ class _CostVolume(hip.Function):
         B, C, H, W = f1.shape
         g1 = torch.empty_like(f1) if ctx.needs_input_grad[0] else None
         g2 = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
+        if len(CORR_BWD_LAUNCH_TIMES) < 64:
+            CORR_BWD_LAUNCH_TIMES.append(time.perf_counter())
         hip.call("irr_corr81_bwd_f32", hip.ptr(f1), hip.ptr(f2), hip.ptr(gout), hip.ptr(out), hip.ptr(g1), hip.ptr(g2),
                  B, C, H, W, hip.bs(f1), hip.bs(f2), hip.bs(gout), hip.bs(out) if out is not None else 0,
                  hip.bs(g1) if g1 is not None else 0, hip.bs(g2) if g2 is not None else 0, hip.stream())

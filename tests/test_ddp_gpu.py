@@ -75,6 +75,14 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0 and out["config"]["transport"] == "gloo"
     assert out["secondary"]["value"] > 0 and out["secondary"]["roofline"]["achieved"] > 0
     assert out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out
+    # the configuration that found round 4's two-rank NaN stays in the suite: the streaming kernel's fp16x2 form is the default now
+    assert out["x3s_h2"] is True and out["launches_per_step"].get("fwd_x3s", 0) > 0
+    # north_star: "all-reduce of gradients ... overlapped with the backward correlation kernel": bucket 0 (the occlusion upsampler,
+    # final after levels 6-5) is enqueued inside backward before the LAST cost-volume gradient launch (levels 4 .. 0 follow it)
+    log = out["ranks"]["bucket_launches_last_step"]
+    corr = out["ranks"]["corr_backward_launches_ms"]
+    assert [tuple(e[:2]) for e in log] == [(0, "backward"), (1, "backward"), (2, "backward")], log
+    assert len(corr) == 5 and log[0][2] < corr[-1] < log[1][2], (log, corr)
 
 
 def test_bench_eight_ranks_share_one_gpu_over_gloo():
