@@ -580,7 +580,8 @@ def main():
             out["ranks"]["bucket_launches_last_step"] = launch_log      # rank 0: (bucket, "backward" | "sync", ms since zero_grad)
             if launch_rep is not None:
                 # ms since zero_grad (host clock) at which the cost-volume gradient kernels of levels 4 .. 0 were issued: bucket 0's
-                # all-reduce is enqueued before the first of them, bucket 1's after the last (it is reduced under the pyramid's backward)
+                # all-reduce is enqueued before the first of them (it runs under all five), bucket 1's around the last (it is reduced
+                # under the pyramid's backward)
                 out["ranks"]["corr_backward_launches_ms"] = launch_rep["corr_backward_launches_ms"]
         if second is not None:
             gf2 = CONV_GFLOP_PER_PAIR[(SECONDARY[1], SECONDARY[2])]

@@ -143,8 +143,8 @@ class GradArena:
 
     def launch_report(self) -> dict:
         """of the step that has just run (call after sync(), before the next zero_grad()): when each bucket's all-reduce was enqueued
-        and when the cost-volume gradient kernels were issued, ms since the step's zero_grad() on the host clock -- bucket 0 must
-        start before the LAST of them (levels 4..0 are visited in that order) for the overlap north_star asks for."""
+        and when the cost-volume gradient kernels were issued, ms since the step's zero_grad() on the host clock -- bucket 0 is
+        enqueued before the FIRST of them (levels 4..0 are visited in that order): the overlap north_star asks for."""
         from . import functional as _fn
         return {"bucket_launches": [(b_, w_, t_) for (b_, w_), t_ in zip(self.launch_log, self.launch_times)],
                 "corr_backward_launches_ms": [round((t - self._t0) * 1e3, 3) for t in _fn.CORR_BWD_LAUNCH_TIMES]}
