@@ -4,7 +4,7 @@
 # 1. bench.py default (two-lane) with the CPU baseline          -> <tag>_bench.json
 # 2. rocprofv3 --kernel-trace --stats, default and single-stream -> <tag>_kernel_stats{,_serial}.txt (+ the JSON line of the same run)
 # 3. two separate PMC passes (FETCH_SIZE, WRITE_SIZE)            -> <tag>_hbm_traffic.txt, hbm_traffic.json
-TAG=${1:-r4}
+TAG=${1:-r5}
 OUT=gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -36,7 +36,7 @@ python tools/rocpd_timeline.py $(find $OUT/kts -name "*.db" | head -1) > $OUT/${
 rm -rf $OUT/kts
 IRR_CONV_MATH=f32 python bench.py --no-cpu-baseline --no-secondary --no-extra-legs > $OUT/${TAG}_bench_math_f32.json 2>> $OUT/${TAG}_bench.err
 IRR_CONV_MATH=x3 python bench.py --no-cpu-baseline --no-secondary --no-extra-legs > $OUT/${TAG}_bench_math_x3.json 2>> $OUT/${TAG}_bench.err
-IRR_X3S_H2=1 python bench.py --no-cpu-baseline --no-secondary --no-extra-legs > $OUT/${TAG}_bench_x3s_h2.json 2>> $OUT/${TAG}_bench.err
+IRR_X3S_H2=0 python bench.py --no-cpu-baseline --no-secondary --no-extra-legs > $OUT/${TAG}_bench_x3s_bf16x3.json 2>> $OUT/${TAG}_bench.err      # (round 5: the fp16x2 form is the default; this leg = round 4's routing)
 IRR_LANE_MAX_LEAD=1 python bench.py --no-cpu-baseline --no-secondary --no-extra-legs > $OUT/${TAG}_bench_bounded_lead.json 2>> $OUT/${TAG}_bench.err
 # 4. the second crop of north_star (per-GPU share of configs[4]): kernel stats + PMC passes of its own
 python bench.py --no-cpu-baseline --no-extra-legs --batch 8 --height 448 --width 1024 > $OUT/${TAG}_bench_448x1024_bs8.json 2>> $OUT/${TAG}_bench.err
