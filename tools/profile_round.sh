@@ -58,5 +58,5 @@ python tools/truth_probe.py 2>/dev/null > $OUT/${TAG}_math_agreement.txt
 python tools/level_times.py 2>/dev/null > $OUT/${TAG}_level_times.txt
 python tools/conv_breakdown.py 32 --fp32 2>/dev/null > $OUT/${TAG}_conv_breakdown.txt
 python tools/op_census.py 2>/dev/null > $OUT/${TAG}_op_census.txt
-[ -d r3tree ] && bash tools/ab_r3.sh 3 > $OUT/${TAG}_ab_vs_r3.txt 2>&1
+[ -d r4tree ] && bash tools/ab_r4.sh 3 > $OUT/${TAG}_ab_vs_r4.txt 2>&1
 ls -la $OUT
