@@ -11,21 +11,32 @@ namespace {
 // load: the slot only grows, and after the first few waves almost nobody has anything to add (a stale look only costs an atomic
 // that changes nothing).  The atomic is the returning form and the wave consumes the result before it ends: a returned value
 // means the update has been performed, whatever the hardware does with posted atomics at the end of a kernel.
+// All comparisons run on the BIT PATTERNS (round 5): for non-negative floats the unsigned order of the patterns is the numeric
+// order, +inf sorts above every finite value and every NaN pattern above +inf -- "a NaN wins" without a second compare.  One
+// v_and_b32 + one v_max_u32 per folded value instead of |.|, two compares, an or and a select: the fold runs once per STORED value
+// in the epilogues, and the epilogue waves of conv_x3s_kernel are bound by their VALU instructions.
+__device__ __forceinline__ uint32_t x3_amax_bits(float v) { return __builtin_bit_cast(uint32_t, v) & 0x7fffffffu; }
+__device__ __forceinline__ float x3_amax_fold(float m, float v) {      // m: a running maximum (non-negative, or a NaN pattern)
+  const uint32_t a = x3_amax_bits(v), b = __builtin_bit_cast(uint32_t, m);
+  return __builtin_bit_cast(float, a > b ? a : b);
+}
 __device__ __forceinline__ float x3_amax_wave(float m) {
+  uint32_t b = __builtin_bit_cast(uint32_t, m);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    const float o = __shfl_xor(m, off, 64);
-    m = (o > m || o != o) ? o : m;
+    const uint32_t o = (uint32_t)__shfl_xor((int)b, off, 64);
+    b = o > b ? o : b;
   }
-  return m;
+  return __builtin_bit_cast(float, b);
 }
 #ifndef X3_AMAX_PRECHECK
 #define X3_AMAX_PRECHECK 1     // 0 (A/B): every wave / block issues its atomic
 #endif
 __device__ __forceinline__ void x3_amax_commit(float m, float* slot) {       // one lane
-  const float cur = X3_AMAX_PRECHECK ? __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1.f;
-  if (m > cur || m != m) {
-    const unsigned int old = atomicMax((unsigned int*)slot, __builtin_bit_cast(unsigned int, m));
+  const uint32_t mb = __builtin_bit_cast(uint32_t, m);
+  const uint32_t cur = X3_AMAX_PRECHECK ? __hip_atomic_load((unsigned int*)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  if (mb > cur || !X3_AMAX_PRECHECK) {
+    const unsigned int old = atomicMax((unsigned int*)slot, mb);
     asm volatile("" ::"v"(old));                            // wait for the atomic's return: performed before the wave ends
   }
 }
@@ -42,13 +53,9 @@ __device__ __forceinline__ void x3_amax_publish_block256(float m, float* slot) {
   if (threadIdx.x == 0) {
     float r = wm[0];
 #pragma unroll
-    for (int i = 1; i < 4; ++i) r = (wm[i] > r || wm[i] != wm[i]) ? wm[i] : r;
+    for (int i = 1; i < 4; ++i) r = x3_amax_fold(r, wm[i]);
     x3_amax_commit(r, slot);
   }
-}
-__device__ __forceinline__ float x3_amax_fold(float m, float v) {
-  const float a = __builtin_fabsf(v);
-  return (a > m || a != a) ? a : m;
 }
 
 }  // namespace

@@ -84,21 +84,30 @@ constexpr float H2_LO_UP = 2048.f;                          // 2^11
 #define H2_LO_UP_ON 1   // 0 (A/B build, IRR_DEFS=-DH2_LO_UP_ON=0 with IRR_BUILD_TAG): round 4's plain low pieces everywhere
 #endif
 
+// The residual comes out of ONE v_fma_mix_f32 per value (fp16 source converted on the fly: (float)hi * -K + x*s*K, exact -- the
+// difference is representable), K = 2^11 for the scaled-up low piece, 1 for the plain one: 4 (3) VALU instructions per value
+// (two (one) multiplies, half a v_cvt_pk_f16_f32 each for hi and lo, the fma_mix) where the convert-back + subtract + scale
+// sequence needed 5 (4) -- the producer waves of conv_x3s_kernel are bound by exactly these instructions.
 template <bool LO_UP = false>
 __device__ __forceinline__ void split8_h2(const float* v, float s, u32x4& h, u32x4& l) {
+  constexpr bool UP = LO_UP && H2_LO_UP_ON;
+  const float s_up = s * H2_LO_UP;                           // (uniform: hoisted out of every loop by the compiler)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float a0 = v[2 * q] * s, a1 = v[2 * q + 1] * s;
     asm volatile("" : "+v"(a0));                            // (scalar v_mul_f32, not v_pk_mul_f32: see split8)
     const f32x2 a = {a0, a1};
     const f16x2 hp = __builtin_convertvector(a, f16x2);
-    float r0 = a[0] - (float)hp[0], r1 = a[1] - (float)hp[1];
-    asm volatile("" : "+v"(r0));                            // (keeps the subtractions scalar, see split8)
-    if (LO_UP && H2_LO_UP_ON) {                             // exact: the residual is <= 2^3 in magnitude, 2^14 after the scaling
-      r0 *= H2_LO_UP;
-      r1 *= H2_LO_UP;
-      asm volatile("" : "+v"(r0));
+    float r0, r1;
+    if (UP) {
+      const float b0 = v[2 * q] * s_up, b1 = v[2 * q + 1] * s_up;      // = a * 2^11 exactly (a power-of-two factor)
+      r0 = __builtin_fmaf((float)hp[0], -H2_LO_UP, b0);
+      r1 = __builtin_fmaf((float)hp[1], -H2_LO_UP, b1);
+    } else {
+      r0 = __builtin_fmaf((float)hp[0], -1.f, a0);
+      r1 = __builtin_fmaf((float)hp[1], -1.f, a1);
     }
+    asm volatile("" : "+v"(r0));                            // (keeps the pair scalar, see split8)
     const f32x2 r = {r0, r1};
     h[q] = __builtin_bit_cast(uint32_t, hp);
     l[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
@@ -107,10 +116,10 @@ __device__ __forceinline__ void split8_h2(const float* v, float s, u32x4& h, u32
 // one value (the weight-gradient kernel's one-pixel margins): the same rounding sequence
 template <bool LO_UP = false>
 __device__ __forceinline__ void split1_h2(float v, float s, uint32_t& hp, uint32_t& lp) {
+  constexpr bool UP = LO_UP && H2_LO_UP_ON;
   const float a0 = v * s;
   const _Float16 hh = (_Float16)a0;
-  float r0 = a0 - (float)hh;
-  if (LO_UP && H2_LO_UP_ON) r0 *= H2_LO_UP;
+  const float r0 = UP ? __builtin_fmaf((float)hh, -H2_LO_UP, v * (s * H2_LO_UP)) : __builtin_fmaf((float)hh, -1.f, a0);
   hp = __builtin_bit_cast(unsigned short, hh);
   lp = __builtin_bit_cast(unsigned short, (_Float16)r0);
 }
