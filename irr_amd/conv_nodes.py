@@ -26,9 +26,18 @@ def wgrad_param(x, gy, weight, bias, stride: int, dil: int, want_bias: bool = Tr
     if routed is not None:
         gwv, gbv = routed
         keep = (x, gy) if (x_amax is None or gy_amax is None) else (x, gy, x_amax.slots, gy_amax.slots)
-        _c.SIDE.launch(lambda: conv_wgrad(x, gy, weight.shape, stride, dil, gw=gwv, gbias=gbv if want_bias else None,
-                                       alpha=alpha, defer=_c.SIDE.batch, x_amax=x_amax, gy_amax=gy_amax), keep,
-                    (weight, bias if (want_bias and gbv is not None) else None), gw=gwv)
+
+        def fn():
+            if _c._CHECK_FINITE == "slots" and x_amax is not None and gy_amax is not None:
+                # diagnosis (NOTES C.5 / D.2): what THIS launch sees on the stream it runs on -- operand magnitudes against their slots
+                inf = float("inf")
+                for tag, t, a in (("x", x, x_amax), ("gy", gy, gy_amax)):
+                    _c._FINITE_LOG.append((f"wgrad {tag} {tuple(t.shape)} -> w {tuple(weight.shape)}", torch.linalg.vector_norm(t, ord=inf),
+                                           a.slots[a.first:a.first + a.n].max()))
+            conv_wgrad(x, gy, weight.shape, stride, dil, gw=gwv, gbias=gbv if want_bias else None,
+                       alpha=alpha, defer=_c.SIDE.batch, x_amax=x_amax, gy_amax=gy_amax)
+
+        _c.SIDE.launch(fn, keep, (weight, bias if (want_bias and gbv is not None) else None), gw=gwv)
         return None, None
     if acc is not None:
         gw, gb = acc
