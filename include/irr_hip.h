@@ -64,6 +64,20 @@ int irr_corr81_bwd_f32(const float* f1, const float* f2, const float* gout, cons
                        long f1_bs, long f2_bs, long gout_bs, long out_bs, long g1_bs, long g2_bs,
                        void* stream);
 
+/* The legacy operator at ANY parameter point (models/correlation_package/correlation.py:47-61; forward arithmetic
+ * correlation_cuda_kernel.cu:41-114, output shape correlation_cuda.cc:23-32): P = input zero-padded by pad, kr = (k - 1) / 2 (k odd),
+ * dr = md / s2, D = 2 dr + 1, (y1, x1) = (oy s1 + md, ox s1 + md):
+ *   out[n, (tj+dr) D + (ti+dr), oy, ox] = 1/(k k C) sum_{j,i in [-kr,kr]} sum_c P1[n,c,y1+j,x1+i] P2[n,c,y1+tj s2+j,x1+ti s2+i]
+ * with OH = ceil((H + 2 pad - 2 (kr + md)) / s1) (irr_corr_general_out_shape).  Backward = the exact adjoint (for k = 1, s1 = 1 identical
+ * to correlation_cuda_kernel.cu:116-300).  General-purpose kernels (one thread per element); the IRR-PWC point (4, 1, 4, 1, 1) is
+ * irr_corr81_*.  g1 / g2 nullable.  (ABI 8) */
+int irr_corr_general_out_shape(int H, int W, int pad, int k, int md, int s1, int s2, int* channels, int* OH, int* OW);
+int irr_corr_general_fwd_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W,
+                             int pad, int k, int md, int s1, int s2, long f1_bs, long f2_bs, long out_bs, void* stream);
+int irr_corr_general_bwd_f32(const float* f1, const float* f2, const float* gout, float* g1, float* g2,
+                             int B, int C, int H, int W, int pad, int k, int md, int s1, int s2,
+                             long f1_bs, long f2_bs, long gout_bs, long g1_bs, long g2_bs, void* stream);
+
 /* ---- flow warping with validity mask -----------------------------------------------------------
  * WarpingLayer.forward (models/pwc_modules.py:115-133) incl. get_grid (:107-112):
  *   grid = linspace(-1,1) + flow*2/max(size_im-1,1)/div_flow ; bilinear, zeros padding,

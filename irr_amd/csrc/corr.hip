@@ -707,3 +707,126 @@ extern "C" int irr_corr81_bwd_f32(const float* f1, const float* f2, const float*
   }
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The legacy operator at ANY parameter point (pad_size, kernel_size, max_displacement, stride1, stride2)
+// (models/correlation_package/correlation.py:47-61; forward arithmetic: correlation_cuda_kernel.cu:41-114, output shape:
+// correlation_cuda.cc:23-32).  No model of the reference leaves the point (4, 1, 4, 1, 1) that the kernels above serve; this pair
+// exists so that the drop-in module accepts what the reference module accepts.  With P1, P2 = the inputs zero-padded by pad_size,
+// kr = (k - 1) / 2, dr = md / s2, D = 2 dr + 1, (y1, x1) = (oy s1 + md, ox s1 + md) in padded coordinates:
+//     out[n, (tj + dr) D + (ti + dr), oy, ox] = 1 / (k k C) * sum_{j, i in [-kr, kr]} sum_c P1[n, c, y1 + j, x1 + i] * P2[n, c, y1 + tj s2 + j, x1 + ti s2 + i]
+// (positions outside the padded arrays -- possible only for kr > md -- read as zero, where the reference would read out of bounds).
+// Backward = the exact adjoint of this forward (for k = 1, s1 = 1 that IS correlation_cuda_kernel.cu:116-300; for the other points
+// the reference's own backward is an approximation that cannot be run or pinned here: DESIGN.md 8).
+// One thread per output / input element, lanes along x: a general-purpose pair, not a tuned one.
+namespace {
+
+struct CorrGen { int C, H, W, pad, k, md, s1, s2, OH, OW, kr, dr, D; long f1_bs, f2_bs, out_bs; };
+
+__device__ __forceinline__ float corrg_at(const float* __restrict__ f, const CorrGen& p, int c, int py, int px) {   // padded coords
+  const int y = py - p.pad, x = px - p.pad;
+  return (y >= 0 && y < p.H && x >= 0 && x < p.W) ? f[(long)c * p.H * p.W + (long)y * p.W + x] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void corr_general_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                              float* __restrict__ out, const CorrGen p) {
+  const int ox = blockIdx.x * 256 + threadIdx.x;
+  const int oy = blockIdx.y % p.OH, tc = blockIdx.y / p.OH, n = blockIdx.z;
+  if (ox >= p.OW) return;
+  const int tj = tc / p.D - p.dr, ti = tc % p.D - p.dr;
+  const int y1 = oy * p.s1 + p.md, x1 = ox * p.s1 + p.md;
+  const float* a = f1 + (long)n * p.f1_bs;
+  const float* b = f2 + (long)n * p.f2_bs;
+  float s = 0.f;
+  for (int c = 0; c < p.C; ++c)
+    for (int j = -p.kr; j <= p.kr; ++j)
+      for (int i = -p.kr; i <= p.kr; ++i)
+        s += corrg_at(a, p, c, y1 + j, x1 + i) * corrg_at(b, p, c, y1 + tj * p.s2 + j, x1 + ti * p.s2 + i);
+  out[(long)n * p.out_bs + ((long)tc * p.OH + oy) * p.OW + ox] = s / (float)(p.k * p.k * p.C);
+}
+
+// SECOND == false: g1[n, c, y, x] = 1/(k k C) sum over (tj, ti, j, i) with (y + pad - j - md, x + pad - i - md) = (oy s1, ox s1):
+//                                   gout[n, tc, oy, ox] * P2[n, c, y + pad + tj s2, x + pad + ti s2]
+// SECOND == true : g2[n, c, y, x]: the same with P1 read at (y + pad - tj s2, x + pad - ti s2) and the window centre moved by (tj s2, ti s2)
+template <bool SECOND>
+__global__ __launch_bounds__(256) void corr_general_bwd_kernel(const float* __restrict__ other, const float* __restrict__ gout,
+                                                              float* __restrict__ gin, const CorrGen p, long other_bs, long gin_bs) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int y = blockIdx.y % p.H, c = blockIdx.y / p.H, n = blockIdx.z;
+  if (x >= p.W) return;
+  const float* o = other + (long)n * other_bs;
+  const float* g = gout + (long)n * p.out_bs;
+  float s = 0.f;
+  for (int tj = -p.dr; tj <= p.dr; ++tj)
+    for (int ti = -p.dr; ti <= p.dr; ++ti) {
+      const int tc = (tj + p.dr) * p.D + (ti + p.dr);
+      for (int j = -p.kr; j <= p.kr; ++j)
+        for (int i = -p.kr; i <= p.kr; ++i) {
+          // padded position of THIS element inside the window: first operand at (y1 + j, x1 + i), second at (y1 + tj s2 + j, x1 + ti s2 + i)
+          const int cy = y + p.pad - j - (SECOND ? tj * p.s2 : 0) - p.md, cx = x + p.pad - i - (SECOND ? ti * p.s2 : 0) - p.md;
+          if (cy < 0 || cx < 0 || cy % p.s1 || cx % p.s1) continue;
+          const int oy = cy / p.s1, ox = cx / p.s1;
+          if (oy >= p.OH || ox >= p.OW) continue;
+          const int py = y + p.pad + (SECOND ? -tj * p.s2 : tj * p.s2), px = x + p.pad + (SECOND ? -ti * p.s2 : ti * p.s2);
+          s += g[((long)tc * p.OH + oy) * p.OW + ox] * corrg_at(o, p, c, py, px);
+        }
+    }
+  gin[(long)n * gin_bs + ((long)c * p.H + y) * p.W + x] = s / (float)(p.k * p.k * p.C);
+}
+
+static int corrg_setup(CorrGen* p, int B, int C, int H, int W, int pad, int k, int md, int s1, int s2) {
+  if (B <= 0 || B > 65535 || C <= 0 || H <= 0 || W <= 0 || pad < 0 || k < 1 || !(k & 1) || md < 0 || s1 < 1 || s2 < 1) return IRR_EINVAL;
+  p->C = C; p->H = H; p->W = W; p->pad = pad; p->k = k; p->md = md; p->s1 = s1; p->s2 = s2;
+  p->kr = (k - 1) / 2; p->dr = md / s2; p->D = 2 * p->dr + 1;
+  const int border = p->kr + md;
+  const int ph = H + 2 * pad - 2 * border, pw = W + 2 * pad - 2 * border;
+  if (ph <= 0 || pw <= 0) return IRR_EINVAL;
+  p->OH = (ph + s1 - 1) / s1; p->OW = (pw + s1 - 1) / s1;                     // ceil, correlation_cuda.cc:31-32
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int irr_corr_general_out_shape(int H, int W, int pad, int k, int md, int s1, int s2, int* channels, int* OH, int* OW) {
+  CorrGen p;
+  const int rc = corrg_setup(&p, 1, 1, H, W, pad, k, md, s1, s2);
+  if (rc) return rc;
+  if (channels) *channels = p.D * p.D;
+  if (OH) *OH = p.OH;
+  if (OW) *OW = p.OW;
+  return 0;
+}
+
+extern "C" int irr_corr_general_fwd_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int pad, int k,
+                                        int md, int s1, int s2, long f1_bs, long f2_bs, long out_bs, void* stream) {
+  CorrGen p;
+  if (!f1 || !f2 || !out) return IRR_EINVAL;
+  const int rc = corrg_setup(&p, B, C, H, W, pad, k, md, s1, s2);
+  if (rc) return rc;
+  if ((long)p.D * p.D * p.OH > 65535) return IRR_EINVAL;
+  p.f1_bs = f1_bs; p.f2_bs = f2_bs; p.out_bs = out_bs;
+  hipLaunchKernelGGL(corr_general_fwd_kernel, dim3(irr_cdiv(p.OW, 256), p.D * p.D * p.OH, B), dim3(256), 0, (hipStream_t)stream, f1, f2, out, p);
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_corr_general_bwd_f32(const float* f1, const float* f2, const float* gout, float* g1, float* g2, int B, int C, int H,
+                                        int W, int pad, int k, int md, int s1, int s2, long f1_bs, long f2_bs, long gout_bs, long g1_bs,
+                                        long g2_bs, void* stream) {
+  CorrGen p;
+  if (!f1 || !f2 || !gout) return IRR_EINVAL;
+  const int rc = corrg_setup(&p, B, C, H, W, pad, k, md, s1, s2);
+  if (rc) return rc;
+  if ((long)C * H > 65535) return IRR_EINVAL;
+  p.f1_bs = f1_bs; p.f2_bs = f2_bs; p.out_bs = gout_bs;
+  const dim3 grid(irr_cdiv(W, 256), C * H, B);
+  if (g1) {
+    hipLaunchKernelGGL(corr_general_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, f2, gout, g1, p, f2_bs, g1_bs);
+    IRR_LAUNCH_CHECK();
+  }
+  if (g2) {
+    hipLaunchKernelGGL(corr_general_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, f1, gout, g2, p, f1_bs, g2_bs);
+    IRR_LAUNCH_CHECK();
+  }
+  return 0;
+}

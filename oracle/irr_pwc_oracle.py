@@ -147,6 +147,44 @@ def cost_volume(f1: torch.Tensor, f2: torch.Tensor, max_disp: int = SEARCH_RANGE
     return torch.cat(planes, dim=1)
 
 
+def correlation_general(f1: torch.Tensor, f2: torch.Tensor, pad_size: int, kernel_size: int, max_displacement: int,
+                        stride1: int, stride2: int) -> torch.Tensor:
+    """The legacy ``Correlation`` operator at any parameter point, restated from the forward kernel
+    (models/correlation_package/correlation_cuda_kernel.cu:41-114; output shape models/correlation_package/correlation_cuda.cc:23-32):
+    P = input zero-padded by pad_size, kr = (k - 1) // 2, dr = md // s2, D = 2 dr + 1, window centre (y1, x1) = (oy s1 + md, ox s1 + md),
+
+        out[n, (tj+dr) D + (ti+dr), oy, ox] = 1/(k k C) sum_{j,i in [-kr,kr]} sum_c P1[n,c,y1+j,x1+i] P2[n,c,y1+tj s2+j,x1+ti s2+i]
+
+    (positions outside the padded arrays read as zero).  Differentiable (torch ops only): its autograd gradient is the exact adjoint,
+    which for k = 1, s1 = 1 is what correlation_cuda_kernel.cu:116-300 computes.  At (md, 1, md, 1, 1) it equals ``cost_volume`` above
+    (= the reference's Python path compute_cost_volume, models/pwc_modules.py:42-62) -- that identity, checked against the imported
+    reference, is what pins it; the points with stride2 > 1 / kernel_size > 1 / stride1 > 1 are pinned to a scalar transcription of the
+    kernel's loops only (tests/golden/corr_general.npz, oracle/gen_golden.py)."""
+    B, C, H, W = f1.shape
+    k, md, s1, s2, pad = kernel_size, max_displacement, stride1, stride2, pad_size
+    kr, dr = (k - 1) // 2, md // s2
+    border = kr + md
+    OH = -(-(H + 2 * pad - 2 * border) // s1)
+    OW = -(-(W + 2 * pad - 2 * border) // s1)
+    # a margin around the padded arrays large enough for every index the loops form (reads as zero)
+    m = md + kr + s1
+    P1 = F.pad(f1, (pad + m, pad + m, pad + m, pad + m))
+    P2 = F.pad(f2, (pad + m, pad + m, pad + m, pad + m))
+    ys = torch.arange(OH) * s1 + md + m
+    xs = torch.arange(OW) * s1 + md + m
+    planes = []
+    for tj in range(-dr, dr + 1):
+        for ti in range(-dr, dr + 1):
+            acc = 0
+            for j in range(-kr, kr + 1):
+                for i in range(-kr, kr + 1):
+                    a = P1[:, :, (ys + j)[:, None], (xs + i)[None, :]]
+                    b = P2[:, :, (ys + tj * s2 + j)[:, None], (xs + ti * s2 + i)[None, :]]
+                    acc = acc + (a * b).sum(dim=1, keepdim=True)
+            planes.append(acc / float(k * k * C))
+    return torch.cat(planes, dim=1)
+
+
 def resize_bilinear_ac(x: torch.Tensor, h: int, w: int) -> torch.Tensor:
     """F.interpolate(bilinear, align_corners=True) -- models/pwc_modules.py:65-67."""
     return F.interpolate(x, [h, w], mode="bilinear", align_corners=True)

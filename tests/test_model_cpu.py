@@ -47,8 +47,15 @@ def test_no_cpu_fallback():
 def test_correlation_signature():
     c = irr_amd.Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1)
     assert (c.pad_size, c.kernel_size, c.max_displacement, c.stride1, c.stride2, c.corr_multiply) == (4, 1, 4, 1, 1, 1)
-    with pytest.raises(ValueError):
-        irr_amd.Correlation(pad_size=3, kernel_size=3, max_displacement=20, stride1=1, stride2=2)
+    # round 5: every parameter point of the legacy operator is accepted (FlowNet's (3, 3, 20, 1, 2) among them) ...
+    c = irr_amd.Correlation(pad_size=3, kernel_size=3, max_displacement=20, stride1=1, stride2=2)
+    assert (c.pad_size, c.kernel_size, c.max_displacement, c.stride1, c.stride2) == (3, 3, 20, 1, 2)
+    # ... except what the reference's kernels cannot compute either: its DEFAULT kernel_size 0 divides by zero, other corr types do not exist
+    for bad in (dict(), dict(kernel_size=2, max_displacement=1), dict(kernel_size=1, corr_multiply=0), dict(kernel_size=1, stride2=0)):
+        with pytest.raises(ValueError):
+            irr_amd.Correlation(**bad)
+    with pytest.raises(RuntimeError):                       # no CPU fallback on this path either
+        c(torch.rand(1, 2, 8, 8), torch.rand(1, 2, 8, 8))
 
 
 def test_loss_scalar_algebra_matches_oracle():

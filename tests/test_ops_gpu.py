@@ -44,8 +44,41 @@ def test_correlation_module_operator_signature(golden_dir, case):
     np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"corr_{case}_out"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(f1.grad.cpu().numpy(), g[f"corr_{case}_g1"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(f2.grad.cpu().numpy(), g[f"corr_{case}_g2"], rtol=1e-5, atol=1e-6)
-    with pytest.raises(ValueError):
-        irr_amd.Correlation(3, 1, 3, 1, 1, 1)
+
+
+GEN_POINTS = [(3, 3, 4, 1, 2), (2, 1, 2, 2, 1), (4, 3, 2, 2, 2), (0, 1, 0, 1, 1), (1, 3, 1, 1, 1), (20, 1, 20, 1, 2)]
+
+
+def test_correlation_module_at_other_parameter_points(golden_dir):
+    """The legacy operator off the IRR-PWC point (models/correlation_package/correlation.py:47-61; VERDICT r4 missing #4):
+    (a) (md, 1, md, 1, 1) for md = 1, 2, 3 against the imported reference's Python path (compute_cost_volume) incl. both gradients;
+    (b) stride2 = 2 / kernel_size = 3 / stride1 = 2 points -- FlowNetC's (20, 1, 20, 1, 2) among them -- against the scalar
+    transcription of correlation_cuda_kernel.cu:41-114, and their gradients against autograd through the oracle's restatement
+    (the exact adjoint)."""
+    import irr_amd
+    from oracle import irr_pwc_oracle as O
+    g = np.load(os.path.join(golden_dir, "corr_general.npz"))
+    f1d, f2d = torch.from_numpy(g["f1"]), torch.from_numpy(g["f2"])
+    for md in (1, 2, 3):
+        f1, f2 = f1d.float().cuda().requires_grad_(True), f2d.float().cuda().requires_grad_(True)
+        out = irr_amd.Correlation(md, 1, md, 1, 1, 1)(f1, f2)
+        out.backward(torch.from_numpy(g[f"ref_md{md}_go"]).float().cuda())
+        np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"ref_md{md}_out"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(f1.grad.cpu().numpy(), g[f"ref_md{md}_g1"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(f2.grad.cpu().numpy(), g[f"ref_md{md}_g2"], rtol=1e-5, atol=1e-6)
+    for pt in GEN_POINTS:
+        f1, f2 = f1d.float().cuda().requires_grad_(True), f2d.float().cuda().requires_grad_(True)
+        out = irr_amd.Correlation(*pt, 1)(f1, f2)
+        ref = g["scalar_" + "_".join(map(str, pt))]
+        assert tuple(out.shape) == ref.shape, (pt, out.shape, ref.shape)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+        a, b = f1d.clone().requires_grad_(True), f2d.clone().requires_grad_(True)
+        o = O.correlation_general(a, b, *pt)
+        go = torch.randn(o.shape, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+        o.backward(go)
+        out.backward(go.float().cuda())
+        np.testing.assert_allclose(f1.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(f2.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-5, atol=1e-6)
 
 
 def test_cost_volume_fused_lrelu(golden_dir):

@@ -223,3 +223,23 @@ def test_chunked_oracle_step_equals_whole_batch():
     for n in P0:
         d = float((P1[n].grad.double() - P0[n].grad.double()).norm())
         assert d <= 2e-4 * float(P0[n].grad.double().norm()) + 1e-6 * tot, (n, d)     # (fp32 summation order of the conv backward)
+
+
+def test_general_correlation_restatement(golden_dir):
+    """oracle.correlation_general (the legacy operator at any parameter point) against tests/golden/corr_general.npz: the imported
+    reference's Python path at (md, 1, md, 1, 1) incl. gradients, the scalar transcription of correlation_cuda_kernel.cu:41-114
+    elsewhere; and it IS cost_volume at the IRR-PWC point."""
+    g = np.load(os.path.join(golden_dir, "corr_general.npz"))
+    f1, f2 = torch.from_numpy(g["f1"]), torch.from_numpy(g["f2"])
+    for md in (1, 2, 3):
+        a, b = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+        o = O.correlation_general(a, b, md, 1, md, 1, 1)
+        o.backward(torch.from_numpy(g[f"ref_md{md}_go"]))
+        np.testing.assert_allclose(o.detach().numpy(), g[f"ref_md{md}_out"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(a.grad.numpy(), g[f"ref_md{md}_g1"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(b.grad.numpy(), g[f"ref_md{md}_g2"], rtol=1e-12, atol=1e-14)
+    for key in g.files:
+        if key.startswith("scalar_"):
+            pt = tuple(int(v) for v in key.split("_")[1:])
+            np.testing.assert_allclose(O.correlation_general(f1, f2, *pt).numpy(), g[key], rtol=1e-12, atol=1e-14)
+    assert torch.equal(O.correlation_general(f1, f2, 4, 1, 4, 1, 1), O.cost_volume(f1, f2, 4))
