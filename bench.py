@@ -48,7 +48,7 @@ X3_PLANES = {1: 352, 2: 616, 3: 640}
 def kernel_name(var):
     """variant code of irr_amd.conv's KernelTimer -> (the kernel's template instantiation SPELLED AS rocprofv3 PRINTS IT, so that the
     line's ``roofline.kernel`` is a row of profiles/*_kernel_stats.txt; its MFMA roof in fp32 TFLOP/s; "hbm" | "mfma" = what bounds it)"""
-    if var >= 100000 and 9010 <= var % 100000 <= 9013:          # the streaming 32-channel kernel, one instantiation per epilogue form
+    if var >= 100000 and 9010 <= var % 100000 <= 9014:          # the streaming 32-channel kernel, one instantiation per epilogue form
         np_ = 2 if var >= 200000 else 3
         return (f"conv_x3s_kernel<{var % 10}, {np_}>", H2_PEAK_TFLOPS if np_ == 2 else X3_PEAK_TFLOPS, "hbm")
     if var >= 200000:

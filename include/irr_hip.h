@@ -315,6 +315,22 @@ int irr_conv2d_fwd_h2_dual(const float* x, const void* wq, const float* bias, co
                            int B, int Cin, int H, int W, int Cout, int dil,
                            long x_bs, long y_bs, long res_bs, long y2_bs, int lrelu, float alpha,
                            const float* x_amax, int n_amax, float* y_amax, void* stream);
+/* ABI 9 -- LeakyReLU' masks of the streaming 32-channel kernel as BITS.  For problems with irr_conv2d_h2_eligible == 9001 and
+ * Cout <= 32 (the OccUpsampleNetwork layers at 1/2 and full resolution, models/irr_modules.py:30-56; anything else: IRR_EINVAL):
+ * irr_conv2d_fwd_h2 where
+ *   bits_out  (forward of a conv + LeakyReLU; res / accumulate must be absent): additionally receives one bit per output element,
+ *             (y > 0), irr_conv2d_x3s_mask_words(B, H, W) 32-bit words in the kernel's own tile order (opaque to the caller);
+ *   mask_bits (data gradient): gx[:, :nmask] *= LeakyReLU'(.) taken from the bits a forward launch of the SAME (B, H, W) wrote,
+ *             instead of re-reading the fp32 activation (mask of irr_conv2d_fwd_h2): one dword per thread and tile instead of
+ *             eight 16-byte loads -- the backward of these layers is bound by HBM bytes.
+ * Exactly one of the two is non-NULL. */
+long irr_conv2d_x3s_mask_words(int B, int H, int W);
+int irr_conv2d_fwd_h2_bits(const float* x, const void* wq, const float* bias, const float* res, float* y,
+                           int B, int Cin, int H, int W, int Cout, int dil,
+                           long x_bs, long y_bs, long res_bs,
+                           int lrelu, float alpha, int accumulate,
+                           const void* mask_bits, int nmask, void* bits_out,
+                           const float* x_amax, int n_amax, float* y_amax, void* stream);
 int irr_conv2d_wgrad_h2_robust_side(int B, int Cin, int H, int W, int Cout, int dil);
 int irr_conv2d_wgrad_h2(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                         int B, int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs,

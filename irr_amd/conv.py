@@ -105,10 +105,11 @@ def set_math(name: str) -> None:
 _X3_ENV_DONE = [False]
 
 
-def x3s_variant(h2: bool, res, accumulate: bool, masked: bool, dual: bool = False) -> int:
+def x3s_variant(h2: bool, res, accumulate: bool, masked: bool, dual: bool = False, bits: bool = False) -> int:
     """KernelTimer key of a conv_x3s_kernel<EPI, NP> launch: 1/2 00000 + 9010 + EPI (the launcher's choice, csrc/conv_x3.hip:
-    2 = accumulate / mask, 3 = second output, 1 = residual, 0 = plain) -- rocprofv3 lists the instantiations separately, so does the timer"""
-    epi = 2 if (accumulate or masked) else (3 if dual else 1) if res is not None else 0
+    4 = mask read as bits, 2 = accumulate / mask, 3 = second output, 1 = residual, 0 = plain) -- rocprofv3 lists the instantiations
+    separately, so does the timer"""
+    epi = 4 if bits else 2 if (accumulate or masked) else (3 if dual else 1) if res is not None else 0
     return (200000 if h2 else 100000) + 9010 + epi
 
 
@@ -150,6 +151,19 @@ def h2_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, di
     code = int(hip.lib().irr_conv2d_h2_eligible(B, cin, H, W, cout, k, stride, dil))
     return 0 if (code == 9001 and not X3S_H2) else code
 
+
+def x3s_bits_ok(B: int, cin: int, H: int, W: int, cout: int) -> bool:
+    """the 3x3 / stride-1 / dilation-1 layer runs on the fp16x2 streaming kernel with one co-tile: its LeakyReLU' mask can travel as
+    bits (irr_conv2d_fwd_h2_bits; IRR_X3S_BITS=0: A/B switch, fp32 activations as masks)"""
+    return X3S_BITS and cout <= 32 and h2_code(B, cin, H, W, cout, 3, 1, 1) == 9001
+
+
+def x3s_mask_words(B: int, H: int, W: int) -> int:
+    return int(hip.lib().irr_conv2d_x3s_mask_words(B, H, W))
+
+
+X3S_BITS = os.environ.get("IRR_X3S_BITS", "1") != "0"
+_X3S_BITS_NOREAD = bool(os.environ.get("IRR_X3S_BITS_NOREAD"))      # diagnosis: the forward writes the bits, the data gradients keep the fp32 masks
 
 from .conv_pack import packed_weights_h2, packed_weights_x3  # noqa: E402,F401
 from .conv_amax import Amax, measure as amax_measure  # noqa: E402,F401
@@ -222,11 +236,13 @@ def _h2_args(x3_args, x, x_amax, y_amax):
 def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, dil: int,
                  lrelu: bool, out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                  alpha: float = 1.0, accumulate: bool = False, real_cin: Optional[int] = None,
-                 x_amax: Optional[Amax] = None, y_amax: Optional[Amax] = None) -> torch.Tensor:
+                 x_amax: Optional[Amax] = None, y_amax: Optional[Amax] = None, bits_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = [res +] alpha * act(conv(x, weight) + bias)   (accumulate: out += ...).
     real_cin: the layer's true input-channel count when x / weight are zero-padded copies (KernelTimer prices algorithmic FLOPs).
     x_amax: slots that bound |x| (MATH == "h2"; measured here when absent).  y_amax: a zeroed slot that holds max |out| after the
-    call whatever kernel family ran (the h2 launch folds it in its epilogue, any other route costs one pass over out)."""
+    call whatever kernel family ran (the h2 launch folds it in its epilogue, any other route costs one pass over out).
+    bits_out: int32 tensor of x3s_mask_words(B, H, W) words that receives (out > 0) per element for conv_dgrad(mask_bits=...) -- the
+    caller has checked x3s_bits_ok for this layer."""
     # (the LeakyReLU'-mask epilogue of the kernel is only used by conv_dgrad)
     B, cin, H, W = x.shape
     cout, cin_w, k, _ = weight.shape
@@ -255,6 +271,11 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
         measure_y = h2 and code == 9001 and y_amax is not None and _X3S_NO_FUSED_AMAX
         if h2:
             args, _xa = _h2_args(args, x, x_amax, None if measure_y else y_amax)
+        if bits_out is not None:
+            if not (h2 and code == 9001 and res is None and not accumulate):
+                raise ValueError("bits_out: only the plain forward of the fp16x2 streaming kernel writes bit masks")
+            # (irr_conv2d_fwd_h2's tuple: ..., accumulate, mask, mask_bs, nmask, x_amax, n, y_amax, stream -> ..., accumulate, mask_bits, nmask, bits_out, ...)
+            args = ("irr_conv2d_fwd_h2_bits",) + tuple(args[1:-7]) + (None, 0, bits_out.data_ptr()) + tuple(args[-4:])
         variant = x3s_variant(h2, res, accumulate, False) if code == 9001 else (200000 if h2 else 100000) + code
         LAUNCHES["fwd_x3s" if code == 9001 else "fwd_h2" if h2 else "fwd_x3"] += 1          # (fwd_x3s: the streaming kernel, either form)
     else:
@@ -322,13 +343,16 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                gx: Optional[torch.Tensor] = None, accumulate: bool = False,
                mask: Optional[torch.Tensor] = None, nmask: int = 0,
                res: Optional[torch.Tensor] = None, alpha: float = 1.0, real_cin: Optional[int] = None,
-               gy_amax: Optional[Amax] = None, gx_amax: Optional[Amax] = None, amax_channels: Optional[int] = None) -> torch.Tensor:
+               gy_amax: Optional[Amax] = None, gx_amax: Optional[Amax] = None, amax_channels: Optional[int] = None,
+               mask_bits: Optional[torch.Tensor] = None) -> torch.Tensor:
     """gx (+)= conv_transpose(gy, weight); gy must already carry the activation derivative.
     mask/nmask: afterwards gx[:, :nmask] *= LeakyReLU'(mask[:, :nmask]) in the same launch (mask = the saved
     activation that produced this conv's input), i.e. gx comes out as a PRE-activation gradient.
     res/alpha: gx = res + alpha * conv_transpose(...) (residual branches: the skip gradient is added in the epilogue).
     gy_amax / gx_amax: as x_amax / y_amax of conv_forward (gx_amax bounds the COMPLETE gx: res, accumulate and mask included).
-    amax_channels (Cout <= 2 heads only): gx_amax bounds gx[:, :amax_channels] instead of all of gx."""
+    amax_channels (Cout <= 2 heads only): gx_amax bounds gx[:, :amax_channels] instead of all of gx.
+    mask_bits (with mask / nmask): the bits conv_forward(bits_out=...) wrote for `mask`; used instead of the fp32 tensor when this data
+    gradient runs on the fp16x2 streaming kernel (both layers passed x3s_bits_ok), ignored otherwise."""
     B, cout, oh, ow = gy.shape
     cout_w, cin, k, _ = weight.shape
     assert cout == cout_w
@@ -355,6 +379,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         weight = torch.cat([weight.detach(), torch.zeros_like(weight.detach())], dim=0)
         cout = 2
     h2 = False
+    use_bits = False
     if stride == 1 and cout >= 2:
         code = x3_code(B, cout, oh, ow, cin, k, 1, dil)
         h2 = bool(code) and bool(h2_code(B, cout, oh, ow, cin, k, 1, dil))
@@ -365,7 +390,10 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                     int(accumulate), *margs, hip.stream())
             if h2:
                 args, _ga = _h2_args(args, gy, gy_amax, None if (code == 9001 and _X3S_NO_FUSED_AMAX) else gx_amax)
-            variant = (x3s_variant(h2, res, accumulate, mask is not None and nmask > 0) if code == 9001
+            use_bits = mask_bits is not None and margs[2] > 0 and h2 and code == 9001 and cin <= 32 and not _X3S_BITS_NOREAD
+            if use_bits:
+                args = ("irr_conv2d_fwd_h2_bits",) + tuple(args[1:-7]) + (mask_bits.data_ptr(), margs[2], None) + tuple(args[-4:])
+            variant = (x3s_variant(h2, res, accumulate, mask is not None and nmask > 0, bits=use_bits) if code == 9001
                        else (200000 if h2 else 100000) + code)
             LAUNCHES["dgrad_x3s" if code == 9001 else "dgrad_h2" if h2 else "dgrad_x3"] += 1
         else:
@@ -382,7 +410,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                 variant = hip.lib().irr_conv2d_fwd_variant(B, cin, H, W, k)
             TIMER.wrap(variant, 2.0 * B * H * W * cout * (real_cin or cin) * k * k, lambda: _call_conv(args), "dgrad",
                        nbytes=_map_bytes(B, oh, ow, cout) + _map_bytes(B, H, W, cin * (1 + (res is not None) + bool(accumulate))
-                                                                       + (min(nmask, cin) if mask is not None else 0)))
+                                                                       + ((1 if use_bits else min(nmask, cin)) if mask is not None else 0)))
     elif stride == 2 and k == 3 and dil == 1 and H == 2 * oh and W == 2 * ow and cout >= 2 and cin > S2_GATHER_MAX_CIN:
         # transposed stride-2 conv == stride-1 conv (flipped weights) of the zero-interleaved gradient
         z = torch.zeros(B, cout, H, W, device=gy.device, dtype=torch.float32)

@@ -524,6 +524,7 @@ def conv_chain(x, layers, res=None):
 # autograd: OccUpsampleNetwork (models/irr_modules.py:30-56) as ONE node
 # ----------------------------------------------------------------------------------------------
 
+_KEEP_LOG = [] if os.environ.get("IRR_OCCUP_KEEP_LOG") else None      # diagnosis: (name, tensor) of the node's gradient maps, tools/lane_race_probe.py
 _LANE_HOLD_OCCUP = os.environ.get("IRR_LANE_HOLD_OCCUP", "0") != "0"      # lane schedule (a) of VERDICT r4 item 4, profiles/r5_lane_schedules.txt
 
 
@@ -559,11 +560,19 @@ class _OccUpsampleFn(hip.Function):
         sl = (lambda i: S.sub(i)) if S is not None else (lambda i: None)
         cat_channels_into(x_in, (occ_up,) + tuple(parts[1:]), zero_tail=cpad - cin, amax=sl(0))
         w_first = _padded_cin(w_init, cpad) if cpad > cin else w_init
-        x_init = conv_forward(x_in, w_first, b_init, 1, 1, True, real_cin=cin, x_amax=sl(0), y_amax=sl(1))
+        # LeakyReLU' masks as bits (round 5): x_init and t_1..t_3 are re-read by the backward's masked data gradients ONLY for the sign
+        # of each element -- where producer and consumer both run on the fp16x2 streaming kernel the forward launch writes one bit per
+        # element beside its output and the data gradient reads 1/32 of the bytes (bits[0]: x_init, bits[1 + i]: t_(i+1))
+        nch = w_r0.shape[0]
+        use_bits = (S is not None and _c.x3s_bits_ok(B, cpad, H, W, nch) and _c.x3s_bits_ok(B, nch, H, W, nch)
+                    and w_r0.shape[1] == nch and tuple(w_r1.shape[:2]) == (nch, nch))
+        bits = ([torch.empty(_c.x3s_mask_words(B, H, W), dtype=torch.int32, device=x_in.device) for _ in range(4)]
+                if use_bits else [None] * 4)
+        x_init = conv_forward(x_in, w_first, b_init, 1, 1, True, real_cin=cin, x_amax=sl(0), y_amax=sl(1), bits_out=bits[0])
         xs = [x_init]
         ts = []
         for i in range(3):
-            t = conv_forward(xs[-1], w_r0, b_r0, 1, 1, True, x_amax=sl(1 + i), y_amax=sl(5 + i))
+            t = conv_forward(xs[-1], w_r0, b_r0, 1, 1, True, x_amax=sl(1 + i), y_amax=sl(5 + i), bits_out=bits[1 + i])
             ts.append(t)
             xs.append(conv_forward(t, w_r1, b_r1, 1, 1, False, res=xs[-1], alpha=mul_const, x_amax=sl(5 + i), y_amax=sl(2 + i)))
         e, x2 = conv_forward_skip(xs[-1], w_end, b_end, True, x_init, x_amax=sl(4))
@@ -579,7 +588,8 @@ class _OccUpsampleFn(hip.Function):
         ctx.widths = widths
         ctx.wobjs = (w_init, w_r0, w_r1, w_end, w_out)
         ctx.bobjs = (b_init, b_r0, b_r1, b_end, b_out)
-        ctx.save_for_backward(x_in, xs[0], xs[1], xs[2], xs[3], ts[0], ts[1], ts[2], e, x2, o)
+        ctx.use_bits = use_bits
+        ctx.save_for_backward(x_in, xs[0], xs[1], xs[2], xs[3], ts[0], ts[1], ts[2], e, x2, o, *(bits if use_bits else ()))
         return out
 
     @staticmethod
@@ -594,7 +604,8 @@ class _OccUpsampleFn(hip.Function):
 
     @staticmethod
     def _backward(ctx, g_out):
-        x_in, x0, x1, x2r, x3, t1, t2, t3, e, x2, o = ctx.saved_tensors
+        x_in, x0, x1, x2r, x3, t1, t2, t3, e, x2, o = ctx.saved_tensors[:11]
+        bits = list(ctx.saved_tensors[11:15]) if ctx.use_bits else [None] * 4
         w_init, w_r0, w_r1, w_end, w_out = ctx.wobjs
         b_init, b_r0, b_r1, b_end, b_out = ctx.bobjs
         mc = ctx.mul_const
@@ -643,7 +654,12 @@ class _OccUpsampleFn(hip.Function):
                 amax_measure(gpre_e, G.sub(0))
             gw_end, _ = wgrad_param_(x3, gpre_e, w_end, None, 1, 1, want_bias=False, x_amax=sl(4), gy_amax=gl(0))
         g_x = conv_dgrad(gpre_e, w_end, 1, 1, hw_, gy_amax=gl(0), gx_amax=gl(1))     # gradient w.r.t. x3
+        if _KEEP_LOG is not None:
+            _KEEP_LOG.extend([(f"occ_upsample backward {tuple(g_out.shape)} g_out", g_out), (f"occ_upsample backward gpre_o", gpre_o),
+                              (f"occ_upsample backward g_x2 (before the accumulate)", g_x2.clone())])
         def _slog(name, t, i):                                  # diagnosis (NOTES C.5), see forward
+            if _KEEP_LOG is not None:                           # (NOTES D.5: references only, no extra launches; read after the pass)
+                _KEEP_LOG.append((f"occ_upsample backward {tuple(t.shape)} {name}", t, (G.slots, G.first + i) if G is not None else None))
             if G is not None and _c._CHECK_FINITE == "slots":
                 _c._FINITE_LOG.append((f"occ_upsample backward {tuple(t.shape)} {name}", torch.linalg.vector_norm(t, ord=float("inf")),
                                        G.slots[G.first + i].clone()))
@@ -658,7 +674,8 @@ class _OccUpsampleFn(hip.Function):
         gxs = 1                                                 # slot of the running g_x
         for i in (2, 1, 0):
             wgrad_param_(ts[i], g_x, w_r1, b_r1, 1, 1, alpha=mc, acc=acc_r1, x_amax=sl(5 + i), gy_amax=gl(gxs))
-            gpre_t = conv_dgrad(g_x, w_r1, 1, 1, hw_, mask=ts[i], nmask=ts[i].shape[1], alpha=mc, gy_amax=gl(gxs), gx_amax=gl(2 + 2 * i))
+            gpre_t = conv_dgrad(g_x, w_r1, 1, 1, hw_, mask=ts[i], nmask=ts[i].shape[1], alpha=mc, gy_amax=gl(gxs), gx_amax=gl(2 + 2 * i),
+                                mask_bits=bits[1 + i])
             _slog(f"gpre_t{i}", gpre_t, 2 + 2 * i)
             wgrad_param_(xs[i], gpre_t, w_r0, b_r0, 1, 1, acc=acc_r0, x_amax=sl(1 + i), gy_amax=gl(2 + 2 * i))
             if i > 0:
@@ -668,7 +685,7 @@ class _OccUpsampleFn(hip.Function):
             else:
                 # x_0 = x_init: add the x2 skip gradient (accumulate into g_x2) and apply init_conv's LeakyReLU'
                 conv_dgrad(gpre_t, w_r0, 1, 1, hw_, gx=g_x2, accumulate=True, res=g_x, mask=x0, nmask=x0.shape[1],
-                           gy_amax=gl(2), gx_amax=gl(8))
+                           gy_amax=gl(2), gx_amax=gl(8), mask_bits=bits[0])
         gw_r0, gb_r0 = acc_r0 if acc_r0 is not None else (None, None)
         gw_r1, gb_r1 = acc_r1 if acc_r1 is not None else (None, None)
         _slog("gpre_init", g_x2, 8)
@@ -679,6 +696,8 @@ class _OccUpsampleFn(hip.Function):
         if any(ctx.needs_input_grad[2:2 + nparts]):
             w_first = _padded_cin(w_init, x_in.shape[1]) if x_in.shape[1] > cin else w_init
             g_xin = conv_dgrad(gpre_init, w_first, 1, 1, hw_, real_cin=cin, gy_amax=gl(8))
+            if _KEEP_LOG is not None:
+                _KEEP_LOG.append((f"occ_upsample backward {tuple(g_xin.shape)} g_xin", g_xin))
             c0 = 0
             for i, wd in enumerate(widths):
                 if ctx.needs_input_grad[2 + i]:

@@ -30,6 +30,28 @@ static inline int irr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 __device__ __forceinline__ float irr_lrelu(float v) { return fmaxf(v, 0.1f * v); }
 __device__ __forceinline__ float irr_lrelu_grad(float y) { return y > 0.f ? 1.f : 0.1f; }
 
+// ---- 16-byte buffer store whose data registers may be reused at once (round 5, profiles/NOTES.md D.5) ------------------------------
+// Measured on gfx950 (ROCm 7.2): `buffer_store_dwordx4 v[8:11], v12, s[80:83], s68 offen` followed IMMEDIATELY by a VALU write of v8
+// stores the NEW v8 in lanes 12..15 of every 16-lane row -- when the memory pipeline is under load from another kernel or process.
+// The ISA manuals ask for wait states between a store of more than 64 bits and a VALU write of its data registers and exempt
+// stores with an SGPR in the soffset field; hipcc follows that (2 wait states behind every other wide store of this library,
+// none behind this form: tools/scan_store_hazard.py), and on this part the exemption does not hold.  The asm statement makes the
+// data registers count as REWRITTEN behind eight wait states, so neither the scheduler nor the register allocator can place a write
+// to them any earlier (tests/test_store_hazard_scan.py checks the machine code of the built library).
+#ifndef X3S_STORE_UNGUARDED
+#define X3S_STORE_UNGUARDED 0
+#endif
+#if X3S_STORE_UNGUARDED
+#define IRR_STORE_GUARD(v) do {} while (0)                    /* A/B: the compiler's own placement (tools/r5_store_hazard_ab.sh) */
+#else
+#define IRR_STORE_GUARD(v) asm volatile("s_nop 7" : "+v"(v))
+#endif
+typedef unsigned int irr_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void irr_buffer_store_b128_guarded(irr_u32x4 v, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, 0);
+  IRR_STORE_GUARD(v);
+}
+
 // XCD-aware block order (speed only, never correctness): the dispatcher is observed to place workgroup b on XCD b % 8, each XCD
 // with its own 4 MiB L2 (MI355X_MICROARCH.md, "Workgroup dispatch").  irr_xcd_order maps the linear workgroup id to its
 // position in "XCD-major" order: ids of one XCD get CONSECUTIVE positions, so a kernel that decodes (position -> tile) with

@@ -368,6 +368,13 @@ struct X3SArgs {
   const float* x_amax;          // NP == 2: as in X3Args
   int n_amax;
   float* y_amax;
+  // LeakyReLU' masks as BITS (round 5): one 32-bit word per epilogue thread and tile -- bit e * 4 + px = (stored value > 0) of channel
+  // eq_c8 * 8 + e, pixel px of the thread's quad -- at word (bits_tile0 + tile) * 256 + ptid.  A forward launch (EPI 0) writes them
+  // next to its output; the masked data gradient of the SAME map shape (EPI 4) reads one dword instead of eight 16-B loads of the
+  // activation: these launches are bound by HBM bytes and by the producers' memory-instruction rate.
+  const uint32_t* mask_bits;
+  uint32_t* bits_out;
+  long bits_tile0;
 };
 
 // s_memtime trace points (IRR_X3S_TRACE=1 builds, tools/x3s_trace.py): block 7, lane 0 of every wave
@@ -382,7 +389,7 @@ struct X3SArgs {
 #endif
 // EPI: what the epilogue has to read besides the accumulators -- 0: nothing (bias, LeakyReLU, alpha), 1: + a residual operand,
 // 2: everything (residual, accumulate-into-output, LeakyReLU'-mask), 3: residual + a SECOND output y2 = the value before the
-// residual is added (y = res + y2; irr_conv2d_fwd_x3_dual).  The kernel is bound by the producer waves' VALU issue
+// residual is added (y = res + y2; irr_conv2d_fwd_x3_dual), 4: as 2 with the mask read as bits (X3SArgs::mask_bits).  The kernel is bound by the producer waves' VALU issue
 // slots (operand split + epilogue), so the plain layers do not pay for 24 operand loads and 5 unused VALU per output.
 // NP: pieces per operand -- 3: bf16x3 (six products), 2: the fp16x2 form of x3_split.h (three products; operands scaled by the
 // powers of two derived from a.x_amax and the weight pack's trailer, accumulators scaled back when they are handed over).
@@ -433,6 +440,8 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, (short)0, (int)0x80000000u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)a.mask, (short)0, (int)0x80000000u, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 3 ? a.y2 : a.y), (short)0, (int)0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 4 ? (const void*)a.mask_bits : (const void*)a.bits_out),
+                                                                            (short)0, (int)0x80000000u, 0x00020000);
     // Staging unit = (k-group gg, patch row ly, aligned pixel quad q): 8 channels x 4 pixels as eight 16-B loads (the
     // vector-memory INSTRUCTION rate, not bandwidth, limited the dword version of this kernel).  The loaded window is
     // columns x0-4 .. x0+35 (ten aligned quads; only x0-1 and x0+32 of the two margin quads are used), so every
@@ -497,7 +506,8 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
     for (int e = 0; e < 8; ++e) bias_r[e] = (a.bias && eq_c8 * 8 + e < a.Cout) ? a.bias[eq_c8 * 8 + e] : 0.f;
     f32x4 erv[8], edv[8], emv[8];
     uint32_t evd = OOB, evd2 = OOB;
-    auto epilogue_loads = [&](const TileAt& at, bool valid) {
+    uint32_t ebits = 0, ebo = OOB;                          // EPI 4: the tile's mask word; EPI 0: where this tile's word goes
+    auto epilogue_loads = [&](const TileAt& at, bool valid, long tix) {
       const int tx = at.tx, ty = at.ty, b = at.b;
       const int oy = ty * 8 + eq_row, ox = tx * 32 + eq_q * 4;
       const bool pv = valid && oy < a.H && ox < a.W;
@@ -506,6 +516,11 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
       evd = pv ? (uint32_t)(((long)b * a.y_bs + pofs) * 4) : OOB;
       if (EPI == 3) evd2 = pv ? (uint32_t)(((long)b * a.y2_bs + pofs) * 4) : OOB;
       const uint32_t vm = (EPI == 2 && pv && a.mask) ? (uint32_t)(((long)b * a.mask_bs + pofs) * 4) : OOB;
+      if (EPI == 0 || EPI == 4) {
+        const uint32_t wo = (uint32_t)(((a.bits_tile0 + tix) * 256 + ptid) * 4);
+        if (EPI == 4) ebits = __builtin_amdgcn_raw_buffer_load_b32(rbits, (int)(valid ? wo : OOB), 0, 0);
+        else ebo = (valid && a.bits_out) ? wo : OOB;
+      }
       if (EPI >= 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -513,10 +528,10 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
           const int co = eq_c8 * 8 + e;
           const bool cok = co < a.Cout;
           erv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)(cok ? vr : OOB), (int)so, 0));
-          if (EPI == 2) {
+          if (EPI == 2 || EPI == 4)
             edv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)((cok && a.accumulate) ? evd : OOB), (int)so, 0));
+          if (EPI == 2)
             emv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rmask, (int)((cok && co < a.nmask) ? vm : OOB), (int)so, 0));
-          }
         }
       }
     };
@@ -528,6 +543,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
       for (int e = 0; e < 8; ++e) eacc[e] = *(const f32x4*)(ol + (eq_c8 * 8 + e) * 256 + eq_row * 32 + eq_q * 4);
     };
     auto epilogue_finish = [&]() {
+      uint32_t obits = 0;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int co = eq_c8 * 8 + e;
@@ -543,14 +559,22 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
             v += edv[e][px];                        // edv = 0 unless accumulating
             if (a.mask && co < a.nmask) v *= irr_lrelu_grad(emv[e][px]);
           }
+          if (EPI == 4) {
+            v += edv[e][px];
+            if (co < a.nmask) v *= ((ebits >> (e * 4 + px)) & 1u) ? 1.f : 0.1f;
+          }
           o[px] = v;
+          if (EPI == 0) obits |= (v > 0.f ? 1u : 0u) << (e * 4 + px);     // (the same predicate irr_lrelu_grad applies to the stored value)
         }
         if (want_amax && co < a.Cout && evd != OOB) ymax = x3_amax_fold(x3_amax_fold(x3_amax_fold(x3_amax_fold(ymax, o[0]), o[1]), o[2]), o[3]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, (int)((co < a.Cout && X3_ABL != 7 && X3_ABL != 10 && X3_ABL != 11) ? evd : OOB),
-                                               (int)((uint32_t)e * hw4), 0);
+        // (irr_buffer_store_b128_guarded, common.h: these stores carry an SGPR soffset, the form behind which hipcc inserts NO wait states
+        // -- and the next channel's arithmetic reuses the data registers at once: the fault of NOTES D.4 / D.5)
+        irr_buffer_store_b128_guarded(__builtin_bit_cast(u32x4, o), ry, (int)((co < a.Cout && X3_ABL != 7 && X3_ABL != 10 && X3_ABL != 11) ? evd : OOB),
+                                      (int)((uint32_t)e * hw4));
         if (EPI == 3)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o2), ry2, (int)(co < a.Cout ? evd2 : OOB), (int)((uint32_t)e * hw4), 0);
+          irr_buffer_store_b128_guarded(__builtin_bit_cast(u32x4, o2), ry2, (int)(co < a.Cout ? evd2 : OOB), (int)((uint32_t)e * hw4));
       }
+      if (EPI == 0) __builtin_amdgcn_raw_buffer_store_b32(obits, rbits, (int)ebo, 0, 0);       // (out-of-range marker unless bits were asked for)
     };
     TileAt at_prev = {0, 0, 0}, at_cur, at_next;            // tiles t - t_step (epilogue), t, t + t_step (loads in flight)
     at_cur.tx = (int)(t_begin % a.tiles_x);
@@ -582,7 +606,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
       __syncthreads();
       TR(5);                                      // barrier #2n: (n, chunk 0) published; accumulators of tile n-1 published
       // phase: MFMA waves on (n, chunk 0); slot 1 is free; the accumulator stage holds tile n-1 until barrier #2n+1
-      epilogue_loads(at_prev, tprev >= 0);
+      epilogue_loads(at_prev, tprev >= 0, tprev);
       epilogue_grab();
       TR(6);
       write_chunk(1);
@@ -598,7 +622,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
     }
     epilogue_finish();
     __syncthreads();                                        // final barrier: accumulators of the last tile published
-    epilogue_loads(at_prev, tprev >= 0);
+    epilogue_loads(at_prev, tprev >= 0, tprev);
     epilogue_grab();
     epilogue_finish();
     if (want_amax) x3_amax_publish(ymax, a.y_amax);
@@ -1016,10 +1040,14 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
                        int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
                        float alpha, int accumulate, const float* mask, long mask_bs, int nmask, float* ws, long ws_elems,
                        void* stream, float* y2 = nullptr, long y2_bs = 0, int np = 3, const float* x_amax = nullptr, int n_amax = 0,
-                       float* y_amax = nullptr) {
+                       float* y_amax = nullptr, const uint32_t* mask_bits = nullptr, uint32_t* bits_out = nullptr) {
   if (!x || !wq || !y || B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1) return IRR_EINVAL;
   if (y2 && (!res || accumulate || mask || !x3s_ok(B, Cin, H, W, Cout, dil))) return IRR_EINVAL;      // second output: streaming kernel only
   if (np == 2 && (!x_amax || n_amax <= 0)) return IRR_EINVAL;
+  // bit masks: the fp16x2 streaming kernel with one co-tile only; a launch either writes them (plain forward) or reads them
+  if ((mask_bits || bits_out) && (np != 2 || Cout > 32 || !x3s_ok(B, Cin, H, W, Cout, dil) || (mask_bits && (mask || bits_out || nmask <= 0)) ||
+                                  (bits_out && (res || accumulate || mask || y2))))
+    return IRR_EINVAL;
   if (x3s_ok(B, Cin, H, W, Cout, dil)) {
     X3SArgs s;
     s.wq = (const u32x4*)wq; s.bias = bias;
@@ -1048,9 +1076,11 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
       IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
       IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
       IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      IRR_HIP_TRY(hipFuncSetAttribute((const void*)conv_x3s_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
       attr_set = true;
     }
     s.x_amax = x_amax; s.n_amax = n_amax; s.y_amax = y_amax;
+    s.mask_bits = mask_bits; s.bits_out = bits_out;
     // every operand is addressed through 32-bit byte voffsets below the 2 GiB out-of-range marker
     long bsmax = x_bs > y_bs ? x_bs : y_bs;
     if (res && res_bs > bsmax) bsmax = res_bs;
@@ -1068,6 +1098,7 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
       s.B = (B - b0) < per ? (B - b0) : (int)per;
       s.x = x + (long)b0 * x_bs;
       s.ntiles = (long)s.B * s.tiles_x * s.tiles_y;
+      s.bits_tile0 = (long)b0 * s.tiles_x * s.tiles_y;
       const long nblk = s.ntiles < 256 ? s.ntiles : 256;             // persistent: one block per CU
       for (int cot = 0; cot < s.wCoT; ++cot) {                       // one launch per 32-channel co-tile
         const long co0 = 32L * cot;
@@ -1079,10 +1110,11 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
         s.mask = (mask && nmask > co0) ? mask + (long)b0 * mask_bs + co0 * hw_ : nullptr;
         s.nmask = nmask - (int)co0 < 0 ? 0 : (nmask - (int)co0 > 32 ? 32 : nmask - (int)co0);
         s.y2 = y2 ? y2 + (long)b0 * y2_bs + co0 * hw_ : nullptr;
-        const int epi = (s.accumulate || s.mask) ? 2 : s.res ? (s.y2 ? 3 : 1) : 0;
+        const int epi = s.mask_bits ? 4 : (s.accumulate || s.mask) ? 2 : s.res ? (s.y2 ? 3 : 1) : 0;
 #define X3S_GO(E) do { if (np == 2) hipLaunchKernelGGL((conv_x3s_kernel<E, 2>), dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s); \
                       else hipLaunchKernelGGL((conv_x3s_kernel<E, 3>), dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s); } while (0)
-        if (epi == 3) X3S_GO(3);
+        if (epi == 4) hipLaunchKernelGGL((conv_x3s_kernel<4, 2>), dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s);
+        else if (epi == 3) X3S_GO(3);
         else if (epi == 0) X3S_GO(0);
         else if (epi == 1) X3S_GO(1);
         else X3S_GO(2);
@@ -1180,6 +1212,22 @@ extern "C" int irr_conv2d_fwd_h2(const float* x, const void* wq, const float* bi
                                  long ws_elems, const float* x_amax, int n_amax, float* y_amax, void* stream) {
   return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, accumulate, mask, mask_bs, nmask,
                      ws, ws_elems, stream, nullptr, 0, 2, x_amax, n_amax, y_amax);
+}
+
+// irr_conv2d_fwd_h2 for the problems of the streaming kernel (irr_conv2d_h2_eligible == 9001, Cout <= 32) with LeakyReLU' masks as bits
+extern "C" long irr_conv2d_x3s_mask_words(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return IRR_EINVAL;
+  return (long)B * ((W + 31) / 32) * ((H + 7) / 8) * 256;
+}
+
+extern "C" int irr_conv2d_fwd_h2_bits(const float* x, const void* wq, const float* bias, const float* res, float* y, int B,
+                                      int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
+                                      float alpha, int accumulate, const void* mask_bits, int nmask, void* bits_out,
+                                      const float* x_amax, int n_amax, float* y_amax, void* stream) {
+  if (!mask_bits && !bits_out) return IRR_EINVAL;
+  if (((uintptr_t)mask_bits | (uintptr_t)bits_out) & 3) return IRR_EINVAL;
+  return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, accumulate, nullptr, 0, nmask,
+                     nullptr, 0, stream, nullptr, 0, 2, x_amax, n_amax, y_amax, (const uint32_t*)mask_bits, (uint32_t*)bits_out);
 }
 
 // irr_conv2d_fwd_x3_dual on the fp16x2 form (y_amax bounds y, the sum)

@@ -234,6 +234,57 @@ def test_streaming_kernel_on_h2_is_fp32_faithful(case, rng, h2_everywhere):
         assert err["h2"][i] <= max(4 * err["f32"][i], 2e-6) and err["h2"][i] <= 5e-6, (what, err)
 
 
+B_CASES = [(32, 32, 2, 40, 64), (16, 32, 1, 24, 96), (32, 32, 3, 23, 92), (32, 24, 1, 31, 60)]   # (Cin, Cout, B, H, W)
+
+
+@pytest.mark.parametrize("case", B_CASES, ids=[f"{c[0]}to{c[1]}_{c[2]}x{c[3]}x{c[4]}" for c in B_CASES])
+def test_streaming_kernel_bit_masks_equal_the_fp32_mask(case, h2_everywhere):
+    """irr_conv2d_fwd_h2_bits (round 5): the forward launch writes (y > 0) as one bit per element, the masked data gradient of the same
+    map shape reads the bits instead of the activation -- BIT-identical to the launch that reads the fp32 tensor (same arithmetic,
+    another source for the same predicate), incl. exact zeros / negative zeros in the activation, ragged tiles, accumulate + residual."""
+    from irr_amd import conv as C
+    cin, cout, B, H, W = case
+    C.set_math("h2")
+    assert C.x3s_bits_ok(B, cin, H, W, cout) and C.x3s_bits_ok(B, cout, H, W, cout)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, cin, H, W, generator=g)
+    x[:, :, : H // 3] = 0.0                                        # a region whose pre-activation is exactly the bias
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(cout, generator=g) * 0.05
+    b[::3] = 0.0                                                   # ... and exactly zero there for every third channel (mask must say 0.1)
+    b[1::6] = -0.0
+    xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+    bits = torch.full((C.x3s_mask_words(B, H, W),), -1, dtype=torch.int32, device="cuda")
+    ya = C.Amax.zeros(xc.device, 1)
+    y_ref = C.conv_forward(xc, wc, bc, 1, 1, True)
+    n0 = C.LAUNCHES["fwd_x3s"]
+    y = C.conv_forward(xc, wc, bc, 1, 1, True, y_amax=ya, bits_out=bits)
+    assert C.LAUNCHES["fwd_x3s"] == n0 + 1
+    assert torch.equal(y, y_ref) and ya.slots[ya.first].item() == y.abs().max().item()
+    assert (y == 0).any()                                          # the case does contain exact zeros
+    # the data gradient of a cout -> cout layer masked by y: bits against the fp32 tensor, plain / residual / accumulate forms
+    w2 = (torch.randn(cout, cout, 3, 3, generator=g) * 0.1).cuda()
+    gy = torch.randn(B, cout, H, W, generator=g).cuda()
+    res = torch.randn(B, cout, H, W, generator=g).cuda()
+    acc0 = torch.randn(B, cout, H, W, generator=g).cuda()
+    for kw in ({}, {"res": res, "alpha": 0.1}, {"accumulate": True}, {"accumulate": True, "res": res}):
+        outs = []
+        for mb in (None, bits):
+            a = dict(kw)
+            if a.pop("accumulate", False):
+                a.update(gx=acc0.clone(), accumulate=True)
+            ga = C.Amax.zeros(xc.device, 1)
+            n1 = C.LAUNCHES["dgrad_x3s"]
+            gx = C.conv_dgrad(gy, w2, 1, 1, (H, W), mask=y, nmask=cout, gx_amax=ga, mask_bits=mb, **a)
+            assert C.LAUNCHES["dgrad_x3s"] == n1 + 1
+            assert ga.slots[ga.first].item() == gx.abs().max().item()
+            outs.append(gx)
+        assert torch.equal(outs[0], outs[1]), kw
+    # rejected: bits together with a residual / on a problem of another kernel
+    with pytest.raises(ValueError):
+        C.conv_forward(xc, wc, bc, 1, 1, True, res=y_ref, bits_out=bits)
+
+
 # ---- regional dynamic range (VERDICT r4 weak #1): an error confined to a QUIET part of a tensor is invisible to max|err| / max|ref|
 # over the whole output, so these cases look at the quiet part alone, relative to ITS OWN range ---------------------------------
 RATIOS = [1e-5, 1e-6, 1e-7]
