@@ -557,7 +557,10 @@ def main():
                                        "before_backward (.item(), as the reference)"},
                "loss": head["loss"],
                "conv_math": C.MATH,
-               "x3s_h2": bool(C.X3S_H2),                   # the streaming 32-channel kernel's fp16x2 form (opt-in: IRR_X3S_H2=1)
+               "x3s_h2": bool(C.X3S_H2),                   # the streaming 32-channel kernel's fp16x2 form (default since round 5; IRR_X3S_H2=0: bf16x3)
+               "x3s_mask_bits": bool(C.X3S_BITS),          # its LeakyReLU' masks as bits (ABI 9; IRR_X3S_BITS=0: fp32 activations)
+               "branch_streams": (f"occlusion branch of levels < {os.environ.get('IRR_BRANCH_LEVELS', '4')} on a second HIP stream"
+                                  if os.environ.get("IRR_BRANCH_STREAMS", "1") != "0" else "off"),
                "conv_math_note": {"h2": "fp32 tensors in HBM, fp32 accumulation and results; the MFMA convs split every operand, scaled by a "
                                         "power of two from max|.| of its tensor, into two fp16 pieces and accumulate three piece products "
                                         "(v_mfma_f32_32x32x16_f16).  The activation-side low piece is stored x 2^11 (its partner, the "

@@ -118,10 +118,13 @@ class PWCNet(nn.Module):
         self.corr_params = {"pad_size": self.search_range, "kernel_size": 1, "max_disp": self.search_range,
                             "stride1": 1, "stride2": 1, "corr_multiply": 1}
         initialize_msra(self.modules())
-        # measured: 281.6 ms/step with the second stream vs 278.0 without (bs32 384x448): the big level-3/4 launches only
-        # time-share the chip and the coarse levels are too short to matter -> off by default
-        self.branch_streams = os.environ.get("IRR_BRANCH_STREAMS", "0") != "0"
-        self.branch_levels = int(os.environ.get("IRR_BRANCH_LEVELS", "5"))     # pyramid levels l < this use the second stream
+        # The occlusion decoder + context network of the coarse levels on a second HIP stream: their launches are too small to fill the
+        # chip and independent of the flow branch (profiles/r5_branch_pairing_bound.txt: 151.6 -> 150.0 ms per step with levels < 4,
+        # 150.5 with < 3, nothing more with < 5; round 1 had measured -1 % with all levels).  ON since the end of round 5: until the
+        # store hazard of conv_x3s_kernel was fixed this configuration failed the bs32 oracle test.
+        # IRR_BRANCH_STREAMS=0: one stream.
+        self.branch_streams = os.environ.get("IRR_BRANCH_STREAMS", "1") != "0"
+        self.branch_levels = int(os.environ.get("IRR_BRANCH_LEVELS", "4"))     # pyramid levels l < this use the second stream
 
     # the validity-mask threshold of WarpingLayer: 1.0 = reference as-is, 0.9999 = robust parity mode
     @property
@@ -142,7 +145,7 @@ class PWCNet(nn.Module):
         return cache[key]
 
     def _branch_stream(self, dev, level=0):
-        """second HIP stream for the occlusion branch (experiment switch IRR_BRANCH_STREAMS=1; default: one stream)"""
+        """second HIP stream for the occlusion branch of the coarse levels (IRR_BRANCH_STREAMS=0: one stream)"""
         if not self.branch_streams or dev.type != "cuda" or level >= self.branch_levels:
             return None
         st = self.__dict__.get("_side_stream")
@@ -194,8 +197,8 @@ class PWCNet(nn.Module):
                 ctx_in, flow_est = self.flow_estimators.forward_residual((corr, x_1by1, flow), flow, self.dim_corr if _CORR_PREMASK else 0)
                 flow_cont = self.context_networks(ctx_in, res=flow_est)
 
-                # The occlusion decoder + context network are independent of the flow branch until refine_occ: with
-                # IRR_BRANCH_STREAMS=1 they run on a second HIP stream (autograd replays their backward there too).
+                # The occlusion decoder + context network are independent of the flow branch until refine_occ: at the coarse levels
+                # they run on a second HIP stream (autograd replays their backward there too; IRR_BRANCH_STREAMS=0: one stream).
                 occ_in = (corr, x_1by1, occ)
                 side = self._branch_stream(dev, l)
                 if side is not None:
