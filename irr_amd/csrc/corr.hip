@@ -730,8 +730,12 @@ __device__ __forceinline__ float corrg_at(const float* __restrict__ f, const Cor
 
 __global__ __launch_bounds__(256) void corr_general_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                               float* __restrict__ out, const CorrGen p) {
-  const int ox = blockIdx.x * 256 + threadIdx.x;
-  const int oy = blockIdx.y % p.OH, tc = blockIdx.y / p.OH, n = blockIdx.z;
+  // (rows of the launch = (displacement channel, output row) pairs, folded into grid.x: D * D * OH exceeds the 65535 of grid.y for
+  // FlowNetC-sized volumes at full resolution)
+  const int nxb = (p.OW + 255) / 256;
+  const int ox = (int)(blockIdx.x % nxb) * 256 + threadIdx.x;
+  const int row = blockIdx.x / nxb;
+  const int oy = row % p.OH, tc = row / p.OH, n = blockIdx.y;
   if (ox >= p.OW) return;
   const int tj = tc / p.D - p.dr, ti = tc % p.D - p.dr;
   const int y1 = oy * p.s1 + p.md, x1 = ox * p.s1 + p.md;
@@ -751,8 +755,10 @@ __global__ __launch_bounds__(256) void corr_general_fwd_kernel(const float* __re
 template <bool SECOND>
 __global__ __launch_bounds__(256) void corr_general_bwd_kernel(const float* __restrict__ other, const float* __restrict__ gout,
                                                               float* __restrict__ gin, const CorrGen p, long other_bs, long gin_bs) {
-  const int x = blockIdx.x * 256 + threadIdx.x;
-  const int y = blockIdx.y % p.H, c = blockIdx.y / p.H, n = blockIdx.z;
+  const int nxb = (p.W + 255) / 256;
+  const int x = (int)(blockIdx.x % nxb) * 256 + threadIdx.x;
+  const int row = blockIdx.x / nxb;
+  const int y = row % p.H, c = row / p.H, n = blockIdx.y;
   if (x >= p.W) return;
   const float* o = other + (long)n * other_bs;
   const float* g = gout + (long)n * p.out_bs;
@@ -803,9 +809,10 @@ extern "C" int irr_corr_general_fwd_f32(const float* f1, const float* f2, float*
   if (!f1 || !f2 || !out) return IRR_EINVAL;
   const int rc = corrg_setup(&p, B, C, H, W, pad, k, md, s1, s2);
   if (rc) return rc;
-  if ((long)p.D * p.D * p.OH > 65535) return IRR_EINVAL;
+  const long nblk = (long)irr_cdiv(p.OW, 256) * p.D * p.D * p.OH;
+  if (nblk > 0x7fffffffL) return IRR_EINVAL;
   p.f1_bs = f1_bs; p.f2_bs = f2_bs; p.out_bs = out_bs;
-  hipLaunchKernelGGL(corr_general_fwd_kernel, dim3(irr_cdiv(p.OW, 256), p.D * p.D * p.OH, B), dim3(256), 0, (hipStream_t)stream, f1, f2, out, p);
+  hipLaunchKernelGGL(corr_general_fwd_kernel, dim3((unsigned)nblk, B), dim3(256), 0, (hipStream_t)stream, f1, f2, out, p);
   IRR_LAUNCH_CHECK();
   return 0;
 }
@@ -817,9 +824,10 @@ extern "C" int irr_corr_general_bwd_f32(const float* f1, const float* f2, const 
   if (!f1 || !f2 || !gout) return IRR_EINVAL;
   const int rc = corrg_setup(&p, B, C, H, W, pad, k, md, s1, s2);
   if (rc) return rc;
-  if ((long)C * H > 65535) return IRR_EINVAL;
+  const long nblk = (long)irr_cdiv(W, 256) * C * H;
+  if (nblk > 0x7fffffffL) return IRR_EINVAL;
   p.f1_bs = f1_bs; p.f2_bs = f2_bs; p.out_bs = gout_bs;
-  const dim3 grid(irr_cdiv(W, 256), C * H, B);
+  const dim3 grid((unsigned)nblk, B);
   if (g1) {
     hipLaunchKernelGGL(corr_general_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, f2, gout, g1, p, f2_bs, g1_bs);
     IRR_LAUNCH_CHECK();

@@ -79,6 +79,21 @@ def test_correlation_module_at_other_parameter_points(golden_dir):
         out.backward(go.float().cuda())
         np.testing.assert_allclose(f1.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(f2.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-5, atol=1e-6)
+    # launches with more than 65535 (channel, row) pairs: FlowNetC-sized volumes (441 displacement channels x 200 rows) and tall
+    # feature maps (300 channels x 256 rows) -- the rows are folded into grid.x
+    gen = torch.Generator().manual_seed(9)
+    for shape, pt in (((1, 2, 200, 12), (20, 1, 20, 1, 2)), ((1, 300, 256, 8), (2, 1, 2, 1, 1))):
+        a = torch.randn(*shape, generator=gen, dtype=torch.float64).requires_grad_(True)
+        b = torch.randn(*shape, generator=gen, dtype=torch.float64).requires_grad_(True)
+        o = O.correlation_general(a, b, *pt)
+        go = torch.randn(o.shape, generator=gen, dtype=torch.float64)
+        o.backward(go)
+        f1, f2 = a.detach().float().cuda().requires_grad_(True), b.detach().float().cuda().requires_grad_(True)
+        out = irr_amd.Correlation(*pt, 1)(f1, f2)
+        out.backward(go.float().cuda())
+        np.testing.assert_allclose(out.detach().cpu().numpy(), o.detach().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(f1.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(f2.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-5)
 
 
 def test_cost_volume_fused_lrelu(golden_dir):
