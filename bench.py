@@ -226,8 +226,19 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # IRR_DDP_SINGLE_RANK=1 (test switch, irr_amd.ddp.collectives_on): a process group of ONE rank with every collective of the
+    # data-parallel step really issued -- the RCCL transport and its stream choreography on a one-GPU box
+    dist_on = world > 1 or bool(os.environ.get("IRR_DDP_SINGLE_RANK"))
+    # stdout carries ONE JSON line (rank 0) and nothing else.  Libraries write there too: RCCL prints a five-line version banner per
+    # communicator with NCCL_DEBUG=VERSION (set on the GPU boxes; C stdio, flushed at exit, i.e. BEHIND the JSON line; NCCL_DEBUG_FILE
+    # does not move it), gloo its "connected to n peer ranks" lines.  So file descriptor 1 is pointed at stderr for the whole process and
+    # the JSON line goes to a saved duplicate of the real stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -260,14 +271,14 @@ def main():
         return irr_amd.PWCNet(types.SimpleNamespace(batch_size=batch_pairs, model_div_flow=0.05)).to(device).train()
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     def own_step_factory(model, arena, opt):
         def make(batch_pairs):
             args = types.SimpleNamespace(batch_size=batch_pairs, model_div_flow=0.05)
-            loss = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(args, reduce_fn=ddp.reduce_losses() if world > 1 else None).train()
+            loss = irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(args, reduce_fn=ddp.reduce_losses() if dist_on else None).train()
             mal = ModelAndLoss(args, model, loss).train()
             # the reference's per-step NaN assertion is ON: asserted before the optimizer step (TrainStep docstring);
             # IRR_BENCH_NANCHECK=before_backward: the reference's exact placement (A/B), =off: diagnostic
@@ -344,7 +355,7 @@ def main():
         torch.cuda.synchronize()
         routing = dict(C.LAUNCHES)
         spread = None
-        if world > 1:
+        if dist_on:
             allt = torch.zeros(world, device=device, dtype=torch.float64)      # every rank fills its slot: SUM == gather
             allt[rank] = dt
             dist.all_reduce(allt, op=dist.ReduceOp.SUM)
@@ -451,7 +462,7 @@ def main():
 
     head = run(make_step, a.batch, a.height, a.width, a.steps, a.warmup, not a.no_kernel_timer)
     # rank 0's bucket schedule of the last step: (bucket, where it was started, ms since zero_grad)
-    launch_rep = arena.launch_report() if (arena is not None and world > 1) else None
+    launch_rep = arena.launch_report() if (arena is not None and dist_on) else None
     launch_log = launch_rep["bucket_launches"] if launch_rep is not None else None
     second = None
     if not a.no_secondary and (a.height, a.width) == (384, 448):
@@ -616,8 +627,9 @@ def main():
                                                     "on both sides; bar 1e-4 px (SURVEY 8(c))")
                 out["forward_only"]["cpu_baseline"] = {"value": round(pps, 4), "unit": "image-pairs/s", "cores": min(16, os.cpu_count() or 16),
                                                        "kind": "port", "sample": "oracle eval forward, 2 pairs of 384x448, one timed pass"}
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -46,10 +46,19 @@ def shard_batch(batch: dict, rank: int, world: int) -> dict:
     return out
 
 
+def collectives_on(group=None) -> bool:
+    """True when the data-parallel collectives run: an initialised process group of more than one rank -- or of ONE rank under
+    IRR_DDP_SINGLE_RANK=1 (test switch: the RCCL transport, its communicator and the stream choreography around it on a one-GPU
+    box -- RCCL refuses two ranks on one device; an all-reduce over one rank is the identity, everything around it is real)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or bool(os.environ.get("IRR_DDP_SINGLE_RANK"))
+
+
 def reduce_losses(group=None) -> Callable:
     """reduce_fn for MultiScaleEPE_PWC_Bi_Occ_upsample: SUM of (flow_loss, occ_loss) over ranks."""
     def fn(f_loss, o_loss):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not collectives_on(group):
             return f_loss, o_loss
         t = torch.stack([f_loss, o_loss])
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -117,13 +126,18 @@ class GradArena:
         self.launch_log: List[Tuple[int, str]] = []    # (bucket, "backward" | "sync") of the last step -- tests / diagnostics
         self.launch_times: List[float] = []            # ms since zero_grad() at which each entry of launch_log was enqueued
         self._reset()
-        if self.world > 1:
+        if self.active:
             for _, p in self.order:
                 self._hooks.append(p.register_post_accumulate_grad_hook(lambda p_: self._contribution(id(p_))))
 
     @property
     def world(self) -> int:
         return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    @property
+    def active(self) -> bool:
+        """the gradient all-reduce runs (collectives_on: more than one rank, or the single-rank test switch)"""
+        return collectives_on(self.group)
 
     def _reset(self):
         self._seen = {pid: 0 for pid in self._bucket_of}
@@ -231,7 +245,7 @@ class GradArena:
                 p.grad = view
 
     def _launch(self, bi: int):
-        if self._launched[bi] or self.world == 1:
+        if self._launched[bi] or not self.active:
             return
         self._launched[bi] = True
         self.launch_log.append((bi, "sync" if self._in_sync else "backward"))
@@ -295,7 +309,7 @@ class GradArena:
         its critical path.  Autograd no longer sees those gradients; the lane reports each contribution instead."""
         from . import conv
         self._side_lane = conv.WgradSide([(p, p.grad) for _, p in self.order])
-        if self.world > 1:
+        if self.active:
             self._side_lane.on_launch = self._on_lane
             self._side_lane.on_queue = self._on_queue
         conv.SIDE = self._side_lane
@@ -306,7 +320,7 @@ class GradArena:
         straight into this arena (no per-use gradient tensors, no autograd accumulation adds, batched folds)."""
         from . import conv
         self._side_lane = conv.WgradSide([(p, p.grad) for _, p in self.order], inline=True)
-        if self.world > 1:
+        if self.active:
             self._side_lane.on_launch = self._on_lane
             self._side_lane.on_queue = self._on_queue
         conv.SIDE = self._side_lane
@@ -325,7 +339,7 @@ class GradArena:
         """call between backward() and optimizer.step(): flush, wait, average."""
         if self._side_lane is not None:
             self._side_lane.join()
-        if self.world == 1:
+        if not self.active:
             return
         self._in_sync = True
         for bi in range(len(self.buckets)):
@@ -368,7 +382,7 @@ class GradArena:
 
 
 def broadcast_params(module: torch.nn.Module, src: int = 0, group=None) -> None:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_on(group):
         return
     for p in module.parameters():
         dist.broadcast(p.data, src=src, group=group)
