@@ -259,7 +259,13 @@ class GradArena:
             # The lane's tail at this moment IS the bucket's last contribution: _on_queue() flushed the lane the moment the
             # bucket's last weight-gradient launch of the step was queued, so the fold that completes the bucket is the last
             # thing on the lane -- the all-reduce does not wait for later levels' launches that the lagging lane still holds.
-            self._side.wait_stream(torch.cuda.current_stream())
+            cur = torch.cuda.current_stream()
+            self._side.wait_stream(cur)
+            # (round 5: backward nodes of the coarse levels' occlusion branch run on a second stream -- the hook / lane callback that
+            # completes a bucket may fire there while earlier contributions were enqueued on the device's default stream)
+            main = torch.cuda.default_stream(chunk.device)
+            if main != cur and not torch.cuda.is_current_stream_capturing():
+                self._side.wait_stream(main)
             if self._side_lane is not None and self._side_lane.stream is not None:
                 self._side.wait_stream(self._side_lane.stream)
             with torch.cuda.stream(self._side):
