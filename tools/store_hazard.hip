@@ -1,0 +1,69 @@
+// Round 5, NOTES D.5: stand-alone victim for the wide-store hazard of gfx950.  Every thread stores (1, 1, 1, 1) to its own 16-byte slot
+// with `buffer_store_dwordx4 v[10:13], voff, rsrc, <soffset> offen` and then, after WS wait states, overwrites the store's first data
+// register (v10) with 2.0 -- the pattern hipcc produced in the epilogue of conv_x3s_kernel (an SGPR soffset, no wait states).  A slot whose
+// first component reads 2.0 afterwards was stored from the REWRITTEN register.
+//   FORM 0: soffset in an SGPR (the form the ISA manuals exempt from the wait states and hipcc leaves unguarded)
+//   FORM 1: soffset = 0 literal (the form behind which hipcc inserts two wait states)
+//   WS    : s_nop count between the store and the overwrite (0 = none)
+// Built and driven by tools/store_hazard.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+template <int FORM, int WS>
+__global__ __launch_bounds__(256) void store_victim(float* out, int iters, long stride_bytes) {
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, (int)0x7fffffff, 0x00020000);
+  const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+  const float good = 1.0f, bad = 2.0f;
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t voff = tid * 16u;
+    const uint32_t soff = (uint32_t)(it * stride_bytes);
+    if (FORM == 0) {
+      if (WS == 0)
+        asm volatile("v_mov_b32 v10, %0\n\tv_mov_b32 v11, %0\n\tv_mov_b32 v12, %0\n\tv_mov_b32 v13, %0\n\ts_nop 4\n\t"
+                     "buffer_store_dwordx4 v[10:13], %2, %3, %4 offen\n\t"
+                     "v_mov_b32 v10, %1\n\t"
+                     :: "v"(good), "v"(bad), "v"(voff), "s"(rsrc), "s"(soff) : "v10", "v11", "v12", "v13", "memory");
+      else
+        asm volatile("v_mov_b32 v10, %0\n\tv_mov_b32 v11, %0\n\tv_mov_b32 v12, %0\n\tv_mov_b32 v13, %0\n\ts_nop 4\n\t"
+                     "buffer_store_dwordx4 v[10:13], %2, %3, %4 offen\n\t"
+                     "s_nop %5\n\t"
+                     "v_mov_b32 v10, %1\n\t"
+                     :: "v"(good), "v"(bad), "v"(voff), "s"(rsrc), "s"(soff), "n"(WS - 1) : "v10", "v11", "v12", "v13", "memory");
+    } else {
+      const uint32_t vo2 = voff + soff;
+      if (WS == 0)
+        asm volatile("v_mov_b32 v10, %0\n\tv_mov_b32 v11, %0\n\tv_mov_b32 v12, %0\n\tv_mov_b32 v13, %0\n\ts_nop 4\n\t"
+                     "buffer_store_dwordx4 v[10:13], %2, %3, 0 offen\n\t"
+                     "v_mov_b32 v10, %1\n\t"
+                     :: "v"(good), "v"(bad), "v"(vo2), "s"(rsrc) : "v10", "v11", "v12", "v13", "memory");
+      else
+        asm volatile("v_mov_b32 v10, %0\n\tv_mov_b32 v11, %0\n\tv_mov_b32 v12, %0\n\tv_mov_b32 v13, %0\n\ts_nop 4\n\t"
+                     "buffer_store_dwordx4 v[10:13], %2, %3, 0 offen\n\t"
+                     "s_nop %4\n\t"
+                     "v_mov_b32 v10, %1\n\t"
+                     :: "v"(good), "v"(bad), "v"(vo2), "s"(rsrc), "n"(WS - 1) : "v10", "v11", "v12", "v13", "memory");
+    }
+  }
+}
+
+// aggressor: a kernel that streams reads and writes through the memory pipeline (grid-stride copy with a little arithmetic)
+__global__ __launch_bounds__(256) void mem_aggressor(const float4* __restrict__ a, float4* __restrict__ b, long n, int rounds) {
+  for (int r = 0; r < rounds; ++r)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+      float4 v = a[i];
+      v.x += 1.f; v.y *= 0.5f;
+      b[i] = v;
+    }
+}
+
+#define GO(F, W) hipLaunchKernelGGL((store_victim<F, W>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, out, iters, stride_bytes)
+extern "C" int launch_store_victim(float* out, int nblk, int iters, long stride_bytes, int form, int ws, void* stream) {
+  if (form == 0) { switch (ws) { case 0: GO(0, 0); break; case 1: GO(0, 1); break; case 2: GO(0, 2); break; case 4: GO(0, 4); break; case 8: GO(0, 8); break; default: return -1; } }
+  else if (form == 1) { switch (ws) { case 0: GO(1, 0); break; case 1: GO(1, 1); break; case 2: GO(1, 2); break; case 4: GO(1, 4); break; case 8: GO(1, 8); break; default: return -1; } }
+  else return -1;
+  return (int)hipGetLastError();
+}
+extern "C" int launch_mem_aggressor(const void* a, void* b, long n16, int rounds, int nblk, void* stream) {
+  hipLaunchKernelGGL(mem_aggressor, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (float4*)b, n16, rounds);
+  return (int)hipGetLastError();
+}
