@@ -56,6 +56,40 @@ __global__ __launch_bounds__(256) void mem_aggressor(const float4* __restrict__ 
     }
 }
 
+// narrower stores (the hazard rule covers only stores of MORE than 64 bits): dwordx2 / dword with an SGPR soffset, overwrite at once
+template <int WIDTH>
+__global__ __launch_bounds__(256) void store_victim_narrow(float* out, int iters, long stride_bytes) {
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, (int)0x7fffffff, 0x00020000);
+  const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+  const float good = 1.0f, bad = 2.0f;
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t voff = tid * 16u;
+    const uint32_t soff = (uint32_t)(it * stride_bytes);
+    if (WIDTH == 2)
+      asm volatile("v_mov_b32 v10, %0\n\tv_mov_b32 v11, %0\n\ts_nop 4\n\t"
+                   "buffer_store_dwordx2 v[10:11], %2, %3, %4 offen\n\t"
+                   "v_mov_b32 v10, %1\n\t"
+                   :: "v"(good), "v"(bad), "v"(voff), "s"(rsrc), "s"(soff) : "v10", "v11", "memory");
+    else if (WIDTH == 3)
+      asm volatile("v_mov_b32 v10, %0\n\tv_mov_b32 v11, %0\n\tv_mov_b32 v12, %0\n\ts_nop 4\n\t"
+                   "buffer_store_dwordx3 v[10:12], %2, %3, %4 offen\n\t"
+                   "v_mov_b32 v10, %1\n\t"
+                   :: "v"(good), "v"(bad), "v"(voff), "s"(rsrc), "s"(soff) : "v10", "v11", "v12", "memory");
+    else
+      asm volatile("v_mov_b32 v10, %0\n\ts_nop 4\n\t"
+                   "buffer_store_dword v10, %2, %3, %4 offen\n\t"
+                   "v_mov_b32 v10, %1\n\t"
+                   :: "v"(good), "v"(bad), "v"(voff), "s"(rsrc), "s"(soff) : "v10", "memory");
+  }
+}
+extern "C" int launch_store_victim_narrow(float* out, int nblk, int iters, long stride_bytes, int width, void* stream) {
+  if (width == 1) hipLaunchKernelGGL(store_victim_narrow<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, out, iters, stride_bytes);
+  else if (width == 2) hipLaunchKernelGGL(store_victim_narrow<2>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, out, iters, stride_bytes);
+  else if (width == 3) hipLaunchKernelGGL(store_victim_narrow<3>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, out, iters, stride_bytes);
+  else return -1;
+  return (int)hipGetLastError();
+}
+
 #define GO(F, W) hipLaunchKernelGGL((store_victim<F, W>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, out, iters, stride_bytes)
 extern "C" int launch_store_victim(float* out, int nblk, int iters, long stride_bytes, int form, int ws, void* stream) {
   if (form == 0) { switch (ws) { case 0: GO(0, 0); break; case 1: GO(0, 1); break; case 2: GO(0, 2); break; case 4: GO(0, 4); break; case 8: GO(0, 8); break; default: return -1; } }

@@ -61,6 +61,21 @@ for form, fname in ((0, "SGPR soffset"), (1, "literal soffset 0")):
                 wrong += w0; other += oth; launches_hit += int(w0 > 0)
             row.append(f"{kind}: {wrong} wrong slots in {launches_hit} of {N} launches" + (f" (+{other} other mismatches)" if other else ""))
         print(f"{fname:18s} {ws} wait states | " + " | ".join(row), flush=True)
+# the narrower stores with an SGPR soffset and NO wait state (dword / dwordx2: outside the hazard rule; dwordx3: inside it)
+so.launch_store_victim_narrow.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+for width in (1, 2, 3):
+    row = []
+    for kind in ("alone", "copy kernel", "32->32 weight gradient"):
+        wrong = 0
+        for rep in range(N):
+            out.zero_()
+            aggress(kind)
+            assert so.launch_store_victim_narrow(out.data_ptr(), NBLK, ITERS, nthr * 16, width, torch.cuda.current_stream().cuda_stream) == 0
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            wrong += int((out.view(-1, 4)[:, 0] == 2.0).sum())
+        row.append(f"{kind}: {wrong} wrong slots")
+    print(f"buffer_store_dword{'' if width == 1 else 'x' + str(width)}, SGPR soffset, 0 wait states | " + " | ".join(row), flush=True)
 # where in a wave do the wrong slots sit (last setting that showed any: form 0, no wait states, beside the weight gradient)
 out.zero_()
 aggress("32->32 weight gradient")
