@@ -31,13 +31,16 @@ __device__ __forceinline__ float irr_lrelu(float v) { return fmaxf(v, 0.1f * v);
 __device__ __forceinline__ float irr_lrelu_grad(float y) { return y > 0.f ? 1.f : 0.1f; }
 
 // ---- 16-byte buffer store whose data registers may be reused at once (round 5, profiles/NOTES.md D.5) ------------------------------
-// Measured on gfx950 (ROCm 7.2): `buffer_store_dwordx4 v[8:11], v12, s[80:83], s68 offen` followed IMMEDIATELY by a VALU write of v8
-// stores the NEW v8 in lanes 12..15 of every 16-lane row -- when the memory pipeline is under load from another kernel or process.
-// The ISA manuals ask for wait states between a store of more than 64 bits and a VALU write of its data registers and exempt
-// stores with an SGPR in the soffset field; hipcc follows that (2 wait states behind every other wide store of this library,
-// none behind this form: tools/scan_store_hazard.py), and on this part the exemption does not hold.  The asm statement makes the
-// data registers count as REWRITTEN behind eight wait states, so neither the scheduler nor the register allocator can place a write
-// to them any earlier (tests/test_store_hazard_scan.py checks the machine code of the built library).
+// Measured on gfx950 (ROCm 7.2; tools/store_hazard.hip, profiles/r5_store_hazard_standalone.txt): behind a buffer store of MORE than
+// 64 bits, a VALU write of the store's data registers needs TWO wait states when the soffset field holds a literal and ONE when it holds
+// an SGPR -- with fewer, lanes 12..15 of every 16-lane row store the NEW register contents (1.5 % of the slots of a lone kernel whose
+// overwrite follows at once, more beside other memory traffic).  The ISA manuals exempt the SGPR form and hipcc follows them: two wait
+// states behind every other wide store of this library, none behind `buffer_store_dwordx4 v[8:11], v12, s[80:83], s68 offen`, which the
+// epilogue of conv_x3s_kernel issues eight times per tile with the next channel's arithmetic writing v8 in the following cycle -- the
+// corruption that showed with a second process on the GPU (round 4's two-rank NaN) and beside the weight-gradient lane.  The asm
+// statement makes the data registers count as REWRITTEN behind eight wait states, so neither the scheduler nor the register allocator
+// can place a write to them any earlier (tools/scan_store_hazard.py / tests/test_store_hazard_scan.py check the machine code of the
+// built library; a plain __builtin_amdgcn_s_nop can be scheduled BEHIND the overwrite and guards nothing).
 #ifndef X3S_STORE_UNGUARDED
 #define X3S_STORE_UNGUARDED 0
 #endif
