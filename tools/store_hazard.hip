@@ -90,6 +90,30 @@ extern "C" int launch_store_victim_narrow(float* out, int nblk, int iters, long 
   return (int)hipGetLastError();
 }
 
+// the same question for LDS: ds_write_b128 v[10:13] followed at once by a VALU write of v10 (no hazard is documented)
+__global__ __launch_bounds__(256) void lds_victim(float* out, int iters) {
+  __shared__ float4 buf[256];
+  const float good = 1.0f, bad = 2.0f;
+  const uint32_t laddr = (uint32_t)(uintptr_t)(&buf[threadIdx.x]) ;
+  float4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    asm volatile("v_mov_b32 v10, %0\n\tv_mov_b32 v11, %0\n\tv_mov_b32 v12, %0\n\tv_mov_b32 v13, %0\n\ts_nop 4\n\t"
+                 "ds_write_b128 %2, v[10:13]\n\t"
+                 "v_mov_b32 v10, %1\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 :: "v"(good), "v"(bad), "v"(laddr) : "v10", "v11", "v12", "v13", "memory");
+    const float4 r = buf[threadIdx.x];
+    acc.x += (r.x == 2.0f) ? 1.f : 0.f;                      // count slots that hold the rewritten value
+    acc.y += (r.y != 1.0f || r.z != 1.0f || r.w != 1.0f || (r.x != 1.0f && r.x != 2.0f)) ? 1.f : 0.f;
+    __syncthreads();
+  }
+  ((float4*)out)[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+extern "C" int launch_lds_victim(float* out, int nblk, int iters, void* stream) {
+  hipLaunchKernelGGL(lds_victim, dim3(nblk), dim3(256), 0, (hipStream_t)stream, out, iters);
+  return (int)hipGetLastError();
+}
+
 #define GO(F, W) hipLaunchKernelGGL((store_victim<F, W>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, out, iters, stride_bytes)
 extern "C" int launch_store_victim(float* out, int nblk, int iters, long stride_bytes, int form, int ws, void* stream) {
   if (form == 0) { switch (ws) { case 0: GO(0, 0); break; case 1: GO(0, 1); break; case 2: GO(0, 2); break; case 4: GO(0, 4); break; case 8: GO(0, 8); break; default: return -1; } }

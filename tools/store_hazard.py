@@ -76,6 +76,21 @@ for width in (1, 2, 3):
             wrong += int((out.view(-1, 4)[:, 0] == 2.0).sum())
         row.append(f"{kind}: {wrong} wrong slots")
     print(f"buffer_store_dword{'' if width == 1 else 'x' + str(width)}, SGPR soffset, 0 wait states | " + " | ".join(row), flush=True)
+# LDS: ds_write_b128 followed at once by a VALU write of its first data register
+so.launch_lds_victim.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+row = []
+for kind in ("alone", "copy kernel", "32->32 weight gradient"):
+    wrong = other = 0
+    for rep in range(N):
+        out.zero_()
+        aggress(kind)
+        assert so.launch_lds_victim(out.data_ptr(), NBLK, 2000, torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        v = out[:nthr * 4].view(-1, 4)
+        wrong += int(v[:, 0].sum()); other += int(v[:, 1].sum())
+    row.append(f"{kind}: {wrong} wrong slots" + (f" (+{other} other)" if other else ""))
+print("ds_write_b128, overwrite of its first data register in the next cycle | " + " | ".join(row), flush=True)
 # where in a wave do the wrong slots sit (last setting that showed any: form 0, no wait states, beside the weight gradient)
 out.zero_()
 aggress("32->32 weight gradient")
