@@ -17,6 +17,22 @@ from .conv_pack import LAUNCHES
 
 POOL_SLOTS = int(os.environ.get("IRR_AMAX_POOL", "4096"))      # (environment: diagnosis switch, profiles/NOTES.md C.5)
 _POOLS = {}
+_STREAMS = {}        # device index -> streams whose kernels use slots (Amax.zeros callers, the weight-gradient lane: note_stream)
+
+
+def note_stream(stream) -> None:
+    """``stream`` launches kernels that read or max into slots.  A pool tensor is allocated on ONE stream; the caching allocator
+    orders its reuse after that stream only.  Every other stream is recorded on the pool (Tensor.record_stream), so that a retired
+    pool -- freed on the host when its last Amax goes -- is not handed out again while kernels queued on another stream still
+    touch its slots (a silently corrupted small tensor or a wrong power-of-two scale, once per ~4096 slots)."""
+    key = stream.device.index if stream.device.index is not None else torch.cuda.current_device()
+    known = _STREAMS.setdefault(key, [])
+    if stream in known:
+        return
+    known.append(stream)
+    pool = _POOLS.get(key)
+    if pool is not None and pool[2] != stream:
+        pool[0].record_stream(stream)
 
 
 class Amax:
@@ -37,10 +53,14 @@ class Amax:
         key = device.index if device.index is not None else torch.cuda.current_device()
         pool = _POOLS.get(key)
         cur = torch.cuda.current_stream(device)
+        note_stream(cur)
         if pool is None or pool[1] + n > POOL_SLOTS:
             t = torch.zeros(POOL_SLOTS, device=device, dtype=torch.float32)
             filled = torch.cuda.Event()
             filled.record(cur)                                  # the fill is ordered on THIS stream only
+            for s_ in _STREAMS.get(key, ()):                    # (see note_stream)
+                if s_ != cur:
+                    t.record_stream(s_)
             pool = _POOLS[key] = [t, 0, cur, filled]
         elif pool[2] != cur:
             # slots handed to a node on ANOTHER stream (a branch stream, a warm-up side stream): nothing else orders their first

@@ -95,6 +95,9 @@ class WgradSide:
         # (no per-use gradient tensors, no autograd accumulation adds, one batched fold): GradArena.enable_direct_wgrad()
         self.inline = inline
         self.stream = None if inline else _lane_stream(dev)
+        if self.stream is not None:
+            from . import conv_amax
+            conv_amax.note_stream(self.stream)       # the lane's weight gradients read amax slots
         # The references in _inflight are dropped only after the lane has passed the launch (marker) or after the current stream
         # has joined the lane, so the caching allocator can never hand the memory out early; Tensor.record_stream on top of that
         # makes the allocator record one (system-scope) event on the lane per freed tensor -- 500 per step (A/B switch: 1 = on)
@@ -130,6 +133,7 @@ class WgradSide:
         self._hold = 0
         self._held = []
         self._queue_stream = None               # stream the launches in _queued were issued from
+        self._inline_streams = []               # inline lane: streams that issued a launch whose fold / report is still pending
 
     def hold(self):
         if not self.inline and self.on_queue is None:
@@ -152,6 +156,7 @@ class WgradSide:
         start of the next training forward pass) re-zeroes / re-adopts the arena afterwards."""
         self._queued = []
         self._pending = []
+        self._inline_streams = []
         self._routed = {}
         self._held, self._hold = [], 0
         if self.batch is not None:
@@ -219,9 +224,23 @@ class WgradSide:
         """fold every pending partial image (one launch on the lane) and report the gradients that are complete now"""
         if kick and not self.inline:
             self._kick()
+        if self.inline and self._inline_streams:
+            # the occlusion branch of the coarse levels runs its backward nodes on a second stream (irr_pwc.py): a launch issued there
+            # may be folded -- and reported to the gradient arena as complete -- from the other one.  The folding stream waits for
+            # every stream that issued a pending launch (ADVICE r5).
+            cur = torch.cuda.current_stream()
+            foreign = [s_ for s_ in self._inline_streams if s_ != cur]
+            for s_ in foreign:
+                cur.wait_stream(s_)
+            self._inline_streams = []
+        else:
+            foreign = []
         if self.batch is not None and self.batch.n:
             if self.inline:
-                self.batch.run()                               # (same stream: the allocator orders any reuse after the fold)
+                keep = self.batch.run()                        # (ordered after every issuing stream, above)
+                if foreign:                                    # partial images allocated on another stream are read by this one
+                    for t_ in keep:
+                        t_.record_stream(torch.cuda.current_stream())
             else:
                 with torch.cuda.stream(self.stream):
                     keep = self.batch.run()
@@ -274,6 +293,9 @@ class WgradSide:
                     or self.batch.n + len(self._queued) >= self.batch.cap - 1):
                 self.flush()
         if self.inline:
+            cur = torch.cuda.current_stream()
+            if cur not in self._inline_streams:
+                self._inline_streams.append(cur)
             fn()
             self._pending.append(params)
             if self.batch is None or not self.batch.n:

@@ -1098,7 +1098,12 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
       s.B = (B - b0) < per ? (B - b0) : (int)per;
       s.x = x + (long)b0 * x_bs;
       s.ntiles = (long)s.B * s.tiles_x * s.tiles_y;
-      s.bits_tile0 = (long)b0 * s.tiles_x * s.tiles_y;
+      // the bit-mask words are rebased per batch chunk like x and y: the kernel forms their byte offset in 32 bits against the 2 GiB
+      // out-of-range marker, and a chunk's words (<= H * W * 4 bytes per sample) stay below it when its activations do
+      const long bits_w0 = (long)b0 * s.tiles_x * s.tiles_y * 256;
+      s.mask_bits = mask_bits ? mask_bits + bits_w0 : nullptr;
+      s.bits_out = bits_out ? bits_out + bits_w0 : nullptr;
+      s.bits_tile0 = 0;
       const long nblk = s.ntiles < 256 ? s.ntiles : 256;             // persistent: one block per CU
       for (int cot = 0; cot < s.wCoT; ++cot) {                       // one launch per 32-channel co-tile
         const long co0 = 32L * cot;

@@ -145,6 +145,7 @@ class GradArena:
         self._in_sync = False
         self._late = False
         self._queued = [0] * len(self.buckets)
+        self._streams = [[] for _ in self.buckets]      # per bucket: the streams its contributions were enqueued on (_launch)
         self._t0 = time.perf_counter()
         self.launch_times = []
         if self._expected is not None:
@@ -254,23 +255,35 @@ class GradArena:
         if e == s:
             return
         chunk = self.flat[s:e]
+        # Every stream that enqueued a contribution to this bucket since zero_grad() (_contribution: the autograd hook's stream -- the
+        # occlusion branch of the coarse levels runs its backward nodes on a second stream, irr_pwc.py -- or the stream an inline
+        # lane folded on) plus the stream this call runs on.  Waiting for a stream waits for everything enqueued on it so far: a
+        # superset of the bucket's contributions, never less (with the last contribution on the main stream the earlier
+        # ones of the branch stream were not waited for).
+        cur = torch.cuda.current_stream() if chunk.is_cuda else None
+        contributors = [s_ for s_ in self._streams[bi] if s_ != cur] if cur is not None else []
+        if cur is not None and not torch.cuda.is_current_stream_capturing():
+            main = torch.cuda.default_stream(chunk.device)
+            if main != cur and main not in contributors:
+                contributors.append(main)
         if self.overlap:
-            # the bucket's contributions were enqueued on the main stream (autograd) and / or on the weight-gradient lane.
-            # The lane's tail at this moment IS the bucket's last contribution: _on_queue() flushed the lane the moment the
+            # The lane's tail at this moment IS the bucket's last routed contribution: _on_queue() flushed the lane the moment the
             # bucket's last weight-gradient launch of the step was queued, so the fold that completes the bucket is the last
             # thing on the lane -- the all-reduce does not wait for later levels' launches that the lagging lane still holds.
-            cur = torch.cuda.current_stream()
             self._side.wait_stream(cur)
-            # (round 5: backward nodes of the coarse levels' occlusion branch run on a second stream -- the hook / lane callback that
-            # completes a bucket may fire there while earlier contributions were enqueued on the device's default stream)
-            main = torch.cuda.default_stream(chunk.device)
-            if main != cur and not torch.cuda.is_current_stream_capturing():
-                self._side.wait_stream(main)
+            for s_ in contributors:
+                self._side.wait_stream(s_)
             if self._side_lane is not None and self._side_lane.stream is not None:
                 self._side.wait_stream(self._side_lane.stream)
             with torch.cuda.stream(self._side):
                 self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
+            # no communication stream: the collective is ordered after the CURRENT stream only (the backend's own rule), so the
+            # current stream waits for the other contributors first
+            for s_ in contributors:
+                cur.wait_stream(s_)
+            if cur is not None and self._side_lane is not None and self._side_lane.stream is not None:
+                cur.wait_stream(self._side_lane.stream)
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _contribution(self, pid: int):
@@ -279,6 +292,10 @@ class GradArena:
         if bi is None:
             return
         self._seen[pid] += 1
+        if self.flat.is_cuda:
+            st = torch.cuda.current_stream()
+            if st not in self._streams[bi]:
+                self._streams[bi].append(st)
         if self._expected is None:
             return
         if self._launched[bi]:

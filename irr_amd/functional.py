@@ -97,14 +97,20 @@ def cost_volume(feat1: torch.Tensor, feat2: torch.Tensor, lrelu: bool = False, g
 
 
 def compute_cost_volume(feat1, feat2, param_dict):
-    """Functional twin with the reference's signature (models/pwc_modules.py:42-53).  The reference
-    reads only ``max_disp`` and silently assumes k=1, s1=s2=1; unsupported values are rejected here."""
-    if int(param_dict.get("max_disp", 4)) != 4:
-        raise ValueError("only max_disp=4 (81 displacements) is implemented")
+    """Functional twin with the reference's signature (models/pwc_modules.py:42-62).  The reference reads only ``max_disp`` -- any
+    value -- and silently assumes k=1, s1=s2=1: max_disp = 4 runs on the tuned 81-displacement kernels, every other value on the
+    general pair (irr_corr_general_*, the same point Correlation(m, 1, m, 1, 1) computes); other kernel sizes / strides are
+    rejected here instead of being ignored."""
     for key, want in (("kernel_size", 1), ("stride1", 1), ("stride2", 1)):
         if int(param_dict.get(key, want)) != want:
             raise ValueError(f"{key} must be {want}")
-    return cost_volume(feat1, feat2, False)
+    md = int(param_dict["max_disp"]) if "max_disp" in param_dict else 4
+    if md < 0:
+        raise ValueError("max_disp must be >= 0")
+    if md == 4:
+        return cost_volume(feat1, feat2, False)
+    from .correlation import _CorrelationGeneral
+    return _CorrelationGeneral.apply(feat1, feat2, md, 1, md, 1, 1)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -123,8 +123,13 @@ def auto_install(model: torch.nn.Module) -> None:
         _conv.SIDE = arena._side_lane
     if not capturing:
         lane = arena._side_lane
-        if lane is not None and lane.stale():
+        # (not while a backward pass is RUNNING on this thread -- a forward executed inside it, e.g. torch.utils.checkpoint's
+        # recomputation or a hook that calls the model, finds the live pass's queued launches and fold jobs, which are not
+        # leftovers: abandoning them would lose gradients silently)
+        in_backward = torch._C._current_graph_task_id() != -1
+        if lane is not None and lane.stale() and not in_backward:
             # the previous backward pass raised (OOM, an assertion in a hook): autograd skipped its final callbacks, so the lane
             # was never joined and still holds launches / fold jobs of the failed pass
             lane.abandon()
-        arena.adopt_grads()
+        if not in_backward:                    # (a live pass's routed sums sit in the slices: nothing to re-adopt, nothing to zero)
+            arena.adopt_grads()

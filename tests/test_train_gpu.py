@@ -224,6 +224,53 @@ def test_zero_grad_after_forward_and_failed_backward_under_the_auto_lane(golden_
     assert C.SIDE is None
 
 
+def test_forward_inside_a_running_backward_keeps_the_live_pass():
+    """ADVICE r5.  A PWCNet.forward executed INSIDE a running backward pass (torch.utils.checkpoint's recomputation, a hook that
+    evaluates the model) finds the lane holding the live pass's queued launches and fold jobs: that is not a failed pass's
+    leftover -- ``auto_install`` must neither abandon them nor re-zero the arena.  The gradients of a pass with such a nested
+    forward equal those of a plain pass."""
+    import irr_amd
+    from irr_amd import conv as C, harness
+    from irr_amd.train import ModelAndLoss
+    from oracle import irr_pwc_oracle as O
+    assert C.SIDE is None, "a previous test left its lane installed"
+    m = irr_amd.PWCNet(_args(2), mask_threshold=0.9999)
+    m.load_state_dict(O.synthetic_params(0), strict=True)
+    m = m.cuda().train()
+    mal = ModelAndLoss(_args(2), m, irr_amd.MultiScaleEPE_PWC_Bi_Occ_upsample(_args(2))).train()
+    optimizer = torch.optim.Adam(mal.parameters(), lr=1e-4, weight_decay=4e-4)
+    nested = []
+
+    def hook(g_):
+        with torch.enable_grad():
+            out = m(_batch(2, 128, 192, 99))        # a training forward pass in the middle of backward
+        nested.append(float(out["flow"][0][0].detach().abs().sum()))
+        return g_
+
+    grads = []
+    try:
+        for with_hook in (False, True):
+            optimizer.zero_grad()
+            b0 = _batch(2, 128, 192, 1234)
+            x1 = b0["input1"].clone().requires_grad_(True)
+            if with_hook:
+                # fires after the whole decoder backward has queued its weight gradients, before the pyramid's
+                x1.register_hook(hook)
+            ld, _ = mal({**b0, "input1": x1 * 1.0})
+            ld["total_loss"].backward()
+            torch.cuda.synchronize()
+            assert all(p.grad is not None for p in m.parameters())
+            grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters()})
+        assert len(nested) == 1 and nested[0] > 0
+        assert harness.installed(m)
+    finally:
+        harness.uninstall(m)
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12, n
+    assert C.SIDE is None
+
+
 def test_fused_adam_is_an_optimizer_with_lr_schedule():
     """FusedAdam under the reference's scheduler (configuration.py:579-608 builds torch.optim.lr_scheduler.MultiStepLR on the
     optimizer; scripts/IRR-PWC_flyingChairsOcc.sh:24-26: milestones [54, 72, 90], gamma 0.5): three steps with a milestone after
