@@ -331,6 +331,19 @@ int irr_conv2d_fwd_h2_bits(const float* x, const void* wq, const float* bias, co
                            int lrelu, float alpha, int accumulate,
                            const void* mask_bits, int nmask, void* bits_out,
                            const float* x_amax, int n_amax, float* y_amax, void* stream);
+/* ABI 10 -- Winograd F(2x2, 3x3) on the fp16x2 arithmetic (csrc/conv_wino.hip; round 6, a gated experiment: tools/wino_check.py).
+ * The 3x3 / stride-1 / dilation-1 conv() block (models/pwc_modules.py:8-19) with 16 instead of 36 products per 2x2 output tile:
+ * U = G g G^T is formed at pack time (irr_conv_pack_weights_wino_h2: transpose = 0 forward, 1 = the stride-1 data gradient's
+ * transposed + flipped matrix; amax = device scalar >= max |w|, one scale per packed matrix; irr_conv_wino_packed_bytes bytes),
+ * V = B^T d B inside the launch.  irr_conv2d_wino_fwd_h2: y = alpha * act(conv(x, w) + bias), operands as in irr_conv2d_fwd_h2
+ * (x_amax / n_amax slots bound |x|; y_amax nullable: receives max |y|).  irr_conv2d_wino_eligible: 1 when the launcher accepts
+ * the problem. */
+long irr_conv_wino_packed_bytes(int Cin, int Cout);
+int irr_conv_pack_weights_wino_h2(const float* w, void* uq, int Cin, int Cout, int transpose, const float* amax, void* stream);
+int irr_conv2d_wino_eligible(int B, int Cin, int H, int W, int Cout);
+int irr_conv2d_wino_fwd_h2(const float* x, const void* uq, const float* bias, float* y,
+                           int B, int Cin, int H, int W, int Cout, long x_bs, long y_bs,
+                           int lrelu, float alpha, const float* x_amax, int n_amax, float* y_amax, void* stream);
 int irr_conv2d_wgrad_h2_robust_side(int B, int Cin, int H, int W, int Cout, int dil);
 int irr_conv2d_wgrad_h2(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                         int B, int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs,

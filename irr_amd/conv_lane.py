@@ -94,6 +94,7 @@ class WgradSide:
         # inline: no second stream -- the launches stay on the current stream, but still accumulate straight into the arena
         # (no per-use gradient tensors, no autograd accumulation adds, one batched fold): GradArena.enable_direct_wgrad()
         self.inline = inline
+        self._on_gpu = dev.type == "cuda"        # (the host logic also runs in the CPU suite)
         self.stream = None if inline else _lane_stream(dev)
         if self.stream is not None:
             from . import conv_amax
@@ -134,6 +135,7 @@ class WgradSide:
         self._held = []
         self._queue_stream = None               # stream the launches in _queued were issued from
         self._inline_streams = []               # inline lane: streams that issued a launch whose fold / report is still pending
+        self.cross_stream_folds = 0             # (diagnostics) flushes that had to wait for another issuing stream
 
     def hold(self):
         if not self.inline and self.on_queue is None:
@@ -232,6 +234,7 @@ class WgradSide:
             foreign = [s_ for s_ in self._inline_streams if s_ != cur]
             for s_ in foreign:
                 cur.wait_stream(s_)
+            self.cross_stream_folds += bool(foreign)
             self._inline_streams = []
         else:
             foreign = []
@@ -293,9 +296,10 @@ class WgradSide:
                     or self.batch.n + len(self._queued) >= self.batch.cap - 1):
                 self.flush()
         if self.inline:
-            cur = torch.cuda.current_stream()
-            if cur not in self._inline_streams:
-                self._inline_streams.append(cur)
+            if self._on_gpu:
+                cur = torch.cuda.current_stream()
+                if cur not in self._inline_streams:
+                    self._inline_streams.append(cur)
             fn()
             self._pending.append(params)
             if self.batch is None or not self.batch.n:

@@ -152,6 +152,13 @@ class PWCNet(nn.Module):
         if st is None or st.device != dev:
             st = torch.cuda.Stream(device=dev)
             self.__dict__["_side_stream"] = st
+            # The shared occlusion decoders are used on this stream at the coarse levels and on the caller's stream at level 4, so a
+            # parameter's AccumulateGrad node (bound to the stream of its FIRST use) receives gradients from both: the engine orders them
+            # with a device-side event wait between the two streams (no host synchronisation; needed, not "unnecessary") and torch
+            # warns about it once per process.  The mismatch is intentional (profiles/NOTES.md E.8).
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if quiet is not None:
+                quiet(False)
         return st
 
     def forward(self, input_dict):

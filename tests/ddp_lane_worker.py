@@ -52,7 +52,11 @@ def main():
     m1, mal1 = build(per, ddp.reduce_losses())
     ddp.broadcast_params(m1)
     a1 = ddp.GradArena(m1.named_parameters())
-    a1.enable_async_wgrad()
+    lane = os.environ.get("IRR_DDP_LANE", "async")      # async (the benched path) | inline (--no-async-wgrad) | plain (autograd hooks)
+    if lane == "async":
+        a1.enable_async_wgrad()
+    elif lane == "inline":
+        a1.enable_direct_wgrad()
     mine = ddp.shard_batch(full, rank, world)
     logs = []
     for _ in range(3):
@@ -62,6 +66,11 @@ def main():
         a1.sync()
         torch.cuda.synchronize()
         logs.append(list(a1.launch_log))
+        if lane == "inline" and m1.branch_streams:
+            # the shared-decoder bucket receives contributions from the main stream (flow branch) AND from the occlusion
+            # branch's stream at the coarse levels; its all-reduce has to wait for both, whichever delivers the last one -- either
+            # the arena saw both streams, or the lane folded launches of one stream on the other (and made it wait)
+            assert len(a1._streams[1]) >= 2 or a1._side_lane.cross_stream_folds > 0, [len(s_) for s_ in a1._streams]
         err = (a1.flat - ref).double().norm().item() / ref.double().norm().item()
         assert err <= 1e-4, (rank, err)
         # total_loss is normalised by the per-rank batch; the mean over ranks is the global-batch loss
@@ -71,7 +80,8 @@ def main():
     assert all(w == "sync" for _, w in logs[0]), logs                       # calibration step
     for lg in logs[1:]:                                                      # then: early + shared buckets start inside backward
         assert (0, "backward") in lg and (1, "backward") in lg, logs
-    a1.disable_async_wgrad()
+    if lane != "plain":
+        a1.disable_async_wgrad()
     if rank == 0:
         print("DDP_LANE_OK", logs[-1], flush=True)
     dist.destroy_process_group()

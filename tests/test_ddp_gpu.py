@@ -61,6 +61,23 @@ def test_single_rank_rccl_transport_lane_sync():
     assert r.returncode == 0 and "DDP_LANE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("lane", ["inline", "plain"])
+def test_single_rank_rccl_other_gradient_routes_with_branch_streams(lane):
+    """with the occlusion branch of the coarse levels on its own stream (the default), a bucket's all-reduce
+    must wait for EVERY stream that contributed to it -- the inline lane (bench.py --no-async-wgrad) and the plain autograd hooks
+    deliver contributions on both streams.  Same worker, same assertions (gradient == single process, buckets 0 and 1 started
+    inside backward), plus: bucket 1 saw two contributing streams."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_lane_worker.py")]
+    env = _env()
+    env["IRR_DDP_SINGLE_RANK"] = "1"
+    env["IRR_DDP_LANE"] = lane
+    env["IRR_BRANCH_STREAMS"] = "1"
+    env.pop("IRR_DDP_BACKEND", None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DDP_LANE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_bench_single_rank_over_rccl():
     """bench.py with the same switch: the line says transport rccl and rank 0's buckets 0 and 1 start inside backward"""
     import json
