@@ -26,9 +26,19 @@
 #include "x3_split.h"
 #include "amax.h"
 
+#ifndef WINO_TR_FIRST_OLD
+#define WINO_TR_FIRST_OLD 1   // 1: the older waves (0-3) transform first and the younger run their MFMAs first; 0 (A/B): the other way round
+#endif
+#ifndef WINO_PRIO
+#define WINO_PRIO 1     // s_setprio of the MFMA phase (0: A/B)
+#endif
 #ifndef WINO_ABL
 #define WINO_ABL 0      // ablation builds (timing only, results wrong): 1 = no U loads in the loop, 2 = no transform (V stale),
 #endif                  // 3 = no raw global loads, 4 = no MFMAs, 5 = same order in all waves (no stagger)
+
+#ifdef WINO_TRACE
+static unsigned long long* g_wino_dbg = nullptr;     // s_memtime trace (tag builds with -DWINO_TRACE=1, tools/wino_trace.py): block 7, lane 0 of every wave
+#endif
 
 namespace {
 
@@ -52,7 +62,21 @@ struct WinoArgs {
   const float* x_amax;
   int n_amax;
   float* y_amax;
+  unsigned long long* dbg;                     // WINO_TRACE builds only
 };
+
+#if defined(WINO_TRACE) && WINO_TRACE >= 2
+#define WTR2(slot) WTR(slot)
+#define WTR2_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define WTR2(slot) do {} while (0)
+#define WTR2_WAIT_LDS() do {} while (0)
+#endif
+#ifdef WINO_TRACE
+#define WTR(slot) do { if (blockIdx.x == 7 && lane == 0 && ntr < 1024) { dbgp[ntr++] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); } } while (0)
+#else
+#define WTR(slot) do {} while (0)
+#endif
 
 __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
   extern __shared__ u32x4 lds[];
@@ -62,6 +86,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef WINO_TRACE
+  int ntr = 0;
+  unsigned long long* dbgp = a.dbg + (size_t)wave * 1024;
+#endif
   const unsigned xpos = irr_xcd_order(blockIdx.x, gridDim.x);
   const int by = (int)(xpos % (unsigned)a.ngy);
   int bt = (int)(xpos / (unsigned)a.ngy);
@@ -81,28 +109,40 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
   const int ew = ((const int*)(a.uq + (long)a.nchunk * 16 * 2 * a.CoT * 64))[0];
   const float sx = ldexpf(1.f, ex), inv_x = ldexpf(1.f, -ex), inv_w = ldexpf(1.f, -ew);
 
-  // ---- staging role: threads 0..323 own one position of the 18 x 18 patch, all 16 channels of a chunk ----
-  const bool stager = tid < 324;
-  const int srow = tid / 18, scol = tid - srow * 18;
+  // ---- staging role ----
+  // 16-byte loads: the vector-memory pipe takes ~16 cycles per wave instruction whatever its width, and eight waves x 16 dword loads
+  // were 2 000 cycles per chunk of pure issue time (s_memtime trace: 1 750 cycles between the barrier and the next stamp in waves that
+  // did nothing else).  A unit = four pixels x0 - 4 + 4 quad .. + 3 of one patch row (quads 0 and 5 carry one patch column each); thread =
+  // (row, quad) of channels 4 kb .. 4 kb + 3, kb = tid / 108: 432 threads, four loads each.  Needs W % 4 == 0 and 16-byte aligned planes.
+  const bool stager = tid < 432;
+  const int kb = tid / 108, spos = tid - kb * 108;
+  const int srow = spos / 6, squad = spos - srow * 6;
   uint32_t svoff = WOOB;
   {
-    const int iy = y0 - 1 + srow, ix = x0 - 1 + scol;
-    if (stager && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) svoff = (uint32_t)(((long)iy * a.W + ix) * 4);
+    const int iy = y0 - 1 + srow, ix = x0 - 4 + 4 * squad;
+    if (stager && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) svoff = (uint32_t)(((long)(kb * 4) * hw + (long)iy * a.W + ix) * 4);
   }
-  const int sidx = srow * RAWP + scol;
+  int soff[4];                                               // LDS dword index of the unit's four values (pad columns 18 / 19 take the unused ones)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int pc = 4 * squad - 3 + e;
+    soff[e] = (kb * 4) * RAWCH + srow * RAWP + ((pc < 0 || pc > 17) ? 18 + (e & 1) : pc);
+  }
   const int tail_base = a.Cin - 16;                          // the last chunk re-reads [Cin-16, Cin) (duplicates have zero weights)
-  float raw[16];
+  f32x4 raw[4];
   auto issue_raw = [&](int c) {
     const int ch0 = (c == a.nchunk - 1) ? tail_base : c * 16;
     const uint32_t s0 = (uint32_t)ch0 * hw4;
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-      raw[k] = (WINO_ABL == 3 && c > 0) ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)svoff, (int)(s0 + k * hw4), 0));
+    for (int k = 0; k < 4; ++k)
+      raw[k] = (WINO_ABL == 3 && c > 0) ? f32x4{1.f, 1.f, 1.f, 1.f} : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)svoff, (int)(s0 + k * hw4), 0));
   };
   auto publish_raw = [&]() {
     if (stager) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) rawl[k * RAWCH + sidx] = raw[k] * sx;
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rawl[k * RAWCH + soff[e]] = raw[k][e] * sx;
     }
   };
 
@@ -128,6 +168,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
       load_row(ch, 0, de[ch]);
     }
     uint32_t* const vw = (uint32_t*)(vl + buf * VUNITS) + tvw;
+    WTR2(10);
+    WTR2_WAIT_LDS();
+    WTR2(11);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float t[2][4];
@@ -147,19 +190,31 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
         else if (c == 1) { v0 = t[0][1] + t[0][2]; v1 = t[1][1] + t[1][2]; }
         else if (c == 2) { v0 = t[0][2] - t[0][1]; v1 = t[1][2] - t[1][1]; }
         else { v0 = t[0][1] - t[0][3]; v1 = t[1][1] - t[1][3]; }
-        asm volatile("" : "+v"(v0));                        // (scalar fp32 VALU beside MFMAs: x3_split.h)
         const f32x2 vv = {v0, v1};
         const f16x2 hp = __builtin_convertvector(vv, f16x2);
-        float r0 = __builtin_fmaf((float)hp[0], -H2_LO_UP, v0 * H2_LO_UP);
-        float r1 = __builtin_fmaf((float)hp[1], -H2_LO_UP, v1 * H2_LO_UP);
-        asm volatile("" : "+v"(r0));
+        const f32x2 vu = vv * H2_LO_UP;                       // (the transform phase never runs beside this wave's own MFMAs)
+        const float r0 = __builtin_fmaf((float)hp[0], -H2_LO_UP, vu[0]);
+        const float r1 = __builtin_fmaf((float)hp[1], -H2_LO_UP, vu[1]);
         const f32x2 rr = {r0, r1};
         const int xi = r * 4 + c;
+        if (WINO_ABL == 6) {                                 // ablation 6: the arithmetic without the LDS writes (kept alive by an empty asm)
+          uint32_t k0 = __builtin_bit_cast(uint32_t, hp), k1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(rr, f16x2));
+          asm volatile("" ::"v"(k0), "v"(k1));
+          continue;
+        }
+        if (WINO_ABL == 7) {                                 // ablation 7: the LDS writes without the arithmetic
+          vw[(xi * 2 + 0) * 512] = __builtin_bit_cast(uint32_t, v0);
+          vw[(xi * 2 + 1) * 512] = __builtin_bit_cast(uint32_t, v1);
+          continue;
+        }
         vw[(xi * 2 + 0) * 512] = __builtin_bit_cast(uint32_t, hp);
         vw[(xi * 2 + 1) * 512] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rr, f16x2));
       }
       __builtin_amdgcn_sched_barrier(0);
+      WTR2(12 + r);
     }
+    WTR2_WAIT_LDS();
+    WTR2(16);
   };
 
   // ---- MFMA role: xi = 2 wave + {0, 1}; co-tiles by * 2 + {0, 1}; tile groups {0, 1} ----
@@ -189,35 +244,54 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
   const int bidx = g * 64 + j;                              // 16-B unit inside one [piece] plane pair: + (xi * 2 + piece) * 128 + tg * 32
   auto mfma = [&](int buf, int cnext) {
     const u32x4* const vb = vl + buf * VUNITS + bidx;
+    // The MFMA phase runs at raised priority: the partner wave of this SIMD is in its transform phase (VALU-dense), and VALU-class
+    // issue is arbitrated by priority, then AGE -- without this the younger waves' MFMAs starved behind the older waves' transform
+    // (s_memtime trace, profiles/r6_wino_trace.txt: 3 300 cycles for 24 MFMAs beside a transforming partner, 1 370 alone).
+    __builtin_amdgcn_s_setprio(WINO_PRIO);
+    WTR2(20);
+    // four stages (xi slot s, tile group t): the two B fragments of stage i + 1 are read before the MFMAs of stage i
+    u32x4 vbuf[2][2];
+    vbuf[0][0] = vb[((2 * wave) * 2 + 0) * 128];
+    vbuf[0][1] = vb[((2 * wave) * 2 + 1) * 128];
+    u32x4 udn[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int xi = 2 * wave + s;
-      if (WINO_ABL != 4) {
+    for (int i = 0; i < 4; ++i) {
+      const int s = i >> 1, t = i & 1, cur = i & 1;
+      if (i + 1 < 4) {
+        const int s1 = (i + 1) >> 1, t1 = (i + 1) & 1;
+        vbuf[cur ^ 1][0] = vb[((2 * wave + s1) * 2 + 0) * 128 + t1 * 32];
+        vbuf[cur ^ 1][1] = vb[((2 * wave + s1) * 2 + 1) * 128 + t1 * 32];
+      }
+      if (t == 0) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const u32x4 vh = vb[(xi * 2 + 0) * 128 + t * 32];
-          const u32x4 vlo = vb[(xi * 2 + 1) * 128 + t * 32];
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const u32x4 udn = h2_hi_down(ua[s][0][q]);
-            f32x16 m = acc[s][q][t];
-            m = mma_h(ua[s][1][q], vh, m);                  // lo * hi
-            m = mma_h(udn, vlo, m);                         // (hi * 2^-11) * (lo * 2^11)
-            m = mma_h(ua[s][0][q], vh, m);                  // hi * hi
-            acc[s][q][t] = m;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int q = 0; q < 2; ++q) udn[q] = h2_hi_down(ua[s][0][q]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      issue_u(s, cnext);                                    // the next chunk's fragments of this slot (clamped re-read at the end)
+      if (WINO_ABL != 4) {
+        // the two co-tiles' accumulators alternate: no MFMA waits for the one issued right before it
+        f32x16 m0 = acc[s][0][t], m1 = acc[s][1][t];
+        m0 = mma_h(ua[s][1][0], vbuf[cur][0], m0);            // lo * hi
+        m1 = mma_h(ua[s][1][1], vbuf[cur][0], m1);
+        m0 = mma_h(udn[0], vbuf[cur][1], m0);                 // (hi * 2^-11) * (lo * 2^11)
+        m1 = mma_h(udn[1], vbuf[cur][1], m1);
+        m0 = mma_h(ua[s][0][0], vbuf[cur][0], m0);            // hi * hi
+        m1 = mma_h(ua[s][0][1], vbuf[cur][0], m1);
+        acc[s][0][t] = m0;
+        acc[s][1][t] = m1;
+      }
       __builtin_amdgcn_sched_barrier(0);
+      WTR2(21 + i);
+      if (t == 1) {
+        issue_u(s, cnext);                                  // the next chunk's fragments of this slot (clamped re-read at the end)
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- main loop over the 16-channel chunks ----
   const int c_begin = 0, c_end = a.nchunk;
-  const bool tr_first = WINO_ABL == 5 || wave < 4;          // (wave-uniform)
+  const bool tr_first = WINO_ABL == 5 || (WINO_TR_FIRST_OLD ? wave < 4 : wave >= 4);          // (wave-uniform)
   issue_raw(c_begin);
   issue_u(0, c_begin);
   issue_u(1, c_begin);
@@ -229,22 +303,28 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
   for (int c = c_begin; c < c_end; ++c) {
     const int nb = (c - c_begin) & 1;
     const bool more = c + 1 < c_end;
+    WTR(0);
     if (more) publish_raw();                                // chunk c + 1 (loaded one iteration ago)
+    WTR(1);
     __syncthreads();
-    if (c + 2 < c_end) issue_raw(c + 2);
+    WTR(2);
+    issue_raw(c + 2 < c_end ? c + 2 : c_end - 1);            // (unconditional: a load behind a branch turns the graded vmcnt waits into vmcnt(0))
     const int cnext = more ? c + 1 : c;
-    // ONE copy of each phase (two copies in the arms of a branch cost 277 spilled registers: the accumulators did not stay in place);
-    // which one runs first is the wave's choice
-#pragma clang loop unroll(disable)
-    for (int ph = 0; ph < 2; ++ph) {
-      if ((ph == 0) == tr_first) {
-        if (more) transform(nb ^ 1);
-      } else {
-        mfma(nb, cnext);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    // ONE copy of the MFMA phase at a fixed place (two copies in the arms of a branch cost 277 spilled registers: the accumulators
+    // did not stay in place; a two-trip loop with the order as a run-time choice hid from the compiler that the phase runs exactly
+    // once, and its vmcnt waits for the U fragments then also waited for the raw loads issued just before -- 2 800 cycles per chunk in
+    // the waves that run their MFMAs first, profiles/r6_wino_trace.txt); the cheap transform phase has two guarded copies around it.
+    if (tr_first && more) transform(nb ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    WTR(3);
+    mfma(nb, cnext);
+    __builtin_amdgcn_sched_barrier(0);
+    WTR(4);
+    if (!tr_first && more) transform(nb ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    WTR(7);
     __syncthreads();
+    WTR(5);
   }
 
   // ---- epilogue: back to the operands' scale, exchange through LDS, output transform ----
@@ -303,6 +383,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
     }
   }
   if (want_amax) x3_amax_publish(ymax, a.y_amax);
+  WTR(6);
+#ifdef WINO_TRACE
+  if (blockIdx.x == 7 && lane == 0) a.dbg[8 * 1024 + wave] = (unsigned long long)ntr;
+#endif
 }
 
 // ---- weight pack: uq[(((chunk * 16 + xi) * 2 + piece) * CoT + cot) * 64 + lane] = 8 fp16 of U[xi] * 2^ew (k-group lane >> 5, row lane & 31) --
@@ -371,8 +455,17 @@ extern "C" int irr_conv_pack_weights_wino_h2(const float* w, void* uq, int Cin, 
   return 0;
 }
 
+#ifdef WINO_TRACE
+extern "C" int irr_wino_trace_read(unsigned long long* host) {      // (trace builds only; not part of include/irr_hip.h)
+  if (!g_wino_dbg) return IRR_EINVAL;
+  IRR_HIP_TRY(hipDeviceSynchronize());
+  IRR_HIP_TRY(hipMemcpy(host, g_wino_dbg, (8 * 1024 + 8) * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+#endif
+
 extern "C" int irr_conv2d_wino_eligible(int B, int Cin, int H, int W, int Cout) {
-  if (B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  if (B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || (W & 3)) return 0;          // (16-byte row loads)
   if ((long)Cin * H * W * 4 >= (1L << 31) || (long)Cout * H * W * 4 >= (1L << 31)) return 0;
   return 1;
 }
@@ -381,6 +474,7 @@ extern "C" int irr_conv2d_wino_fwd_h2(const float* x, const void* uq, const floa
                                       long x_bs, long y_bs, int lrelu, float alpha, const float* x_amax, int n_amax, float* y_amax,
                                       void* stream) {
   if (!x || !uq || !y || !x_amax || n_amax <= 0 || !irr_conv2d_wino_eligible(B, Cin, H, W, Cout)) return IRR_EINVAL;
+  if (((uintptr_t)x & 15) || (x_bs & 3) || (((long)H * W) & 3)) return IRR_EINVAL;
   WinoArgs a;
   a.x = x; a.uq = (const u32x4*)uq; a.bias = bias; a.y = y;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
@@ -388,6 +482,11 @@ extern "C" int irr_conv2d_wino_fwd_h2(const float* x, const void* uq, const floa
   a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16; a.ngy = a.CoT / 2;
   a.x_bs = x_bs; a.y_bs = y_bs; a.lrelu = lrelu; a.alpha = alpha;
   a.x_amax = x_amax; a.n_amax = n_amax; a.y_amax = y_amax;
+  a.dbg = nullptr;
+#ifdef WINO_TRACE
+  if (!g_wino_dbg) { IRR_HIP_TRY(hipMalloc((void**)&g_wino_dbg, (8 * 1024 + 8) * 8)); }
+  a.dbg = g_wino_dbg;
+#endif
   constexpr size_t lds_bytes = (size_t)2 * VUNITS * 16 + (size_t)16 * RAWCH * 4;
   static_assert(lds_bytes <= 160 * 1024, "V double buffer + raw patch must fit the 160 KiB LDS");
   static bool attr_set = false;
