@@ -354,11 +354,15 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   auto compute = [&](int y, int gbuf) {
     constexpr int NKW = NK / KW;                           // this wave's k-steps: wk, wk + KW, ...
     u32x4 af[NP];
+    // ring slot of x row (y - 1 + k), k = row + dy in [0, R + 2): ONE division per unit, then compare-and-subtract (round 6,
+    // profiles/r6_pmc_wgrad.txt: 1.9-3.6 scalar instructions per MFMA -- the division-by-constant sequence used to run in every stage)
+    const int ring0 = (y - 1 + RING) % RING;
     auto b_index = [&](int ki, int dy, int q) {
       const int ks = wk + KW * ki;
       const int gi = 2 * ks + g;
       const int row = gi / KG, grp = gi - row * KG;
-      const int slot = (y + row + dy - 1 + RING) % RING;
+      int slot = ring0 + row + dy;                           // < 2 RING: row + dy <= R + 1 < RING
+      slot = slot >= RING ? slot - RING : slot;
       return b_base + slot * XG + grp + MG + q * XPLANE;
     };
     auto read_a1 = [&](int ki, int p) {
