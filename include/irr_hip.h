@@ -348,6 +348,20 @@ int irr_conv2d_wgrad_h2_robust_side(int B, int Cin, int H, int W, int Cout, int 
 int irr_conv2d_wgrad_h2(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                         int B, int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs,
                         const float* x_amax, int nx, const float* gy_amax, int ng, void* stream);
+/* ABI 11 -- one operand scale per CHANNEL for the weight gradient's gy-role operand.  The fp32 convolution of the reference
+ * (models/pwc_modules.py:8-19) resolves a gradient row whatever its size; the plain fp16 pair of the operand in the kernel's gy role
+ * does so only within 2^17 of the tensor's scale.  irr_amax_channels_f32: out[c] = max |x[:, c]| over B plane-dense samples of C planes
+ * of hw floats (batch stride bs; accumulate = 1: max(out[c], ...) -- out holds zeros or earlier folds -- 0: out is overwritten); irr_conv2d_wgrad_h2_ch: irr_conv2d_wgrad_h2 with x_chmax (Cin floats) / gy_chmax (Cout floats) --
+ * only the one of the operand that irr_conv2d_wgrad_h2_robust_side does NOT name is read (robust side 1 -> gy_chmax, 0 -> x_chmax),
+ * the other may be NULL: that operand is scaled channel by channel and the scales are undone per row of dW. */
+int irr_amax_channels_f32(const float* x, int B, int C, long hw, long bs, float* out, int accumulate, void* stream);
+/* one-shot: the NEXT irr_conv2d_fwd_h2 launch of the calling thread (conv_x3_kernel: irr_conv2d_h2_eligible != 9001) folds
+ * max |y[:, co]| of what it stores into chmax[co] (Cout zero-initialised floats) -- the same maxima without a pass over y */
+int irr_conv_x3_next_chmax(float* chmax);
+int irr_conv2d_wgrad_h2_ch(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
+                           int B, int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs,
+                           const float* x_amax, int nx, const float* gy_amax, int ng,
+                           const float* x_chmax, const float* gy_chmax, void* stream);
 
 /* ---- tiny-Cout heads (Cout <= 4, stride 1): direct VALU kernels, same contracts as the MFMA entry points -------
  * conv_last 563->2 / 562->1, context tails 32->2 / 32->1, OccUpsampleNetwork.out_convs 32->1

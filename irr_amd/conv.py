@@ -236,13 +236,16 @@ def _h2_args(x3_args, x, x_amax, y_amax):
 def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, dil: int,
                  lrelu: bool, out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                  alpha: float = 1.0, accumulate: bool = False, real_cin: Optional[int] = None,
-                 x_amax: Optional[Amax] = None, y_amax: Optional[Amax] = None, bits_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 x_amax: Optional[Amax] = None, y_amax: Optional[Amax] = None, bits_out: Optional[torch.Tensor] = None,
+                 y_chmax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = [res +] alpha * act(conv(x, weight) + bias)   (accumulate: out += ...).
     real_cin: the layer's true input-channel count when x / weight are zero-padded copies (KernelTimer prices algorithmic FLOPs).
     x_amax: slots that bound |x| (MATH == "h2"; measured here when absent).  y_amax: a zeroed slot that holds max |out| after the
     call whatever kernel family ran (the h2 launch folds it in its epilogue, any other route costs one pass over out).
     bits_out: int32 tensor of x3s_mask_words(B, H, W) words that receives (out > 0) per element for conv_dgrad(mask_bits=...) -- the
-    caller has checked x3s_bits_ok for this layer."""
+    caller has checked x3s_bits_ok for this layer.
+    y_chmax: a ZEROED (Cout,) tensor that holds max |out[:, c]| per channel after the call (as gx_chmax of conv_dgrad): the scales of a
+    weight gradient that takes ``out`` as the operand in its kernel's gy role (a layer whose launch runs with exchanged roles)."""
     # (the LeakyReLU'-mask epilogue of the kernel is only used by conv_dgrad)
     B, cin, H, W = x.shape
     cout, cin_w, k, _ = weight.shape
@@ -286,6 +289,9 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                 hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
                 int(lrelu), float(alpha), int(accumulate), None, 0, 0, hip.stream())
         variant = None
+    if y_chmax is not None and h2 and code != 9001 and args[0] == "irr_conv2d_fwd_h2":
+        hip.lib().irr_conv_x3_next_chmax(y_chmax.data_ptr())      # (one-shot: the launch below)
+        y_chmax = None
     if TIMER is None:
         _call_conv(args)
     else:
@@ -295,6 +301,8 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                    nbytes=_map_bytes(B, H, W, cin) + _map_bytes(B, oh, ow, cout * (1 + (res is not None) + bool(accumulate))))
     if y_amax is not None and (not h2 or (code == 9001 and _X3S_NO_FUSED_AMAX)):
         amax_measure(out, y_amax)
+    if y_chmax is not None:                                 # (no launch folded them)
+        channel_amax(out, y_chmax)
     if _CHECK_FINITE and _CHECK_FINITE != "slots":
         _check_finite(f"conv_forward {tuple(x.shape)} -> {cout} code {code} h2 {h2}", out, x_amax, y_amax)
     return out
@@ -344,7 +352,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                mask: Optional[torch.Tensor] = None, nmask: int = 0,
                res: Optional[torch.Tensor] = None, alpha: float = 1.0, real_cin: Optional[int] = None,
                gy_amax: Optional[Amax] = None, gx_amax: Optional[Amax] = None, amax_channels: Optional[int] = None,
-               mask_bits: Optional[torch.Tensor] = None) -> torch.Tensor:
+               mask_bits: Optional[torch.Tensor] = None, gx_chmax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """gx (+)= conv_transpose(gy, weight); gy must already carry the activation derivative.
     mask/nmask: afterwards gx[:, :nmask] *= LeakyReLU'(mask[:, :nmask]) in the same launch (mask = the saved
     activation that produced this conv's input), i.e. gx comes out as a PRE-activation gradient.
@@ -352,7 +360,10 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
     gy_amax / gx_amax: as x_amax / y_amax of conv_forward (gx_amax bounds the COMPLETE gx: res, accumulate and mask included).
     amax_channels (Cout <= 2 heads only): gx_amax bounds gx[:, :amax_channels] instead of all of gx.
     mask_bits (with mask / nmask): the bits conv_forward(bits_out=...) wrote for `mask`; used instead of the fp32 tensor when this data
-    gradient runs on the fp16x2 streaming kernel (both layers passed x3s_bits_ok), ignored otherwise."""
+    gradient runs on the fp16x2 streaming kernel (both layers passed x3s_bits_ok), ignored otherwise.
+    gx_chmax: a ZEROED (Cin,) tensor that holds max |gx[:, c]| per channel of the complete gx after the call: folded by the launch's
+    epilogue on the fp16x2 form of conv_x3_kernel (irr_conv_x3_next_chmax), one pass over gx on every other route -- the scales of
+    the weight gradient that takes gx as its gy (conv_wgrad(gy_chmax=...))."""
     B, cout, oh, ow = gy.shape
     cout_w, cin, k, _ = weight.shape
     assert cout == cout_w
@@ -403,6 +414,10 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                     k, 1, dil, hip.bs(gy), hip.bs(gx), hip.bs(res) if res is not None else 0, 0, float(alpha),
                     int(accumulate), *margs, hip.stream())
             variant = None
+        fold_ch = gx_chmax is not None and h2 and code != 9001
+        if fold_ch:
+            hip.lib().irr_conv_x3_next_chmax(gx_chmax.data_ptr())      # (one-shot: the launch below)
+            gx_chmax = None
         if TIMER is None:
             _call_conv(args)
         else:
@@ -433,18 +448,56 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
             gx[:, :nmask] *= torch.where(mask[:, :nmask] > 0, 1.0, 0.1)
     if gx_amax is not None and (not h2 or (code == 9001 and _X3S_NO_FUSED_AMAX)):
         amax_measure(gx, gx_amax)
+    if gx_chmax is not None:                                # (no launch folded them)
+        channel_amax(gx, gx_chmax)
     if _CHECK_FINITE and _CHECK_FINITE != "slots":
         _check_finite(f"conv_dgrad {tuple(gy.shape)} -> {cin} dil {dil} stride {stride} h2 {h2}", gx, gy_amax, gx_amax)
     return gx
 
 
 
+# one operand scale per channel for the weight gradient's gy-role operand (round 6; IRR_WGRAD_CHANNEL_SCALE=0: the tensor's scale, A/B)
+WGRAD_CHANNEL_SCALE = os.environ.get("IRR_WGRAD_CHANNEL_SCALE", "1") != "0"
+
+
+# tensors above this size keep the tensor's one scale when nobody folded their channel maxima on the way (the 32-channel full-resolution
+# maps of the occlusion upsampler: 1.4 GB each, seven per call -- a pass over them would cost 2 ms per step)
+WGRAD_CHANNEL_PASS_MAX_BYTES = int(float(os.environ.get("IRR_WGRAD_CH_PASS_MAX_MB", "768")) * (1 << 20))
+
+
+CHANNEL_PASS_LOG = None
+
+
+def channel_amax(t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """max |t[:, c]| per channel of a plane-dense (B, C, H, W) tensor: (C,) float32, one HBM pass (irr_amax_channels_f32)"""
+    B, C, H, W = t.shape
+    if out is None:
+        out = zero_slots(t.device, C)                       # (pre-zeroed pool memory: no fill launch per call)
+    assert out.numel() == C and out.is_contiguous()
+    LAUNCHES["amax_channels"] += 1
+    if CHANNEL_PASS_LOG is not None:                        # (tools/r6_chs_census.py: which tensors still need a pass)
+        import traceback
+        CHANNEL_PASS_LOG.append((tuple(t.shape), [f.name for f in traceback.extract_stack(limit=8)][:-1]))
+    hip.call("irr_amax_channels_f32", hip.ptr(t), B, C, H * W, hip.bs(t), hip.ptr(out), 1, hip.stream())
+    return out
+
+
+def zero_slots(device, n: int) -> torch.Tensor:
+    """n zeroed float32 values for a launch to fold maxima into -- carved from the amax pool (one fill per pool, not per vector)"""
+    a = Amax.zeros(device, n)
+    return a.slots[a.first:a.first + a.n]
+
+
 def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil: int,
                gw: Optional[torch.Tensor] = None, gbias: Optional[torch.Tensor] = None, alpha: float = 1.0,
-               defer: Optional[ReduceBatch] = None, x_amax: Optional[Amax] = None, gy_amax: Optional[Amax] = None) -> torch.Tensor:
+               defer: Optional[ReduceBatch] = None, x_amax: Optional[Amax] = None, gy_amax: Optional[Amax] = None,
+               x_chmax: Optional[torch.Tensor] = None, gy_chmax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """gw += d/dW; gw (Cout,Cin,k,k) is created zeroed when not given.  gbias (optional, (Cout,)) += sum of gy over
     (b, h, w): the bias gradient comes out of the same launch (the gy tiles are staged there anyway).
-    ``defer``: the MFMA kernels leave the fold of their partial images to ``defer.run()`` (gw is complete only after it)."""
+    ``defer``: the MFMA kernels leave the fold of their partial images to ``defer.run()`` (gw is complete only after it).
+    x_chmax / gy_chmax (fp16x2 route): max |.| per channel of x / gy when a producer has folded them (conv_dgrad(gx_chmax=...)); the
+    operand in the kernel's gy role is scaled channel by channel from them -- measured here by one pass when absent and the operand
+    is not larger than WGRAD_CHANNEL_PASS_MAX_BYTES (above that: the tensor's one scale)."""
     cout, cin, k, _ = weight_shape
     B, _, H, W = x.shape
     _, _, oh, ow = gy.shape
@@ -477,7 +530,22 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, weight_shape, stride: int, dil
     if defer is not None:
         defer.begin()
     try:
-        if use_h2:
+        if use_h2 and WGRAD_CHANNEL_SCALE:
+            # one scale per channel for the operand in the kernel's gy role (the other one is robust element by element): its channel
+            # maxima from one pass over it, unless the caller has them
+            robust_x = bool(hip.lib().irr_conv2d_wgrad_h2_robust_side(B, cin, H, W, cout, dil))
+            role = gy if robust_x else x
+            chm = gy_chmax if robust_x else x_chmax
+            if callable(chm):                                # (measured lazily, on the stream this launch runs on: the DenseNet node's buffer maxima)
+                chm = chm()
+            if chm is None and role.numel() * 4 <= WGRAD_CHANNEL_PASS_MAX_BYTES:
+                chm = channel_amax(role)
+        if use_h2 and WGRAD_CHANNEL_SCALE and chm is not None:
+            assert chm.numel() == role.shape[1] and chm.is_contiguous() and chm.dtype == torch.float32
+            hip.call("irr_conv2d_wgrad_h2_ch", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
+                     cout, dil, hip.bs(x), hip.bs(gy), x_amax.ptr(), x_amax.n, gy_amax.ptr(), gy_amax.n,
+                     None if robust_x else chm.data_ptr(), chm.data_ptr() if robust_x else None, hip.stream())
+        elif use_h2:
             hip.call("irr_conv2d_wgrad_h2", hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), hip.ptr(gbias), float(alpha), B, cin, H, W,
                      cout, dil, hip.bs(x), hip.bs(gy), x_amax.ptr(), x_amax.n, gy_amax.ptr(), gy_amax.n, hip.stream())
         elif use_x3 and dil > 1:

@@ -15,7 +15,7 @@ import torch
 from . import hip
 from .conv_pack import LAUNCHES
 
-POOL_SLOTS = int(os.environ.get("IRR_AMAX_POOL", "4096"))      # (environment: diagnosis switch, profiles/NOTES.md C.5)
+POOL_SLOTS = int(os.environ.get("IRR_AMAX_POOL", "16384"))      # (environment: diagnosis switch, profiles/NOTES.md C.5)
 _POOLS = {}
 _STREAMS = {}        # device index -> streams whose kernels use slots (Amax.zeros callers, the weight-gradient lane: note_stream)
 
@@ -54,8 +54,8 @@ class Amax:
         pool = _POOLS.get(key)
         cur = torch.cuda.current_stream(device)
         note_stream(cur)
-        if pool is None or pool[1] + n > POOL_SLOTS:
-            t = torch.zeros(POOL_SLOTS, device=device, dtype=torch.float32)
+        if pool is None or pool[1] + n > pool[0].numel():
+            t = torch.zeros(max(POOL_SLOTS, n), device=device, dtype=torch.float32)
             filled = torch.cuda.Event()
             filled.record(cur)                                  # the fill is ordered on THIS stream only
             for s_ in _STREAMS.get(key, ()):                    # (see note_stream)

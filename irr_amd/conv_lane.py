@@ -133,6 +133,11 @@ class WgradSide:
         # weight gradients run under the MFMA-bound levels that follow.  Not under DDP bucket counting (on_queue set).
         self._hold = 0
         self._held = []
+        # here() ... there(): launches issued in between run on the ISSUING stream (their folds still run on the lane, which then
+        # waits for that stream first) -- lane schedule (c) of VERDICT r5 next #5: the HBM-bound levels 5-6 keep their weight gradients
+        # in line, the lane serves the MFMA-bound levels
+        self._here = 0
+        self._here_streams = []
         self._queue_stream = None               # stream the launches in _queued were issued from
         self._inline_streams = []               # inline lane: streams that issued a launch whose fold / report is still pending
         self.cross_stream_folds = 0             # (diagnostics) flushes that had to wait for another issuing stream
@@ -151,6 +156,16 @@ class WgradSide:
             for item in held:
                 self.launch(*item)
 
+    def here(self):
+        if not self.inline:
+            self._here += 1
+            return True
+        return False
+
+    def there(self):
+        if self._here > 0:
+            self._here -= 1
+
     def abandon(self):
         """Forget everything a backward pass that RAISED left behind (autograd skips its final callbacks then, so nobody joined):
         queued launches, pending contribution reports, fold jobs whose partial images belong to the failed pass, and the sticky
@@ -161,6 +176,7 @@ class WgradSide:
         self._inline_streams = []
         self._routed = {}
         self._held, self._hold = [], 0
+        self._here, self._here_streams = 0, []
         if self.batch is not None:
             self.batch.n, self.batch.keep, self.batch.targets = 0, [], set()
         self._join_queued = False
@@ -238,6 +254,10 @@ class WgradSide:
             self._inline_streams = []
         else:
             foreign = []
+        if not self.inline and self._here_streams:
+            for s_ in self._here_streams:                      # partial images written by in-line launches of a lane (here())
+                self.stream.wait_stream(s_)
+            self._here_streams = []
         if self.batch is not None and self.batch.n:
             if self.inline:
                 keep = self.batch.run()                        # (ordered after every issuing stream, above)
@@ -308,6 +328,18 @@ class WgradSide:
                 self.on_queue(*params)
             return
         cur = torch.cuda.current_stream()
+        if self._here > 0:
+            # in line on the issuing stream; what it accumulates into directly is ordered like any other kernel of that stream, its
+            # partial images are folded on the lane behind a wait for this stream (flush)
+            if self._queued:
+                self._kick()
+            fn()
+            self._pending.append(params)
+            if cur not in self._here_streams:
+                self._here_streams.append(cur)
+            if self.on_queue is not None and params[0] is not None:
+                self.on_queue(*params)
+            return
         if self._queued and self._queue_stream is not None and self._queue_stream != cur:
             self._kick()                                       # the parked launches were issued from another stream: hand them over first
         self._queue_stream = cur

@@ -17,7 +17,7 @@ from .conv_pack import LAUNCHES, _dense_column_packs, _padded_cin
 
 
 def wgrad_param(x, gy, weight, bias, stride: int, dil: int, want_bias: bool = True, alpha: float = 1.0,
-                acc=None, x_amax: Optional[Amax] = None, gy_amax: Optional[Amax] = None):
+                acc=None, x_amax: Optional[Amax] = None, gy_amax: Optional[Amax] = None, x_chmax=None, gy_chmax=None):
     """Weight (+bias) gradient of one conv use.  Returns (gw, gb) tensors for autograd -- or (None, None) when the
     result was accumulated asynchronously into the gradient arena (SIDE lane).  ``acc`` = optional (gw, gb) pair to
     accumulate into (shared weights used several times inside one autograd node).
@@ -26,6 +26,7 @@ def wgrad_param(x, gy, weight, bias, stride: int, dil: int, want_bias: bool = Tr
     if routed is not None:
         gwv, gbv = routed
         keep = (x, gy) if (x_amax is None or gy_amax is None) else (x, gy, x_amax.slots, gy_amax.slots)
+        keep = keep + tuple(t_ for t_ in (x_chmax, gy_chmax) if torch.is_tensor(t_))
 
         def fn():
             if _c._CHECK_FINITE == "slots" and x_amax is not None and gy_amax is not None:
@@ -35,7 +36,7 @@ def wgrad_param(x, gy, weight, bias, stride: int, dil: int, want_bias: bool = Tr
                     _c._FINITE_LOG.append((f"wgrad {tag} {tuple(t.shape)} -> w {tuple(weight.shape)}", torch.linalg.vector_norm(t, ord=inf),
                                            a.slots[a.first:a.first + a.n].max()))
             conv_wgrad(x, gy, weight.shape, stride, dil, gw=gwv, gbias=gbv if want_bias else None,
-                       alpha=alpha, defer=_c.SIDE.batch, x_amax=x_amax, gy_amax=gy_amax)
+                       alpha=alpha, defer=_c.SIDE.batch, x_amax=x_amax, gy_amax=gy_amax, x_chmax=x_chmax, gy_chmax=gy_chmax)
 
         _c.SIDE.launch(fn, keep, (weight, bias if (want_bias and gbv is not None) else None), gw=gwv)
         return None, None
@@ -45,7 +46,7 @@ def wgrad_param(x, gy, weight, bias, stride: int, dil: int, want_bias: bool = Tr
         gw = None
         gb = torch.zeros(weight.shape[0], device=x.device, dtype=torch.float32) if (want_bias and bias is not None) else None
     gw = conv_wgrad(x, gy, weight.shape, stride, dil, gw=gw, gbias=gb if want_bias else None, alpha=alpha,
-                    x_amax=x_amax, gy_amax=gy_amax)
+                    x_amax=x_amax, gy_amax=gy_amax, x_chmax=x_chmax, gy_chmax=gy_chmax)
     return gw, gb
 
 
@@ -256,13 +257,21 @@ class _DenseEstimatorFn(hip.Function):
         if _fwd_h2(buf[:, 448:ctot], ws[0], 1, 1):
             S = Amax.zeros(buf.device, 7)                        # (slot 6: the est slot behind the parts, when there is one)
         cat_channels_into(buf[:, 448:], parts, amax=S.sub(5) if S is not None else None)
+        # round 6: max |buf[:, c]| per channel, for the weight gradients whose launch takes the buffer as the operand in its gy role
+        # (conv3 / conv5: exchanged roles) -- every layer's launch folds its own slice, the input part costs one small pass
+        Bch = None
+        if S is not None and _c.WGRAD_CHANNEL_SCALE and any(ctx.needs_input_grad[3 + nparts:]):      # (a training pass: some weight wants its gradient)
+            Bch = _c.zero_slots(buf.device, ctot)
+            _c.channel_amax(buf[:, 448:ctot], Bch[448:ctot])
         off = 448
         for i in range(5):
             co = _DenseEstimatorFn.GROW[i]
             conv_forward(buf[:, off:ctot], ws[i], bs[i], 1, 1, True, out=buf[:, off - co:off],
-                         x_amax=S.sub(5 - i, i + 1) if S is not None else None, y_amax=S.sub(4 - i) if S is not None else None)
+                         x_amax=S.sub(5 - i, i + 1) if S is not None else None, y_amax=S.sub(4 - i) if S is not None else None,
+                         y_chmax=Bch[off - co:off] if Bch is not None else None)
             off -= co
         ctx.amax = S
+        ctx.bch = Bch
         if has_base:
             base_c = base if _planes_dense(base) else base.contiguous()
             out = conv_forward(buf[:, :ctot], ws[5], bs[5], 1, 1, False, res=base_c, alpha=1.0)
@@ -316,6 +325,30 @@ class _DenseEstimatorFn(hip.Function):
         # folds the magnitude of the slice it completes into slot k+1; slot 0 (the c5 slice) comes out of conv_last's data gradient
         S = ctx.amax
         Gs = Amax.zeros(dev, 6) if (S is not None or any(u == 2 for u in use_x3)) else None
+        # one scale per channel for the weight gradients' gy-role operand (round 6): the column launches fold the channel maxima of the
+        # gradient slice they complete (Gch); the layers whose launch runs with exchanged roles (Cout 96 / 32) need those of the
+        # forward buffer instead: ONE pass over it serves both (Bch)
+        ch_on = _c.WGRAD_CHANNEL_SCALE and S is not None and Gs is not None
+        Gch = _c.zero_slots(dev, ctot) if ch_on else None
+        Bch = [None]
+
+        def chmax_for(t0_, t1_, cout_):
+            """(x_chmax, gy_chmax) of the weight gradient of the layer with x = buf[:, t1_:ctot], gy = G[:, t0_:t1_]"""
+            if not ch_on:
+                return None, None
+            if hip.lib().irr_conv2d_wgrad_h2_robust_side(B, ctot - t1_, H, W, cout_, 1):
+                return None, (Gch[t0_:t1_] if Gch_valid[0] else None)
+            if ctx.bch is not None:                          # folded slice by slice in the forward pass
+                return ctx.bch[t1_:ctot], None
+            if buf[:, :ctot].numel() * 4 > 4 * _c.WGRAD_CHANNEL_PASS_MAX_BYTES:
+                return None, None
+
+            def lazy():                                      # runs inside the weight-gradient launch (on the lane when there is one): the first
+                if Bch[0] is None:                           # exchanged layer of the node measures the buffer, the second reuses it
+                    Bch[0] = _c.channel_amax(buf[:, :ctot])
+                return Bch[0][t1_:ctot]
+            return lazy, None
+        Gch_valid = [False]
         if g_est is not None:
             grads_w[5], grads_b[5] = wgrad_param(buf[:, :ctot], g_est, ctx.wobjs[5], ctx.bobjs[5], 1, 1)
             conv_dgrad(g_est, ws[5], 1, 1, (H, W), gx=G[:, :ctot], accumulate=True, mask=buf[:, :ctot], nmask=32,
@@ -327,9 +360,10 @@ class _DenseEstimatorFn(hip.Function):
             if Gs is not None:
                 amax_measure(G[:, :32], Gs.sub(0))
         packs = _dense_column_packs(ctx.wobjs[:5], cin0, tuple(use_x3))
+        xc_, gc_ = chmax_for(0, 32, 32)                     # (conv5's gy, the c5 slice, comes from conv_last's data gradient: no fold there)
         grads_w[4], grads_b[4] = wgrad_param(buf[:, 32:ctot], G[:, :32], ctx.wobjs[4], ctx.bobjs[4], 1, 1,
                                              x_amax=S.sub(1, 5) if S is not None else None,
-                                             gy_amax=Gs.sub(0) if Gs is not None else None)   # conv5
+                                             gy_amax=Gs.sub(0) if Gs is not None else None, x_chmax=xc_, gy_chmax=gc_)   # conv5
         bounds = [(32, 96), (96, 192), (192, 320), (320, 448), (448, ctot)]
         for k_, (t0, t1) in enumerate(bounds):
             last = k_ == 4
@@ -349,7 +383,13 @@ class _DenseEstimatorFn(hip.Function):
                            else (200000 if use_x3[k_] == 2 else 100000) + code)
                 if use_x3[k_] == 2:
                     args, _ = _h2_args(args, G[:, :t0], Gs.sub(0, k_ + 1), Gs.sub(k_ + 1) if not last else None)
+                    Gch_valid[0] = ch_on and not last and code != 9001
+                    if Gch_valid[0]:
+                        hip.lib().irr_conv_x3_next_chmax(Gch[t0:t1].data_ptr())      # (one-shot: this column's launch)
+                else:
+                    Gch_valid[0] = False
             else:
+                Gch_valid[0] = False
                 args = ("irr_conv2d_fwd_f32", hip.ptr(G), hip.ptr(packs[k_]), None, None, hip.ptr(G[:, t0:t1]), B, t0, H, W,
                         t1 - t0, H, W, 3, 1, 1, hip.bs(G), hip.bs(G), 0, 0, 1.0, 1, *margs, hip.stream())
                 variant = hip.lib().irr_conv2d_fwd_variant(B, t1 - t0, H, W, 3)
@@ -362,9 +402,11 @@ class _DenseEstimatorFn(hip.Function):
                 i = 3 - k_
                 if Gs is not None and use_x3[k_] != 2:
                     amax_measure(G[:, t0:t1], Gs.sub(k_ + 1))
+                xc_, gc_ = chmax_for(t0, t1, t1 - t0)
                 grads_w[i], grads_b[i] = wgrad_param(buf[:, t1:ctot], G[:, t0:t1], ctx.wobjs[i], ctx.bobjs[i], 1, 1,
                                                      x_amax=S.sub(k_ + 2, 4 - k_) if S is not None else None,
-                                                     gy_amax=Gs.sub(k_ + 1) if (Gs is not None and S is not None) else None)
+                                                     gy_amax=Gs.sub(k_ + 1) if (Gs is not None and S is not None) else None,
+                                                     x_chmax=xc_, gy_chmax=gc_)
         # g_est is still being read by the asynchronous wgrad lane (conv_last): autograd gets its own copy, because
         # the engine may accumulate the other gradients of `base` into the returned tensor IN PLACE
         gbase = g_est.clone() if (has_base and ctx.needs_input_grad[1]) else None
@@ -431,6 +473,7 @@ class _ConvChainFn(hip.Function):
                 in_amax[0] = x_amax
             else:
                 amax_measure(x, in_amax[0])
+        xch = [None] * (n + 1)                                 # channel maxima of layer i's INPUT, where its weight gradient wants them
         for i in range(n):
             stride, dil, lrelu = cfg[i]
             last = i == n - 1
@@ -445,8 +488,16 @@ class _ConvChainFn(hip.Function):
                     cur = conv_forward(cur, ws[i], bs[i], stride, dil, False, res=res_c, x_amax=in_amax[i])
                     acts.append(None)
             else:
-                cur = conv_forward(cur, ws[i], bs[i], stride, dil, lrelu, x_amax=in_amax[i], y_amax=ya)
+                ych = None
+                if (not last and _c.WGRAD_CHANNEL_SCALE and _c.MATH == "h2" and h2_in[i + 1] and ctx.needs_input_grad[4 + 2 * (i + 1)]
+                        and ws[i + 1].shape[2] == 3 and cfg[i + 1][0] == 1
+                        and not hip.lib().irr_conv2d_wgrad_h2_robust_side(shapes[i + 1][0], shapes[i + 1][1], shapes[i + 1][2], shapes[i + 1][3],
+                                                                         ws[i + 1].shape[0], cfg[i + 1][1])):
+                    ych = _c.zero_slots(x.device, ws[i].shape[0])      # layer i + 1's weight gradient scales THIS output channel by channel
+                cur = conv_forward(cur, ws[i], bs[i], stride, dil, lrelu, x_amax=in_amax[i], y_amax=ya, y_chmax=ych)
                 acts.append(cur)
+                xch[i + 1] = ych
+        ctx.xch = xch
         ctx.in_amax = in_amax
         ctx.cfg = cfg
         ctx.has_res = res is not None
@@ -489,15 +540,24 @@ class _ConvChainFn(hip.Function):
             g = gpre
         elif ga is not None:
             amax_measure(g, ga)
+        gch = None                                             # channel maxima of g when the launch that produced it folded them (round 6)
         for i in range(n - 1, -1, -1):
             stride, dil, _ = cfg[i]
             inp = acts[i - 1] if i > 0 else x
-            grads[2 * i], grads[2 * i + 1] = wgrad_param(inp, g, ws[i], ctx.bias_objs[i], stride, dil, x_amax=in_amax[i], gy_amax=ga)
+            grads[2 * i], grads[2 * i + 1] = wgrad_param(inp, g, ws[i], ctx.bias_objs[i], stride, dil, x_amax=in_amax[i], gy_amax=ga,
+                                                         gy_chmax=gch, x_chmax=ctx.xch[i])
             gxa = gslots.sub(i - 1) if (i > 0 and need_g[i - 1]) else None
+            gch = None
             if i > 0:
                 prev_lrelu = cfg[i - 1][2]
+                # layer i - 1's weight gradient takes this launch's output as its gy: fold its channel maxima here when that launch
+                # will scale it channel by channel (fp16x2 route, gy in the kernel's gy role)
+                if (_c.WGRAD_CHANNEL_SCALE and _c.MATH == "h2" and in_amax[i - 1] is not None and gxa is not None and ws[i - 1].shape[2] == 3
+                        and cfg[i - 1][0] == 1 and hip.lib().irr_conv2d_wgrad_h2_robust_side(gshape[i - 1][0], ws[i - 1].shape[1], gshape[i - 1][2],
+                                                                                         gshape[i - 1][3], ws[i - 1].shape[0], cfg[i - 1][1])):
+                    gch = _c.zero_slots(dev, inp.shape[1])
                 g = conv_dgrad(g, ws[i], stride, dil, inp.shape[2:], mask=inp if prev_lrelu else None,
-                               nmask=inp.shape[1] if prev_lrelu else 0, gy_amax=ga, gx_amax=gxa)
+                               nmask=inp.shape[1] if prev_lrelu else 0, gy_amax=ga, gx_amax=gxa, gx_chmax=gch)
             elif ctx.needs_input_grad[0]:
                 g = conv_dgrad(g, ws[i], stride, dil, inp.shape[2:], gy_amax=ga)
             else:
@@ -525,6 +585,7 @@ def conv_chain(x, layers, res=None):
 # ----------------------------------------------------------------------------------------------
 
 _KEEP_LOG = [] if os.environ.get("IRR_OCCUP_KEEP_LOG") else None      # diagnosis: (name, tensor) of the node's gradient maps, tools/lane_race_probe.py
+_LANE_OCCUP_INLINE = os.environ.get("IRR_LANE_OCCUP_INLINE", "0") != "0"    # lane schedule (c), VERDICT r5 next #5 (profiles/r6_lane.txt): levels 5-6 keep their weight gradients in line
 _LANE_HOLD_OCCUP = os.environ.get("IRR_LANE_HOLD_OCCUP", "0") != "0"      # lane schedule (a) of VERDICT r4 item 4, profiles/r5_lane_schedules.txt
 
 
@@ -596,11 +657,14 @@ class _OccUpsampleFn(hip.Function):
     def backward(ctx, g_out):
         # (IRR_LANE_HOLD_OCCUP: the node's weight-gradient launches reach the lane only when its data-gradient chain has been issued)
         held = _c.SIDE.hold() if (_LANE_HOLD_OCCUP and _c.SIDE is not None) else False
+        here = _c.SIDE.here() if (_LANE_OCCUP_INLINE and _c.SIDE is not None and not held) else False
         try:
             return _OccUpsampleFn._backward(ctx, g_out)
         finally:
             if held:
                 _c.SIDE.release()
+            if here:
+                _c.SIDE.there()
 
     @staticmethod
     def _backward(ctx, g_out):

@@ -70,6 +70,11 @@ struct WX3Args {
   const float* x_amax;
   const float* g_amax;
   int nx_amax, ng_amax;
+  // round 6: nullable -- max |.| of EVERY channel of the gy-role operand (a.Cout floats).  The plain fp16 pair of that operand carries
+  // full precision only within 2^17 of its scale: with one scale per CHANNEL (= per output row of dW, undone per row at the flush) a
+  // channel that is 1e-6 of the tensor's loudest keeps fp32 accuracy relative to its own range (Adam divides every
+  // element by its own sqrt(v), so a quiet filter's gradient row matters as much as a loud one's).
+  const float* g_chmax;
 };
 
 
@@ -182,6 +187,12 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   float bsum[GR];
 #pragma unroll
   for (int r = 0; r < GR; ++r) bsum[r] = 0.f;
+  float sgc[GR];                                            // H2: the scale of each gy staging role (its channel's own, or the tensor's)
+#pragma unroll
+  for (int r = 0; r < GR; ++r) {
+    sgc[r] = sg;
+    if (H2 && a.g_chmax && gu[r] >= 0 && co0 + RU_CH(gu[r]) < a.Cout) sgc[r] = ldexpf(1.f, x3_h2_exp(a.g_chmax[co0 + RU_CH(gu[r])]));
+  }
   constexpr bool XB = NW == 1;                              // (only the one-tile-wide blocks ever run with exchanged roles)
   float xsum[XB ? XR : 1];
 #pragma unroll
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
 #if WX3_ABL == 1
         h = __builtin_bit_cast(u32x4, graw[r][0]); m = __builtin_bit_cast(u32x4, graw[r][1]); l = h;
 #else
-        if (H2) split8_h2(v, sg, h, m);
+        if (H2) split8_h2(v, sgc[r], h, m);
         else split8(v, h, m, l);
 #endif
         const int idx = RU_CH(gu[r]) * GPITCH + (gbuf * R + RU_RR(gu[r])) * KG + RU_GRP(gu[r]);
@@ -580,14 +591,20 @@ __global__ __launch_bounds__(MW* NW * KW * 64) void conv_wgrad_x3_kernel(const W
   // ---- flush: ws[blockIdx.x][co][tap][ci] = alpha * acc (lanes = ci: coalesced stores; wgrad_reduce_x3_kernel sums the
   // partials in a fixed order: no atomics, no zero-fill of the workspace, bit-reproducible weight gradients) ----
   float* const wsp = a.ws + (long)bx * a.n;
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    if (KW > 1 && wk > 0) break;
+  if (!(KW > 1 && wk > 0)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
       const int ci = ci0 + wn * 32 + j;
-      if (co < a.Cout && ci < a.Cin) wsp[((long)co * 9 + t) * a.Cin + ci] = H2 ? a.alpha * ((acc[t][r] * unscale_x) * unscale_g) : a.alpha * acc[t][r];
+      // (the row's own scale, once per row: with the exponent arithmetic inside the tap loop the flush of the short launches of the
+      // small pyramid levels took longer than their pixel walk)
+      float ug = unscale_g;
+      if (H2 && a.g_chmax && co < a.Cout) ug = ldexpf(1.f, -x3_h2_exp(a.g_chmax[co]));
+      const float us = H2 ? a.alpha * ug : a.alpha;
+      if (co < a.Cout && ci < a.Cin) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wsp[((long)co * 9 + t) * a.Cin + ci] = H2 ? (acc[t][r] * unscale_x) * us : us * acc[t][r];
+      }
     }
   }
   if constexpr (XB) if (a.xbias && bz == 0) {
@@ -822,14 +839,16 @@ static int launch_dil(const WX3Args& a, int kg, hipStream_t st) {
 
 static int wgrad_x3_dil_impl(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
                              int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs, const float* x_amax, int nx,
-                             const float* g_amax, int ng, void* stream) {
+                             const float* g_amax, int ng, void* stream, const float* gy_chmax = nullptr) {
   if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (W % 4) || !dil_ok(Cout, W, dil)) return IRR_EINVAL;
   const long n = (long)Cout * Cin * 9;
   hipStream_t st = (hipStream_t)stream;
   WX3Args a;
   a.ws = ws; a.gbias = gbias; a.xbias = nullptr; a.alpha = alpha;
+  a.g_chmax = nullptr;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.x_bs = x_bs; a.gy_bs = gy_bs;
   a.x_amax = x_amax; a.nx_amax = nx; a.g_amax = g_amax; a.ng_amax = ng;
+  a.g_chmax = gy_chmax;                                     // (dilated launches never exchange the roles)
   const long lim = (1L << 29) - 64;
   const long bsmax = x_bs > gy_bs ? x_bs : gy_bs;
   long per = bsmax > 0 ? (lim - (long)(Cin > Cout ? Cin : Cout) * H * W) / bsmax : B;
@@ -880,7 +899,7 @@ extern "C" int irr_conv2d_wgrad_h2_robust_side(int B, int Cin, int H, int W, int
 
 static int wgrad_x3_impl(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
                          int Cin, int H, int W, int Cout, long x_bs, long gy_bs, const float* x_amax, int nx,
-                         const float* g_amax, int ng, void* stream) {
+                         const float* g_amax, int ng, void* stream, const float* x_chmax = nullptr, const float* gy_chmax = nullptr) {
   if (!x || !gy || !gw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return IRR_EINVAL;
   if ((W % 4) && (((uintptr_t)x | (uintptr_t)gy) & 3)) return IRR_EINVAL;
   const long n = (long)Cout * Cin * 9;
@@ -902,6 +921,7 @@ static int wgrad_x3_impl(const float* x, const float* gy, float* gw, float* ws, 
   const bool swapped = (cot == 1 && !ksplit) || sw4;
   if (swapped != wx3_roles_exchanged(Cin, Cout)) return IRR_EINVAL;          // (one rule, stated twice: keep them together)
   WX3Args a;
+  a.g_chmax = nullptr;
   a.ws = ws; a.gbias = swapped ? nullptr : gbias; a.xbias = swapped ? gbias : nullptr; a.alpha = alpha;
   a.H = H; a.W = W;
   a.Cin = swapped ? Cout : Cin;
@@ -910,6 +930,7 @@ static int wgrad_x3_impl(const float* x, const float* gy, float* gw, float* ws, 
   a.gy_bs = swapped ? x_bs : gy_bs;
   a.x_amax = swapped ? g_amax : x_amax; a.nx_amax = swapped ? ng : nx;
   a.g_amax = swapped ? x_amax : g_amax; a.ng_amax = swapped ? nx : ng;
+  a.g_chmax = swapped ? x_chmax : gy_chmax;                                 // the channel maxima of the tensor in the kernel's gy role
   const long lim = (1L << 29) - 64;                                        // elements: byte voffsets below the 2 GiB marker
   const long bsmax = x_bs > gy_bs ? x_bs : gy_bs;
   long per = bsmax > 0 ? (lim - (long)(Cin > Cout ? Cin : Cout) * H * W) / bsmax : B;
@@ -964,4 +985,19 @@ extern "C" int irr_conv2d_wgrad_h2(const float* x, const float* gy, float* gw, f
   if (!x_amax || !gy_amax || nx <= 0 || ng <= 0 || dil < 1) return IRR_EINVAL;
   if (dil > 1) return wgrad_x3_dil_impl(x, gy, gw, ws, gbias, alpha, B, Cin, H, W, Cout, dil, x_bs, gy_bs, x_amax, nx, gy_amax, ng, stream);
   return wgrad_x3_impl(x, gy, gw, ws, gbias, alpha, B, Cin, H, W, Cout, x_bs, gy_bs, x_amax, nx, gy_amax, ng, stream);
+}
+
+// irr_conv2d_wgrad_h2 with one scale per CHANNEL of the operand in the kernel's gy role (round 6; ABI 11): x_chmax (Cin floats) /
+// gy_chmax (Cout floats) = max |.| of every channel of x / gy, e.g. from irr_amax_channels_f32; only the one that
+// irr_conv2d_wgrad_h2_robust_side names as NOT robust is read (robust side 1 -> gy_chmax, 0 -> x_chmax), the other may be NULL.
+extern "C" int irr_conv2d_wgrad_h2_ch(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha, int B,
+                                      int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs, const float* x_amax, int nx,
+                                      const float* gy_amax, int ng, const float* x_chmax, const float* gy_chmax, void* stream) {
+  if (!x_amax || !gy_amax || nx <= 0 || ng <= 0 || dil < 1) return IRR_EINVAL;
+  if (dil > 1) {
+    if (!gy_chmax) return IRR_EINVAL;
+    return wgrad_x3_dil_impl(x, gy, gw, ws, gbias, alpha, B, Cin, H, W, Cout, dil, x_bs, gy_bs, x_amax, nx, gy_amax, ng, stream, gy_chmax);
+  }
+  if (!(wx3_roles_exchanged(Cin, Cout) ? x_chmax : gy_chmax)) return IRR_EINVAL;
+  return wgrad_x3_impl(x, gy, gw, ws, gbias, alpha, B, Cin, H, W, Cout, x_bs, gy_bs, x_amax, nx, gy_amax, ng, stream, x_chmax, gy_chmax);
 }

@@ -36,6 +36,8 @@ static unsigned long long* g_x3s_dbg = nullptr;
 #define X3_ABL 0     // ablation builds (timing only, results wrong): 1 = no weight loads in the loop, 2 = no LDS reads in the loop,
 #endif               // 3 = producers skip their global loads, 4 = independent accumulators (no dependent MFMA chain)
 
+int irr_amax_channels_launch(const float* x, int B, int C, long hw, long bs, float* out, hipStream_t st, bool zero);      // misc.hip
+
 namespace {
 
 constexpr uint32_t OOB = 0x80000000u;     // voffset marker: beyond num_records -> the load returns 0, touches nothing
@@ -64,6 +66,7 @@ struct X3Args {
   const float* x_amax;                     // max |x| of the input tensor = max over n_amax device slots -> the operand scale
   int n_amax;
   float* y_amax;                           // nullable: slot that receives max |y| of this launch's output (atomic max on the bit pattern)
+  float* y_chmax;                          // nullable (round 6): Cout slots that receive max |y[:, co]| PER OUTPUT CHANNEL (irr_conv_x3_next_chmax)
 };
 
 // Block = CT*PG symmetric waves, two blocks per CU (256 registers per wave, 128 of them accumulators): every wave
@@ -256,6 +259,10 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
   }
   float ymax = 0.f;
   const bool want_amax = NP == 2 && a.y_amax != nullptr && a.ksplit <= 1;
+  const bool want_ch = NP == 2 && a.y_chmax != nullptr && a.ksplit <= 1;
+  float chm[16];                                           // max |stored value| of this lane per accumulator row (= output channel)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) chm[r] = 0.f;
 
   // ---- epilogue: D[i][jj], i = (r&3) + 8*(r>>2) + 4*g, jj = lane&31 ----
   const long ohw = hw;
@@ -305,6 +312,7 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
           if (a.lrelu) v = irr_lrelu(v);
           v *= a.alpha;
           if (want_amax && vo[k] != OOB) ymax = x3_amax_fold(ymax, v);
+          if (want_ch && vo[k] != OOB) chm[r0 + k] = x3_amax_fold(chm[r0 + k], v);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)vo[k], 0, 0);
         }
         continue;
@@ -328,13 +336,35 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
         v += dv[k];                                   // 0 unless accumulating
         if (a.mask && co < a.nmask) v *= irr_lrelu_grad(mv[k]);
         if (want_amax && vo[k] != OOB) ymax = x3_amax_fold(ymax, v);
+        if (want_ch && vo[k] != OOB) chm[r] = x3_amax_fold(chm[r], v);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)vo[k], 0, 0);
       }
     }
   }
   if (want_amax) x3_amax_publish(ymax, a.y_amax);
+  if (want_ch) {
+    // the 32 lanes of a half-wave hold the 32 pixels of one accumulator row each: fold them; then lane j = r of each half looks at the
+    // slot of row r and raises it when it has to -- sixteen lanes, one round trip (sixteen dependent look-then-atomic sequences at the
+    // end of every wave cost these launches 8 %)
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      uint32_t mb = __builtin_bit_cast(uint32_t, chm[r]);
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)mb, off, 64);
+        mb = o > mb ? o : mb;
+      }
+      mine = j == r ? mb : mine;
+    }
+    if (j < 16) {
+      const int co = cot * 32 + (j & 3) + 8 * (j >> 2) + 4 * g;
+      if (co < a.Cout) x3_amax_commit(__builtin_bit_cast(float, mine), a.y_chmax + co);
+    }
+  }
 }
 
+static thread_local float* g_next_chmax = nullptr;   // (irr_conv_x3_next_chmax)
 static std::atomic<int> g_min_blocks{384};     // (the ONE process-wide routing policy, see irr_conv_x3_set_min_blocks) launches with fewer blocks cannot fill 256 CUs x 2 blocks: they stay on the fp32 kernels
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1041,7 +1071,10 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
                        float alpha, int accumulate, const float* mask, long mask_bs, int nmask, float* ws, long ws_elems,
                        void* stream, float* y2 = nullptr, long y2_bs = 0, int np = 3, const float* x_amax = nullptr, int n_amax = 0,
                        float* y_amax = nullptr, const uint32_t* mask_bits = nullptr, uint32_t* bits_out = nullptr) {
+  float* const next_chmax = g_next_chmax;                   // (irr_conv_x3_next_chmax: consumed by this launch, whatever happens to it)
+  g_next_chmax = nullptr;
   if (!x || !wq || !y || B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1) return IRR_EINVAL;
+  if (next_chmax && (np != 2 || x3s_ok(B, Cin, H, W, Cout, dil))) return IRR_EINVAL;      // only the fp16x2 form of conv_x3_kernel folds channel maxima
   if (y2 && (!res || accumulate || mask || !x3s_ok(B, Cin, H, W, Cout, dil))) return IRR_EINVAL;      // second output: streaming kernel only
   if (np == 2 && (!x_amax || n_amax <= 0)) return IRR_EINVAL;
   // bit masks: the fp16x2 streaming kernel with one co-tile only; a launch either writes them (plain forward) or reads them
@@ -1141,6 +1174,7 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
   a.ksplit = (ws && (long)p.ksplit * B * Cout * H * W <= ws_elems) ? p.ksplit : 1;     // no scratch: run unsplit (slower, same result class)
   a.part = ws;
   a.x_amax = x_amax; a.n_amax = n_amax; a.y_amax = y_amax;
+  a.y_chmax = np == 2 ? next_chmax : nullptr;
   // 32-bit byte voffsets below the 2 GiB out-of-range marker: split the batch accordingly
   const long lim = (1L << 29) - (long)(Cin + 16) * H * W - 64;        // elements
   if (lim <= 0) return IRR_EINVAL;
@@ -1181,6 +1215,9 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
       hipLaunchKernelGGL(x3_splitk_epilogue_kernel, dim3((unsigned)irr_cdiv(n, 256)), dim3(256), 0, st, ws, bias, a.res, a.y, a.mask, a.B,
                          Cout, (long)H * W, a.ksplit, y_bs, res_bs, mask_bs, nmask, lrelu, alpha, accumulate, np == 2 ? y_amax : nullptr);
       IRR_LAUNCH_CHECK();
+      // (channel maxima of a K-split launch: the small pyramid levels -- one pass over the finished slice of y instead of a fold in
+      // an element-wise kernel whose blocks straddle the 42 ... 672-pixel planes)
+      if (a.y_chmax) { const int rc2 = irr_amax_channels_launch(a.y, a.B, Cout, (long)H * W, y_bs, a.y_chmax, st, false); if (rc2) return rc2; }
     }
   }
   return 0;
@@ -1242,4 +1279,13 @@ extern "C" int irr_conv2d_fwd_h2_dual(const float* x, const void* wq, const floa
   if (!y2 || !res) return IRR_EINVAL;
   return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, 0, nullptr, 0, 0, nullptr, 0, stream,
                      y2, y2_bs, 2, x_amax, n_amax, y_amax);
+}
+
+// The NEXT irr_conv2d_fwd_h2 launch of the calling thread (forward or data gradient on conv_x3_kernel, not the streaming 32-channel
+// kernel: irr_conv2d_h2_eligible != 9001) additionally folds max |y[:, co]| of what it stores into chmax[co], co < Cout (atomic max on
+// non-negative bit patterns: pre-set the slots to 0; a launch that accumulates into y folds the accumulated values).  One-shot:
+// consumed by that launch.  The scales of the weight gradient's gy-role operand (irr_conv2d_wgrad_h2_ch) without a pass over it.
+extern "C" int irr_conv_x3_next_chmax(float* chmax) {
+  g_next_chmax = chmax;
+  return 0;
 }

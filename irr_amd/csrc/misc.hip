@@ -1,6 +1,6 @@
 #include "common.h"
 #include "amax.h"
-extern "C" int irr_abi_version(void) { return 10; }   // 10: Winograd F(2x2,3x3) forward on the fp16x2 arithmetic (irr_conv2d_wino_fwd_h2, experimental); 9: bit masks for the streaming kernel (irr_conv2d_fwd_h2_bits); 8: the legacy Correlation operator at any parameter point (irr_corr_general_*); 7: the fp16x2 pairs of activation-side operands carry a scaled-up low piece (range 2^17 -> 2^29 per element; irr_conv2d_wgrad_h2_robust_side); 6: the streaming 32-channel kernel takes the fp16x2 form too (irr_conv2d_fwd_h2_dual); 5: fp16x2 ("h2") conv entry points + amax slots; 4: loss reductions take a partial-sum scratch (fixed summation order); 3: Adam scalars are doubles
+extern "C" int irr_abi_version(void) { return 11; }   // 11: one operand scale per channel for the weight gradient's gy-role operand (irr_conv2d_wgrad_h2_ch, irr_amax_channels_f32); 10: Winograd F(2x2,3x3) forward on the fp16x2 arithmetic (irr_conv2d_wino_fwd_h2, experimental); 9: bit masks for the streaming kernel (irr_conv2d_fwd_h2_bits); 8: the legacy Correlation operator at any parameter point (irr_corr_general_*); 7: the fp16x2 pairs of activation-side operands carry a scaled-up low piece (range 2^17 -> 2^29 per element; irr_conv2d_wgrad_h2_robust_side); 6: the streaming 32-channel kernel takes the fp16x2 form too (irr_conv2d_fwd_h2_dual); 5: fp16x2 ("h2") conv entry points + amax slots; 4: loss reductions take a partial-sum scratch (fixed summation order); 3: Adam scalars are doubles
 
 // ---- channel concatenation of up to IRR_CAT_MAX_PARTS tensors in ONE launch (include/irr_hip.h) ----------------------------
 // The decoder input of a level is cat([cost volume, projected features, flow, occlusion]) (models/IRR_PWC.py:104-107) and the
@@ -132,4 +132,60 @@ extern "C" int irr_add_planes_f32(float* out, const float* x, const float* y, in
   else hipLaunchKernelGGL(add_planes_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, out, x, y, n, out_bs, x_bs, y_bs);
   IRR_LAUNCH_CHECK();
   return 0;
+}
+
+// ---- max |x| per CHANNEL (round 6): out[c] = max over (b, pixels) of |x[b, c, :]| for B plane-dense samples -- the scales of the weight
+// gradient's gy-role operand (irr_conv2d_wgrad_h2_ch).  A block takes one channel and about 16K floats of it: a chunk of one plane, or
+// the whole planes of several samples at the small pyramid levels (one block per (sample, channel) plane of 42 floats was launch-bound:
+// 36 000 blocks for a 6 MB tensor); 16-byte loads where a plane allows; the bit-pattern fold of amax.h, one look at the slot + at most
+// one atomic max per block.  HBM-bound on the large maps.
+namespace {
+__global__ __launch_bounds__(256) void amax_channels_kernel(const float* __restrict__ x, int B, long hw, long bs, float* __restrict__ out, long chunk,
+                                                            int spb, int vec) {
+  const int c = blockIdx.y;
+  float m = 0.f;
+  if (spb > 1) {                                            // small planes: samples [b0, b0 + spb) of channel c, whole planes
+    const int b0 = blockIdx.x * spb, b1 = min(B, b0 + spb);
+    const long n = (long)(b1 - b0) * hw;
+    for (long i = threadIdx.x; i < n; i += 256) {
+      const long bb = i / hw, p = i - bb * hw;
+      m = x3_amax_fold(m, x[(b0 + bb) * bs + (long)c * hw + p]);
+    }
+  } else {
+    const int b = blockIdx.z;
+    const long p0 = (long)blockIdx.x * chunk, p1 = min(hw, p0 + chunk);
+    const float* xp = x + (long)b * bs + (long)c * hw;
+    if (vec) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      for (long p = p0 + 4L * threadIdx.x; p < p1; p += 1024) {
+        const f4 v = *(const f4*)(xp + p);
+        m = x3_amax_fold(x3_amax_fold(x3_amax_fold(x3_amax_fold(m, v[0]), v[1]), v[2]), v[3]);
+      }
+    } else {
+      for (long p = p0 + threadIdx.x; p < p1; p += 256) m = x3_amax_fold(m, xp[p]);
+    }
+  }
+  x3_amax_publish_block256(m, out + c);
+}
+}  // namespace
+
+// (also called by conv_x3.hip behind a K-split launch that was asked for channel maxima: accumulate = the slots already hold folds)
+int irr_amax_channels_launch(const float* x, int B, int C, long hw, long bs, float* out, hipStream_t st, bool zero) {
+  if (zero) IRR_HIP_TRY(irr_zero_async(out, (size_t)C * 4, st));
+  const int vec = ((hw & 3) == 0 && (bs & 3) == 0 && (((uintptr_t)x) & 15) == 0) ? 1 : 0;
+  const long chunk = 16384;                                 // floats per block
+  if (hw * 2 <= chunk) {
+    const int spb = (int)(chunk / hw);
+    hipLaunchKernelGGL(amax_channels_kernel, dim3((unsigned)((B + spb - 1) / spb), (unsigned)C, 1), dim3(256), 0, st, x, B, hw, bs, out, chunk, spb, 0);
+  } else {
+    const long nchunks = (hw + chunk - 1) / chunk;
+    hipLaunchKernelGGL(amax_channels_kernel, dim3((unsigned)nchunks, (unsigned)C, (unsigned)B), dim3(256), 0, st, x, B, hw, bs, out, chunk, 1, vec);
+  }
+  IRR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int irr_amax_channels_f32(const float* x, int B, int C, long hw, long bs, float* out, int accumulate, void* stream) {
+  if (!x || !out || B <= 0 || C <= 0 || hw <= 0 || B > 65535 || C > 65535) return IRR_EINVAL;
+  return irr_amax_channels_launch(x, B, C, hw, bs, out, (hipStream_t)stream, !accumulate);
 }

@@ -378,10 +378,9 @@ def test_streaming_kernel_quiet_regions_keep_fp32_accuracy(case, ratio, h2_every
 def test_h2_weight_gradient_of_quiet_channels(case, side, ratio, h2_everywhere):
     """For the weight gradient the sample / pixel axes are the SUMMATION axis (a quiet sample is as invisible in the fp32 sum as in
     ours); what has its own output region is a quiet CHANNEL: half the input channels of x (columns of dW) or half the channels of
-    gy (rows of dW) scaled by 1e-5 ... 1e-7.  The operand in the kernel's x role carries the scaled-up low piece (2^28 : 1), the one
-    in its gy role the plain pair (2^17 : 1 at full precision, absolute 2^-25 of the tensor's scale below): the x-role side must
-    stay within 4x of the fp32-MFMA kernel at every ratio, the gy-role side within 4x down to 1e-5 and within the documented
-    absolute bound (2^-24 of the tensor maximum per element: 40x fp32 at 1e-6, 400x at 1e-7) below."""
+    gy (rows of dW) scaled by 1e-5 ... 1e-7.  The operand in the kernel's x role carries the scaled-up low piece (2^28 : 1 element by
+    element), the one in its gy role the plain pair under ONE SCALE PER CHANNEL (round 6): both sides stay within 4x of the fp32-MFMA
+    kernel at every ratio."""
     from irr_amd import conv as C, hip
     cin, cout, dil, B, H, W = case
     x, w, gy = _operands(case, "unit")
@@ -401,8 +400,7 @@ def test_h2_weight_gradient_of_quiet_channels(case, side, ratio, h2_everywhere):
         err[m] = _rel(gw[qi], wref)
     if not C.LAUNCHES["wgrad_h2"]:
         pytest.skip("this shape's weight gradient does not run on the fp16x2 kernel")
-    robust = bool(hip.lib().irr_conv2d_wgrad_h2_robust_side(B, cin, H, W, cout, dil)) == (side == "x_channels")
-    if robust or ratio >= 1e-5:
-        assert err["h2"] <= max(4 * err["f32"], 1e-6), (side, ratio, err)
-    else:
-        assert err["h2"] <= max(4 * err["f32"], 2.0 ** -24 / ratio * 8), (side, ratio, err)
+    # round 6: BOTH sides at every ratio -- the operand in the kernel's x role is robust element by element, the one in its gy role
+    # carries one scale per channel (irr_conv2d_wgrad_h2_ch; VERDICT r5 weak #1: the old bound let a 480 % error of a quiet row pass)
+    assert C.LAUNCHES["amax_channels"] >= 1, dict(C.LAUNCHES)
+    assert err["h2"] <= max(4 * err["f32"], 1e-6), (side, ratio, err)
