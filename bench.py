@@ -589,7 +589,7 @@ def main():
                                         "weight-side high piece, x 2^-11 in registers): 22-23 significant bits for every ELEMENT within "
                                         "2^29 (5e8 : 1) of its tensor's maximum, absolute 2^-36 of the scaled range below -- regional "
                                         "tests in tests/test_h2_gpu.py (quiet samples / rows / channels at 1e-5 ... 1e-7); the weight "
-                                        "gradient's gy-role operand keeps the plain pair (2^17 : 1).  'conv_math_x3' = the same step on "
+                                        "gradient's gy-role operand keeps the plain pair under one scale per channel (round 6).  'conv_math_x3' = the same step on "
                                         "bf16x3 (range-free, 24 bits); IRR_CONV_MATH=f32: fp32 MFMA",
                                   "x3": "fp32 tensors in HBM; the MFMA convs split every operand into three bf16 pieces and accumulate six "
                                         "piece products in fp32", "f32": "fp32 MFMA everywhere"}.get(C.MATH),

@@ -295,7 +295,8 @@ int irr_conv2d_wgrad_x3_dil(const float* x, const float* gy, float* gw, float* w
  * tensor's maximum, absolute 2^-36 of the scaled range below; the weight side multiplies its high piece by 2^-11 in registers
  * (exact within 2^18 of the matrix maximum).  The weight gradient has two activation operands: the one in the kernel's x role
  * gets the scaled-up low piece (2^28 : 1), the other the plain pair (2^17 : 1 at full precision, absolute 2^-25 of its scale
- * below); irr_conv2d_wgrad_h2_robust_side says which is which for a problem (1: x, 0: gy). */
+ * below -- per CHANNEL with irr_conv2d_wgrad_h2_ch, ABI 11); irr_conv2d_wgrad_h2_robust_side says which is which for a problem
+ * (1: x, 0: gy). */
 int irr_amax_f32(const float* x, int B, long n, long bs, float* slot, void* stream);
 long irr_conv_h2_packed_bytes(int Cin, int Cout);
 int irr_conv_pack_weights_h2(const float* w, void* wq, int Cin, int Cout, int transpose, const float* amax, void* stream);

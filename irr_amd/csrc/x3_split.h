@@ -75,7 +75,9 @@ __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
 // matrix maximum, absolute error 2^-40 of that maximum below) -- still three MFMAs into ONE accumulator:
 //     acc += wh * xh  +  wl * xh  +  (wh * 2^-11) * lo'
 // The weight gradient has no benign operand (both are activations): its x-ROLE operand gets the scaled low piece (2^28 : 1), its
-// gy-role operand keeps the plain pair (2^17 : 1 at full precision, absolute 2^-25 below); DESIGN.md 5.3 has the error budget.
+// gy-role operand keeps the plain pair (2^17 : 1 at full precision, absolute 2^-25 below) -- under one scale per CHANNEL since round 6
+// (conv_wgrad_x3.hip, g_chmax: a channel is an output row of dW, so its scale is undone per row at the flush); profiles/NOTES.md F.2 has
+// the error budget.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
