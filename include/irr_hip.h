@@ -356,8 +356,8 @@ int irr_conv2d_wgrad_h2(const float* x, const float* gy, float* gw, float* ws, f
  * only the one of the operand that irr_conv2d_wgrad_h2_robust_side does NOT name is read (robust side 1 -> gy_chmax, 0 -> x_chmax),
  * the other may be NULL: that operand is scaled channel by channel and the scales are undone per row of dW. */
 int irr_amax_channels_f32(const float* x, int B, int C, long hw, long bs, float* out, int accumulate, void* stream);
-/* one-shot: the NEXT irr_conv2d_fwd_h2 launch of the calling thread (conv_x3_kernel: irr_conv2d_h2_eligible != 9001) folds
- * max |y[:, co]| of what it stores into chmax[co] (Cout zero-initialised floats) -- the same maxima without a pass over y */
+/* one-shot: the NEXT irr_conv2d_fwd_h2 / _h2_bits / _h2_dual launch of the calling thread (either kernel family; a bf16x3 launch answers
+ * IRR_EINVAL) folds max |y[:, co]| of what it stores into chmax[co] (Cout zero-initialised floats) -- the same maxima without a pass over y */
 int irr_conv_x3_next_chmax(float* chmax);
 int irr_conv2d_wgrad_h2_ch(const float* x, const float* gy, float* gw, float* ws, float* gbias, float alpha,
                            int B, int Cin, int H, int W, int Cout, int dil, long x_bs, long gy_bs,
@@ -394,6 +394,11 @@ int irr_conv2d_smallco_dgrad_dual_f32(const float* gy, const float* w, float* gx
                                       int B, int Cin, int H, int W, int Cout,
                                       long gy_bs, long gx_bs, long raw_bs, long mask_bs, float* amax, void* stream);
 /* (ABI 7) amax (nullable): *amax = max(*amax, max |gx|) (the masked form). */
+int irr_conv2d_smallco_dgrad_dual_ch_f32(const float* gy, const float* w, float* gx, float* gx_raw, const float* mask,
+                                         int B, int Cin, int H, int W, int Cout,
+                                         long gy_bs, long gx_bs, long raw_bs, long mask_bs, float* amax, float* chmax, void* stream);
+/* (ABI 12) the same with chmax (nullable, Cin zero-initialised floats): chmax[ci] = max(chmax[ci], max |gx[:, ci]|), the channel maxima of
+ * the masked form -- the scales of the weight gradient that takes gx as its gy (irr_conv2d_wgrad_h2_ch) without a pass over it. */
 
 
 /* gpre = gy * (y>0 ? 1 : 0.1) (if lrelu) ; gbias[co] += sum gpre (gbias nullable, accumulated).

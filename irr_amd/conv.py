@@ -289,7 +289,7 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                 hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
                 int(lrelu), float(alpha), int(accumulate), None, 0, 0, hip.stream())
         variant = None
-    if y_chmax is not None and h2 and code != 9001 and args[0] == "irr_conv2d_fwd_h2":
+    if y_chmax is not None and h2 and args[0] in ("irr_conv2d_fwd_h2", "irr_conv2d_fwd_h2_bits") and not (code == 9001 and _X3S_NO_FUSED_AMAX):
         hip.lib().irr_conv_x3_next_chmax(y_chmax.data_ptr())      # (one-shot: the launch below)
         y_chmax = None
     if TIMER is None:
@@ -309,7 +309,7 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
 
 
 def conv_forward_skip(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], lrelu: bool, skip: torch.Tensor,
-                      x_amax: Optional[Amax] = None, y_amax: Optional[Amax] = None):
+                      x_amax: Optional[Amax] = None, y_amax: Optional[Amax] = None, y_chmax: Optional[torch.Tensor] = None):
     """(e, y) with e = act(conv3x3(x) + bias) and y = skip + e.  On the streaming 32-channel kernel both come out of ONE launch
     (irr_conv2d_fwd_x3_dual / _h2_dual); elsewhere e is computed and the sum is an elementwise pass.  x_amax / y_amax: as in
     conv_forward (y_amax bounds y)."""
@@ -328,6 +328,9 @@ def conv_forward_skip(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
             xa = x_amax if x_amax is not None else amax_measure(x)
             args += (xa.ptr(), xa.n, y_amax.ptr() if y_amax is not None else None)
         args += (hip.stream(),)
+        if y_chmax is not None and h2:
+            hip.lib().irr_conv_x3_next_chmax(y_chmax.data_ptr())      # (one-shot: the launch below; y_chmax bounds y, the sum)
+            y_chmax = None
         if TIMER is None:
             hip.call(*args)
         else:
@@ -335,11 +338,15 @@ def conv_forward_skip(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
                        nbytes=_map_bytes(B, H, W, cin, 3 * cout))
         if y_amax is not None and not h2:
             amax_measure(y, y_amax)
+        if y_chmax is not None:
+            channel_amax(y, y_chmax)
         return e, y
     e = conv_forward(x, weight, bias, 1, 1, lrelu, x_amax=x_amax)
     y = torch.add(skip, e)
     if y_amax is not None:
         amax_measure(y, y_amax)
+    if y_chmax is not None:
+        channel_amax(y, y_chmax)
     return e, y
 
 
@@ -362,7 +369,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
     mask_bits (with mask / nmask): the bits conv_forward(bits_out=...) wrote for `mask`; used instead of the fp32 tensor when this data
     gradient runs on the fp16x2 streaming kernel (both layers passed x3s_bits_ok), ignored otherwise.
     gx_chmax: a ZEROED (Cin,) tensor that holds max |gx[:, c]| per channel of the complete gx after the call: folded by the launch's
-    epilogue on the fp16x2 form of conv_x3_kernel (irr_conv_x3_next_chmax), one pass over gx on every other route -- the scales of
+    epilogue on the fp16x2 kernels (irr_conv_x3_next_chmax), one pass over gx on every other route -- the scales of
     the weight gradient that takes gx as its gy (conv_wgrad(gy_chmax=...))."""
     B, cout, oh, ow = gy.shape
     cout_w, cin, k, _ = weight.shape
@@ -414,7 +421,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                     k, 1, dil, hip.bs(gy), hip.bs(gx), hip.bs(res) if res is not None else 0, 0, float(alpha),
                     int(accumulate), *margs, hip.stream())
             variant = None
-        fold_ch = gx_chmax is not None and h2 and code != 9001
+        fold_ch = gx_chmax is not None and h2 and not (code == 9001 and _X3S_NO_FUSED_AMAX)     # (either kernel family folds them in its epilogue)
         if fold_ch:
             hip.lib().irr_conv_x3_next_chmax(gx_chmax.data_ptr())      # (one-shot: the launch below)
             gx_chmax = None

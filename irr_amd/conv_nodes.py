@@ -701,14 +701,27 @@ class _OccUpsampleFn(hip.Function):
         # applies (one pass less over two 32-channel full-resolution maps); the bias gradient then rides on the wgrad launch.
         B_, _, H_, W_ = x2.shape
         dual = (w_out.shape[0] == 1 and W_ % 4 == 0 and not os.environ.get("IRR_OCCUP_NO_DUAL_DGRAD"))       # (A/B switch)
+        # one scale per channel for the weight gradients' gy-role operand (round 6): the launches that PRODUCE the node's gradient maps fold
+        # their channel maxima (the streaming kernel's epilogue waves keep one running maximum per channel anyway; the dual small-Cout
+        # kernel reduces per wave and channel) -- no pass over the 0.35 / 1.4 GB maps of the 1/2- and full-resolution calls
+        nch_ = w_r0.shape[0]
+        ch_base = _c.WGRAD_CHANNEL_SCALE and G is not None and _c.MATH == "h2"
+
+        def chv(cin_, cout_):
+            """zeroed channel slots for the gy operand of a (cin_ -> cout_) layer's weight gradient at this map size, None when that
+            launch does not scale its gy operand by channel"""
+            if ch_base and bool(hip.lib().irr_conv2d_wgrad_h2_robust_side(B_, cin_, H_, W_, cout_, 1)):
+                return _c.zero_slots(dev, cout_)
+            return None
         if dual:
             g_x2 = torch.empty(B_, w_out.shape[1], H_, W_, device=dev, dtype=torch.float32)
             gpre_e = torch.empty_like(g_x2)
+            ech = chv(w_end.shape[1], w_end.shape[0])
             LAUNCHES["dgrad_smallco"] += 1
-            hip.call("irr_conv2d_smallco_dgrad_dual_f32", hip.ptr(gpre_o), hip.ptr(w_out.detach().contiguous()), hip.ptr(gpre_e),
+            hip.call("irr_conv2d_smallco_dgrad_dual_ch_f32", hip.ptr(gpre_o), hip.ptr(w_out.detach().contiguous()), hip.ptr(gpre_e),
                      hip.ptr(g_x2), hip.ptr(e), B_, w_out.shape[1], H_, W_, 1, hip.bs(gpre_o), hip.bs(gpre_e), hip.bs(g_x2), hip.bs(e),
-                     G.sub(0).ptr() if G is not None else None, hip.stream())      # (max |gpre_e| folded by the same pass)
-            gw_end, gb_end = wgrad_param_(x3, gpre_e, w_end, b_end, 1, 1, want_bias=True, x_amax=sl(4), gy_amax=gl(0))
+                     G.sub(0).ptr() if G is not None else None, hip.ptr(ech), hip.stream())      # (max |gpre_e|, per tensor and per channel, folded by the same pass)
+            gw_end, gb_end = wgrad_param_(x3, gpre_e, w_end, b_end, 1, 1, want_bias=True, x_amax=sl(4), gy_amax=gl(0), gy_chmax=ech)
         else:
             g_x2 = conv_dgrad(gpre_o, w_out, 1, 1, hw_)                      # (B,32,H,W); also the gradient of x_init via the skip
             gpre_e = torch.empty_like(g_x2)
@@ -717,7 +730,8 @@ class _OccUpsampleFn(hip.Function):
             if G is not None:
                 amax_measure(gpre_e, G.sub(0))
             gw_end, _ = wgrad_param_(x3, gpre_e, w_end, None, 1, 1, want_bias=False, x_amax=sl(4), gy_amax=gl(0))
-        g_x = conv_dgrad(gpre_e, w_end, 1, 1, hw_, gy_amax=gl(0), gx_amax=gl(1))     # gradient w.r.t. x3
+        gch = chv(w_r1.shape[1], w_r1.shape[0])                # (g_x is the gy of conv_r1's weight gradient)
+        g_x = conv_dgrad(gpre_e, w_end, 1, 1, hw_, gy_amax=gl(0), gx_amax=gl(1), gx_chmax=gch)     # gradient w.r.t. x3
         if _KEEP_LOG is not None:
             _KEEP_LOG.extend([(f"occ_upsample backward {tuple(g_out.shape)} g_out", g_out), (f"occ_upsample backward gpre_o", gpre_o),
                               (f"occ_upsample backward g_x2 (before the accumulate)", g_x2.clone())])
@@ -737,25 +751,28 @@ class _OccUpsampleFn(hip.Function):
         ts = [t1, t2, t3]
         gxs = 1                                                 # slot of the running g_x
         for i in (2, 1, 0):
-            wgrad_param_(ts[i], g_x, w_r1, b_r1, 1, 1, alpha=mc, acc=acc_r1, x_amax=sl(5 + i), gy_amax=gl(gxs))
+            wgrad_param_(ts[i], g_x, w_r1, b_r1, 1, 1, alpha=mc, acc=acc_r1, x_amax=sl(5 + i), gy_amax=gl(gxs), gy_chmax=gch)
+            tch = chv(w_r0.shape[1], w_r0.shape[0])
             gpre_t = conv_dgrad(g_x, w_r1, 1, 1, hw_, mask=ts[i], nmask=ts[i].shape[1], alpha=mc, gy_amax=gl(gxs), gx_amax=gl(2 + 2 * i),
-                                mask_bits=bits[1 + i])
+                                mask_bits=bits[1 + i], gx_chmax=tch)
             _slog(f"gpre_t{i}", gpre_t, 2 + 2 * i)
-            wgrad_param_(xs[i], gpre_t, w_r0, b_r0, 1, 1, acc=acc_r0, x_amax=sl(1 + i), gy_amax=gl(2 + 2 * i))
+            wgrad_param_(xs[i], gpre_t, w_r0, b_r0, 1, 1, acc=acc_r0, x_amax=sl(1 + i), gy_amax=gl(2 + 2 * i), gy_chmax=tch)
             if i > 0:
-                g_x = conv_dgrad(gpre_t, w_r0, 1, 1, hw_, res=g_x, gy_amax=gl(2 + 2 * i), gx_amax=gl(3 + 2 * i))      # skip + branch in one launch
+                gch = chv(w_r1.shape[1], w_r1.shape[0])
+                g_x = conv_dgrad(gpre_t, w_r0, 1, 1, hw_, res=g_x, gy_amax=gl(2 + 2 * i), gx_amax=gl(3 + 2 * i), gx_chmax=gch)      # skip + branch in one launch
                 gxs = 3 + 2 * i
                 _slog(f"g_x{i}", g_x, gxs)
             else:
                 # x_0 = x_init: add the x2 skip gradient (accumulate into g_x2) and apply init_conv's LeakyReLU'
+                ich = chv(cin, w_init.shape[0])                # (gpre_init is the gy of init_conv's weight gradient)
                 conv_dgrad(gpre_t, w_r0, 1, 1, hw_, gx=g_x2, accumulate=True, res=g_x, mask=x0, nmask=x0.shape[1],
-                           gy_amax=gl(2), gx_amax=gl(8), mask_bits=bits[0])
+                           gy_amax=gl(2), gx_amax=gl(8), mask_bits=bits[0], gx_chmax=ich)
         gw_r0, gb_r0 = acc_r0 if acc_r0 is not None else (None, None)
         gw_r1, gb_r1 = acc_r1 if acc_r1 is not None else (None, None)
         _slog("gpre_init", g_x2, 8)
         gpre_init = g_x2
         x_real = x_in[:, :cin] if x_in.shape[1] > cin else x_in
-        gw_init, gb_init = wgrad_param_(x_real, gpre_init, w_init, b_init, 1, 1, x_amax=sl(0), gy_amax=gl(8))
+        gw_init, gb_init = wgrad_param_(x_real, gpre_init, w_init, b_init, 1, 1, x_amax=sl(0), gy_amax=gl(8), gy_chmax=ich)
         gparts = [None] * nparts
         if any(ctx.needs_input_grad[2:2 + nparts]):
             w_first = _padded_cin(w_init, x_in.shape[1]) if x_in.shape[1] > cin else w_init

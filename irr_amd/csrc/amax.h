@@ -29,6 +29,23 @@ __device__ __forceinline__ float x3_amax_wave(float m) {
   }
   return __builtin_bit_cast(float, b);
 }
+// max over the 32 lanes of each HALF-wave of a bit pattern, valid in lanes 16..31 and 48..63 afterwards: five DPP steps (lane swaps
+// inside quads, the two mirrors of a 16-lane row, then lane 15 of rows 0 / 2 broadcast into rows 1 / 3) -- VALU only, no LDS crossbar
+// round trips (sixteen of these per wave end the epilogue of a launch that folds channel maxima; as __shfl_xor ladders they were 80
+// ds_bpermute with their waits)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t x3_dpp_max(uint32_t v) {
+  const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWS, 0xF, false);
+  return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t x3_amax_half_upper(uint32_t v) {
+  v = x3_dpp_max<0xB1, 0xF>(v);                             // quad_perm [1, 0, 3, 2]
+  v = x3_dpp_max<0x4E, 0xF>(v);                             // quad_perm [2, 3, 0, 1]
+  v = x3_dpp_max<0x141, 0xF>(v);                            // row_half_mirror
+  v = x3_dpp_max<0x140, 0xF>(v);                            // row_mirror
+  v = x3_dpp_max<0x142, 0xA>(v);                            // row_bcast:15 into rows 1 and 3
+  return v;
+}
 #ifndef X3_AMAX_PRECHECK
 #define X3_AMAX_PRECHECK 1     // 0 (A/B): every wave / block issues its atomic
 #endif

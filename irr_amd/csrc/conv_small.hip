@@ -542,8 +542,15 @@ __global__ __launch_bounds__(256) void conv_smallco_dgrad4_kernel(const float* _
                                                                  int H, int W, long gy_bs, long gx_bs, long mask_bs, int nmask,
                                                                  int accumulate, int ci_per_block, float* __restrict__ amax,
                                                                  int amax_channels, float* __restrict__ gx_raw = nullptr,
-                                                                 long raw_bs = 0) {
+                                                                 long raw_bs = 0, float* __restrict__ chmax = nullptr) {
   constexpr int U = 4;
+  // chmax (nullable, DUAL only; end of round 6): chmax[ci] = max(chmax[ci], max |stored gx[:, ci]|) -- per wave and channel one shuffle
+  // reduction and one LDS maximum, per block and channel one look-then-atomic (the kernel is bound by its 12 bytes per element)
+  __shared__ uint32_t chl[DUAL ? 64 : 1];
+  if (DUAL && chmax) {
+    if (threadIdx.x < 64) chl[threadIdx.x] = 0u;
+    __syncthreads();
+  }
   float vmax = 0.f;                                          // max |stored gx| over channels < amax_channels
   const long hw = (long)H * W;
   const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -602,9 +609,18 @@ __global__ __launch_bounds__(256) void conv_smallco_dgrad4_kernel(const float* _
       }
       if (qok && ci + u < c1 && ci + u < amax_channels)
         vmax = x3_amax_fold(x3_amax_fold(x3_amax_fold(x3_amax_fold(vmax, v[0]), v[1]), v[2]), v[3]);
+      if (DUAL && chmax) {                                       // (uniform branch)
+        float m = (qok && ci + u < c1) ? x3_amax_fold(x3_amax_fold(x3_amax_fold(x3_amax_fold(0.f, v[0]), v[1]), v[2]), v[3]) : 0.f;
+        m = x3_amax_wave(m);
+        if ((threadIdx.x & 63) == 0 && ci + u < c1) atomicMax(&chl[(ci + u - c0) & 63], __builtin_bit_cast(uint32_t, m));
+      }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), xr,
                                              (int)(ci + u < c1 ? vp : SOOB), (int)((uint32_t)(ci + u) * hw4), 0);
     }
+  }
+  if (DUAL && chmax) {
+    __syncthreads();
+    if ((int)threadIdx.x < c1 - c0 && threadIdx.x < 64) x3_amax_commit(__builtin_bit_cast(float, chl[threadIdx.x]), chmax + c0 + threadIdx.x);
   }
   if (amax && c0 < amax_channels) x3_amax_publish_block256(vmax, amax);      // (block-uniform condition; every thread arrives)
 }
@@ -724,9 +740,9 @@ extern "C" int irr_conv2d_smallco_dgrad_f32(const float* gy, const float* w, flo
 // gx = LeakyReLU'(mask) * conv_transpose(gy, w) and gx_raw = conv_transpose(gy, w) from ONE pass (Cout = 1, dilation 1, W % 4 == 0,
 // batch strides multiples of 4: the quad kernel); IRR_EINVAL otherwise -- the caller then runs irr_conv2d_smallco_dgrad_f32 +
 // irr_lrelu_bwd_bias_f32.
-extern "C" int irr_conv2d_smallco_dgrad_dual_f32(const float* gy, const float* w, float* gx, float* gx_raw, const float* mask, int B,
-                                                 int Cin, int H, int W, int Cout, long gy_bs, long gx_bs, long raw_bs, long mask_bs,
-                                                 float* amax, void* stream) {
+static int smallco_dgrad_dual_impl(const float* gy, const float* w, float* gx, float* gx_raw, const float* mask, int B,
+                                   int Cin, int H, int W, int Cout, long gy_bs, long gx_bs, long raw_bs, long mask_bs,
+                                   float* amax, float* chmax, void* stream) {
   if (!gy || !w || !gx || !gx_raw || !mask || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout != 1 || B > 65535) return IRR_EINVAL;
   if ((W & 3) || ((gy_bs | gx_bs | raw_bs | mask_bs) & 3)) return IRR_EINVAL;
   const long hw = (long)H * W;
@@ -734,12 +750,28 @@ extern "C" int irr_conv2d_smallco_dgrad_dual_f32(const float* gy, const float* w
   int split4 = (int)((2048 + (long)qblocks * B - 1) / ((long)qblocks * B));
   if (split4 < 1) split4 = 1;
   if (split4 > Cin) split4 = Cin;
-  const int cpb4 = ((Cin + split4 - 1) / split4 + 3) / 4 * 4;
+  int cpb4 = ((Cin + split4 - 1) / split4 + 3) / 4 * 4;
+  if (chmax && cpb4 > 64) {                                  // (the block's LDS maxima hold 64 channels)
+    cpb4 = 64;
+  }
   dim3 grid4(qblocks, irr_cdiv(Cin, cpb4), B);
   hipLaunchKernelGGL((conv_smallco_dgrad4_kernel<1, true>), grid4, dim3(256), 0, (hipStream_t)stream, gy, w, gx, mask, Cin, H, W, gy_bs,
-                     gx_bs, mask_bs, Cin, 0, cpb4, amax, amax ? Cin : 0, gx_raw, raw_bs);
+                     gx_bs, mask_bs, Cin, 0, cpb4, amax, amax ? Cin : 0, gx_raw, raw_bs, chmax);
   IRR_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int irr_conv2d_smallco_dgrad_dual_f32(const float* gy, const float* w, float* gx, float* gx_raw, const float* mask, int B,
+                                                 int Cin, int H, int W, int Cout, long gy_bs, long gx_bs, long raw_bs, long mask_bs,
+                                                 float* amax, void* stream) {
+  return smallco_dgrad_dual_impl(gy, w, gx, gx_raw, mask, B, Cin, H, W, Cout, gy_bs, gx_bs, raw_bs, mask_bs, amax, nullptr, stream);
+}
+
+// (ABI 12) the same with chmax (nullable): chmax[ci] = max(chmax[ci], max |gx[:, ci]|) per channel of the masked form, Cin floats
+extern "C" int irr_conv2d_smallco_dgrad_dual_ch_f32(const float* gy, const float* w, float* gx, float* gx_raw, const float* mask, int B,
+                                                    int Cin, int H, int W, int Cout, long gy_bs, long gx_bs, long raw_bs, long mask_bs,
+                                                    float* amax, float* chmax, void* stream) {
+  return smallco_dgrad_dual_impl(gy, w, gx, gx_raw, mask, B, Cin, H, W, Cout, gy_bs, gx_bs, raw_bs, mask_bs, amax, chmax, stream);
 }
 
 extern "C" int irr_conv2d_smallco_fwd_f32(const float* x, const float* w, const float* bias, const float* res, float* y,

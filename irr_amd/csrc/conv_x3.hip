@@ -343,22 +343,18 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
   }
   if (want_amax) x3_amax_publish(ymax, a.y_amax);
   if (want_ch) {
-    // the 32 lanes of a half-wave hold the 32 pixels of one accumulator row each: fold them; then lane j = r of each half looks at the
-    // slot of row r and raises it when it has to -- sixteen lanes, one round trip (sixteen dependent look-then-atomic sequences at the
+    // the 32 lanes of a half-wave hold the 32 pixels of one accumulator row each: fold them (DPP, amax.h); then lane j = 16 + r of each half
+    // looks at the slot of row r and raises it when it has to -- sixteen lanes, one round trip (sixteen dependent look-then-atomic sequences at the
     // end of every wave cost these launches 8 %)
     uint32_t mine = 0u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      uint32_t mb = __builtin_bit_cast(uint32_t, chm[r]);
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)mb, off, 64);
-        mb = o > mb ? o : mb;
-      }
-      mine = j == r ? mb : mine;
+      const uint32_t mb = x3_amax_half_upper(__builtin_bit_cast(uint32_t, chm[r]));      // (valid in lanes j >= 16 of each half)
+      mine = j == 16 + r ? mb : mine;
     }
-    if (j < 16) {
-      const int co = cot * 32 + (j & 3) + 8 * (j >> 2) + 4 * g;
+    if (j >= 16) {
+      const int r = j - 16;
+      const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
       if (co < a.Cout) x3_amax_commit(__builtin_bit_cast(float, mine), a.y_chmax + co);
     }
   }
@@ -398,6 +394,7 @@ struct X3SArgs {
   const float* x_amax;          // NP == 2: as in X3Args
   int n_amax;
   float* y_amax;
+  float* y_chmax;               // nullable (round 6, NP == 2): this launch's Cout slots for max |y[:, co]| PER OUTPUT CHANNEL (irr_conv_x3_next_chmax)
   // LeakyReLU' masks as BITS (round 5): one 32-bit word per epilogue thread and tile -- bit e * 4 + px = (stored value > 0) of channel
   // eq_c8 * 8 + e, pixel px of the thread's quad -- at word (bits_tile0 + tile) * 256 + ptid.  A forward launch (EPI 0) writes them
   // next to its output; the masked data gradient of the SAME map shape (EPI 4) reads one dword instead of eight 16-B loads of the
@@ -565,8 +562,13 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
         }
       }
     };
-    float ymax = 0.f;                                        // NP == 2 with a.y_amax: max |stored value| of this thread
-    const bool want_amax = NP == 2 && a.y_amax != nullptr;
+    // NP == 2 with a.y_amax / a.y_chmax: max |stored value| of this thread PER CHANNEL (its eight channels are the same for all 64 threads
+    // of the wave: eq_c8 = ptid >> 6).  The tensor's maximum is the maximum of these -- the per-channel fold costs the same four VALU
+    // instructions per stored 16-B unit the per-tensor fold did, and the cross-lane part runs once per wave and LAUNCH (persistent blocks).
+    float chm[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) chm[e] = 0.f;
+    const bool want_amax = NP == 2 && (a.y_amax != nullptr || a.y_chmax != nullptr);
     f32x4 eacc[8];                                           // the finished tile's accumulators, copied out of the LDS stage
     auto epilogue_grab = [&]() {
 #pragma unroll
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
           o[px] = v;
           if (EPI == 0) obits |= (v > 0.f ? 1u : 0u) << (e * 4 + px);     // (the same predicate irr_lrelu_grad applies to the stored value)
         }
-        if (want_amax && co < a.Cout && evd != OOB) ymax = x3_amax_fold(x3_amax_fold(x3_amax_fold(x3_amax_fold(ymax, o[0]), o[1]), o[2]), o[3]);
+        if (want_amax && co < a.Cout && evd != OOB) chm[e] = x3_amax_fold(x3_amax_fold(x3_amax_fold(x3_amax_fold(chm[e], o[0]), o[1]), o[2]), o[3]);
         // (irr_buffer_store_b128_guarded, common.h: these stores carry an SGPR soffset, the form behind which hipcc inserts NO wait states
         // -- and the next channel's arithmetic reuses the data registers at once: the fault of NOTES D.4 / D.5)
         irr_buffer_store_b128_guarded(__builtin_bit_cast(u32x4, o), ry, (int)((co < a.Cout && X3_ABL != 7 && X3_ABL != 10 && X3_ABL != 11) ? evd : OOB),
@@ -655,7 +657,18 @@ __global__ __launch_bounds__(512) void conv_x3s_kernel(const X3SArgs a) {
     epilogue_loads(at_prev, tprev >= 0, tprev);
     epilogue_grab();
     epilogue_finish();
-    if (want_amax) x3_amax_publish(ymax, a.y_amax);
+    if (want_amax) {
+      float ymax = 0.f;
+      uint32_t mine = 0u;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float m = x3_amax_wave(chm[e]);                // (uniform after the fold)
+        ymax = x3_amax_fold(ymax, m);
+        mine = lane == e ? __builtin_bit_cast(uint32_t, m) : mine;
+      }
+      if (a.y_amax && lane == 0) x3_amax_commit(ymax, a.y_amax);
+      if (a.y_chmax && lane < 8 && eq_c8 * 8 + lane < a.Cout) x3_amax_commit(__builtin_bit_cast(float, mine), a.y_chmax + eq_c8 * 8 + lane);   // eight lanes, one round trip
+    }
     return;
   }
 
@@ -1058,6 +1071,52 @@ __global__ __launch_bounds__(256) void x3_splitk_epilogue_kernel(const float* __
   if (y_amax) x3_amax_publish_block256(__builtin_fabsf(v), y_amax);      // (uniform: every thread of the block arrives)
 }
 
+// The same with BLOCKS THAT STAY INSIDE ONE CHANNEL: used when the launch also owes the channel maxima of what it stores
+// (irr_conv_x3_next_chmax) -- a block = the planes of channel co for spb consecutive samples (256 / hw of them at the 6x7 and 12x14
+// levels), so its maximum is one channel's: one look-then-atomic per block instead of a second launch that reads the finished slice
+// again (26 such passes per train step on the main stream).  (One WAVE per plane, or several, was slower than the flat kernel plus
+// the pass: tens of thousands of waves each looking at the same slots.)
+__global__ __launch_bounds__(256) void x3_splitk_epilogue_planes_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                                       const float* __restrict__ res, float* __restrict__ y,
+                                                                       const float* __restrict__ mask, int B, int Cout, long hw, int ksplit,
+                                                                       long y_bs, long res_bs, long mask_bs, int nmask, int lrelu,
+                                                                       float alpha, int accumulate, float* __restrict__ y_amax,
+                                                                       float* __restrict__ y_chmax, int spb) {
+  const int co = (int)(blockIdx.x % (unsigned)Cout);
+  const long b0 = (long)(blockIdx.x / (unsigned)Cout) * spb;
+  const long n = (long)B * Cout * hw;
+  const float bv = bias ? bias[co] : 0.f;
+  const bool masked = mask && co < nmask;
+  float m = 0.f;
+  for (long e = threadIdx.x; e < (long)spb * hw; e += 256) {
+    const long b = b0 + e / hw;
+    const long pix = e % hw;
+    if (b >= B) break;
+    const long i = (b * Cout + co) * hw + pix;
+    float v = 0.f;
+    for (int k = 0; k < ksplit; ++k) v += part[(long)k * n + i];
+    v += bv;
+    if (lrelu) v = irr_lrelu(v);
+    const long o = (long)co * hw + pix;
+    if (res) v = res[b * res_bs + o] + alpha * v;
+    else v *= alpha;
+    float* dst = y + b * y_bs + o;
+    if (accumulate) v += *dst;
+    if (masked) v *= irr_lrelu_grad(mask[b * mask_bs + o]);
+    *dst = v;
+    m = x3_amax_fold(m, v);
+  }
+  __shared__ float wm[4];
+  m = x3_amax_wave(m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float r = x3_amax_fold(x3_amax_fold(wm[0], wm[1]), x3_amax_fold(wm[2], wm[3]));
+    x3_amax_commit(r, y_chmax + co);
+    if (y_amax) x3_amax_commit(r, y_amax);
+  }
+}
+
 // floats of scratch a K-split launch needs (0: the problem runs unsplit)
 extern "C" long irr_conv2d_fwd_x3_ws_elems(int B, int Cin, int H, int W, int Cout, int dil) {
   if (B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1 || x3s_ok(B, Cin, H, W, Cout, dil)) return 0;
@@ -1074,7 +1133,7 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
   float* const next_chmax = g_next_chmax;                   // (irr_conv_x3_next_chmax: consumed by this launch, whatever happens to it)
   g_next_chmax = nullptr;
   if (!x || !wq || !y || B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1) return IRR_EINVAL;
-  if (next_chmax && (np != 2 || x3s_ok(B, Cin, H, W, Cout, dil))) return IRR_EINVAL;      // only the fp16x2 form of conv_x3_kernel folds channel maxima
+  if (next_chmax && np != 2) return IRR_EINVAL;             // only the fp16x2 forms fold channel maxima
   if (y2 && (!res || accumulate || mask || !x3s_ok(B, Cin, H, W, Cout, dil))) return IRR_EINVAL;      // second output: streaming kernel only
   if (np == 2 && (!x_amax || n_amax <= 0)) return IRR_EINVAL;
   // bit masks: the fp16x2 streaming kernel with one co-tile only; a launch either writes them (plain forward) or reads them
@@ -1148,6 +1207,7 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
         s.mask = (mask && nmask > co0) ? mask + (long)b0 * mask_bs + co0 * hw_ : nullptr;
         s.nmask = nmask - (int)co0 < 0 ? 0 : (nmask - (int)co0 > 32 ? 32 : nmask - (int)co0);
         s.y2 = y2 ? y2 + (long)b0 * y2_bs + co0 * hw_ : nullptr;
+        s.y_chmax = (np == 2 && next_chmax) ? next_chmax + co0 : nullptr;
         const int epi = s.mask_bits ? 4 : (s.accumulate || s.mask) ? 2 : s.res ? (s.y2 ? 3 : 1) : 0;
 #define X3S_GO(E) do { if (np == 2) hipLaunchKernelGGL((conv_x3s_kernel<E, 2>), dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s); \
                       else hipLaunchKernelGGL((conv_x3s_kernel<E, 3>), dim3((unsigned)nblk), dim3(512), lds_bytes, (hipStream_t)stream, s); } while (0)
@@ -1212,12 +1272,18 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
     if (rc) return rc;
     if (a.ksplit > 1) {
       const long n = (long)a.B * Cout * H * W;
-      hipLaunchKernelGGL(x3_splitk_epilogue_kernel, dim3((unsigned)irr_cdiv(n, 256)), dim3(256), 0, st, ws, bias, a.res, a.y, a.mask, a.B,
-                         Cout, (long)H * W, a.ksplit, y_bs, res_bs, mask_bs, nmask, lrelu, alpha, accumulate, np == 2 ? y_amax : nullptr);
+      if (a.y_chmax && (long)H * W <= 4096) {               // (the small pyramid levels: waves that stay inside a plane fold the channel's maximum)
+        const int spb = (long)H * W >= 256 ? 1 : (int)(256 / ((long)H * W));
+        const long blocks = (long)Cout * irr_cdiv(a.B, spb);
+        hipLaunchKernelGGL(x3_splitk_epilogue_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ws, bias, a.res, a.y, a.mask,
+                           a.B, Cout, (long)H * W, a.ksplit, y_bs, res_bs, mask_bs, nmask, lrelu, alpha, accumulate,
+                           np == 2 ? y_amax : nullptr, a.y_chmax, spb);
+      } else
+        hipLaunchKernelGGL(x3_splitk_epilogue_kernel, dim3((unsigned)irr_cdiv(n, 256)), dim3(256), 0, st, ws, bias, a.res, a.y, a.mask, a.B,
+                           Cout, (long)H * W, a.ksplit, y_bs, res_bs, mask_bs, nmask, lrelu, alpha, accumulate, np == 2 ? y_amax : nullptr);
       IRR_LAUNCH_CHECK();
-      // (channel maxima of a K-split launch: the small pyramid levels -- one pass over the finished slice of y instead of a fold in
-      // an element-wise kernel whose blocks straddle the 42 ... 672-pixel planes)
-      if (a.y_chmax) { const int rc2 = irr_amax_channels_launch(a.y, a.B, Cout, (long)H * W, y_bs, a.y_chmax, st, false); if (rc2) return rc2; }
+      // (larger planes with a K split: one pass over the finished slice of y)
+      if (a.y_chmax && (long)H * W > 4096) { const int rc2 = irr_amax_channels_launch(a.y, a.B, Cout, (long)H * W, y_bs, a.y_chmax, st, false); if (rc2) return rc2; }
     }
   }
   return 0;
@@ -1281,8 +1347,8 @@ extern "C" int irr_conv2d_fwd_h2_dual(const float* x, const void* wq, const floa
                      y2, y2_bs, 2, x_amax, n_amax, y_amax);
 }
 
-// The NEXT irr_conv2d_fwd_h2 launch of the calling thread (forward or data gradient on conv_x3_kernel, not the streaming 32-channel
-// kernel: irr_conv2d_h2_eligible != 9001) additionally folds max |y[:, co]| of what it stores into chmax[co], co < Cout (atomic max on
+// The NEXT irr_conv2d_fwd_h2 / _h2_bits / _h2_dual launch of the calling thread (forward or data gradient; since the end of round 6 the
+// streaming 32-channel kernel too) additionally folds max |y[:, co]| of what it stores into chmax[co], co < Cout (atomic max on
 // non-negative bit patterns: pre-set the slots to 0; a launch that accumulates into y folds the accumulated values).  One-shot:
 // consumed by that launch.  The scales of the weight gradient's gy-role operand (irr_conv2d_wgrad_h2_ch) without a pass over it.
 extern "C" int irr_conv_x3_next_chmax(float* chmax) {

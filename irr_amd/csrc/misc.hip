@@ -1,6 +1,6 @@
 #include "common.h"
 #include "amax.h"
-extern "C" int irr_abi_version(void) { return 11; }   // 11: one operand scale per channel for the weight gradient's gy-role operand (irr_conv2d_wgrad_h2_ch, irr_amax_channels_f32); 10: Winograd F(2x2,3x3) forward on the fp16x2 arithmetic (irr_conv2d_wino_fwd_h2, experimental); 9: bit masks for the streaming kernel (irr_conv2d_fwd_h2_bits); 8: the legacy Correlation operator at any parameter point (irr_corr_general_*); 7: the fp16x2 pairs of activation-side operands carry a scaled-up low piece (range 2^17 -> 2^29 per element; irr_conv2d_wgrad_h2_robust_side); 6: the streaming 32-channel kernel takes the fp16x2 form too (irr_conv2d_fwd_h2_dual); 5: fp16x2 ("h2") conv entry points + amax slots; 4: loss reductions take a partial-sum scratch (fixed summation order); 3: Adam scalars are doubles
+extern "C" int irr_abi_version(void) { return 12; }   // 12: channel maxima out of the dual small-Cout data gradient (irr_conv2d_smallco_dgrad_dual_ch_f32) and the streaming kernel (irr_conv_x3_next_chmax on every fp16x2 launch); 11: one operand scale per channel for the weight gradient's gy-role operand (irr_conv2d_wgrad_h2_ch, irr_amax_channels_f32); 10: Winograd F(2x2,3x3) forward on the fp16x2 arithmetic (irr_conv2d_wino_fwd_h2, experimental); 9: bit masks for the streaming kernel (irr_conv2d_fwd_h2_bits); 8: the legacy Correlation operator at any parameter point (irr_corr_general_*); 7: the fp16x2 pairs of activation-side operands carry a scaled-up low piece (range 2^17 -> 2^29 per element; irr_conv2d_wgrad_h2_robust_side); 6: the streaming 32-channel kernel takes the fp16x2 form too (irr_conv2d_fwd_h2_dual); 5: fp16x2 ("h2") conv entry points + amax slots; 4: loss reductions take a partial-sum scratch (fixed summation order); 3: Adam scalars are doubles
 
 // ---- channel concatenation of up to IRR_CAT_MAX_PARTS tensors in ONE launch (include/irr_hip.h) ----------------------------
 // The decoder input of a level is cat([cost volume, projected features, flow, occlusion]) (models/IRR_PWC.py:104-107) and the

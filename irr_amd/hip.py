@@ -19,7 +19,7 @@ HEADER = os.path.join(os.path.dirname(_PKG), "include", "irr_hip.h")
 # IRR_HIP_LIB: load another build of the SAME ABI (ablation / trace builds of irr_amd.build with IRR_BUILD_TAG)
 LIB_PATH = os.environ.get("IRR_HIP_LIB") or os.path.join(_PKG, "lib", "libirr_hip.so")
 
-ABI_VERSION = 11         # irr_abi_version() of the library this binding was written against (csrc/misc.hip)
+ABI_VERSION = 12         # irr_abi_version() of the library this binding was written against (csrc/misc.hip)
 
 _CTYPES = {
     "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,

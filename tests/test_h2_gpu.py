@@ -191,6 +191,47 @@ def test_dense_estimator_and_chain_nodes_on_h2(h2_everywhere):
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-30, i
 
 
+def test_occlusion_upsampler_node_scales_every_gradient_map_by_channel(h2_everywhere):
+    """End of round 6: every gradient map of the upsampler node (gpre_e out of the dual small-Cout data gradient, g_x / gpre_t / gpre_init
+    out of the streaming kernel) arrives at its weight gradient with channel maxima folded by the launch that produced it -- no
+    irr_amax_channels_f32 pass in the backward, whatever the map size -- and a QUIET half of the feature channels (conv_r1 / conv_end rows
+    scaled by 1e-6: quiet rows of dW) keeps the fp32-MFMA route's accuracy."""
+    from irr_amd import conv as C, modules as M
+    torch.manual_seed(3)
+    B, H, W = 2, 40, 64
+    mod = M.OccUpsampleNetwork(11, 1).cuda()
+    with torch.no_grad():                                      # quiet output channels: their gradient maps are 1e-6 of the loud ones'
+        for layer in (mod.res_convs[1], mod.res_end_conv):
+            layer.weight[16:] *= 1e-6
+            layer.bias[16:] *= 1e-6
+        mod.out_convs.weight[:, 16:] *= 1e-6
+    occ = torch.randn(B, 1, H // 2, W // 2, device="cuda", requires_grad=True)
+    guide = torch.randn(B, 10, H, W, device="cuda", requires_grad=True)
+    params = list(mod.parameters())
+
+    def run(math):
+        C.set_math(math)
+        for t in [occ, guide] + params:
+            t.grad = None
+        out = mod(occ, guide)
+        n0 = C.LAUNCHES["amax_channels"]
+        (out ** 2).sum().backward()
+        torch.cuda.synchronize()
+        return [out.detach().clone()] + [t.grad.detach().clone() for t in [occ, guide] + params], C.LAUNCHES["amax_channels"] - n0
+
+    ref, _ = run("f32")
+    got, passes = run("h2")
+    assert C.LAUNCHES["dgrad_x3s"] >= 7 and C.LAUNCHES["wgrad_h2"] >= 7, dict(C.LAUNCHES)
+    assert passes == 0, (passes, dict(C.LAUNCHES))
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-30, i
+    # the quiet rows of the shared residual weights and of res_end_conv, relative to THEIR OWN range
+    for n, layer in (("res_convs[1]", mod.res_convs[1]), ("res_end_conv", mod.res_end_conv)):
+        i = 3 + [id(p_) for p_ in params].index(id(layer.weight))
+        a, b = got[i][16:], ref[i][16:]
+        assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-30, (n, (a - b).abs().max().item(), b.abs().max().item())
+
+
 S_CASES = [(32, 32, 2, 40, 64), (16, 32, 1, 24, 96), (27, 32, 1, 32, 60), (32, 64, 1, 16, 96), (32, 24, 1, 23, 64)]   # (Cin, Cout, B, H, W)
 
 
@@ -232,6 +273,85 @@ def test_streaming_kernel_on_h2_is_fp32_faithful(case, rng, h2_everywhere):
         if i == 4 and not C.LAUNCHES["dgrad_x3s"]:
             continue
         assert err["h2"][i] <= max(4 * err["f32"][i], 2e-6) and err["h2"][i] <= 5e-6, (what, err)
+
+
+@pytest.mark.parametrize("case", S_CASES, ids=[f"{c[0]}to{c[1]}_{c[3]}x{c[4]}" for c in S_CASES])
+def test_streaming_kernel_folds_channel_maxima(case, h2_everywhere):
+    """End of round 6: the epilogue waves of conv_x3s_kernel<EPI, 2> keep one running maximum per output channel (the tensor's maximum
+    is their maximum): y_chmax / gx_chmax of every epilogue form -- plain, residual, second output, accumulate + mask, bit masks, two
+    co-tiles, ragged tiles, Cout < 32 -- equal a pass over the stored tensor, without an irr_amax_channels_f32 launch."""
+    from irr_amd import conv as C
+    cin, cout, B, H, W = case
+    x, w, gy = _operands((cin, cout, 1, B, H, W), "per_channel")
+    assert C.h2_code(B, cin, H, W, cout, 3, 1, 1) == 9001
+    g = torch.Generator().manual_seed(9)
+    xc, wc, gc = x.cuda(), w.cuda(), gy.cuda()
+    b = (torch.linspace(-1, 1, cout) * 0.1).cuda()
+    res = torch.randn(B, cout, H, W, generator=g).cuda()
+    xa = C.amax_measure(xc)
+    per_ch = lambda t: t.abs().amax(dim=(0, 2, 3))
+    n0 = C.LAUNCHES["amax_channels"]
+    for kw in ({}, {"res": res, "alpha": 0.1}):
+        ch = C.zero_slots(xc.device, cout)
+        ya = C.Amax.zeros(xc.device, 1)
+        y = C.conv_forward(xc, wc, b, 1, 1, True, x_amax=xa, y_amax=ya, y_chmax=ch, **kw)
+        assert torch.equal(ch, per_ch(y)), kw
+        assert ya.slots[ya.first].item() == y.abs().max().item()
+    ch = C.zero_slots(xc.device, cout)
+    e, y2 = C.conv_forward_skip(xc, wc, b, True, res, x_amax=xa, y_chmax=ch)
+    assert torch.equal(ch, per_ch(y2))
+    if C.x3s_bits_ok(B, cin, H, W, cout):
+        bits = torch.empty(C.x3s_mask_words(B, H, W), dtype=torch.int32, device="cuda")
+        ch = C.zero_slots(xc.device, cout)
+        y = C.conv_forward(xc, wc, b, 1, 1, True, x_amax=xa, y_chmax=ch, bits_out=bits)
+        assert torch.equal(ch, per_ch(y))
+    # data gradient (Cout -> Cin channels): accumulate + mask, fp32 mask and (where both layers qualify) bits
+    ga = C.amax_measure(gc)
+    mask = torch.randn(B, cin, H, W, generator=g).cuda()
+    for kw in ({}, {"accumulate": True}):
+        gx0 = torch.randn(B, cin, H, W, generator=g).cuda()
+        ch = C.zero_slots(xc.device, cin)
+        a = dict(gx=gx0, accumulate=True) if kw else {}
+        gx = C.conv_dgrad(gc, wc, 1, 1, (H, W), mask=mask, nmask=cin, gy_amax=ga, gx_chmax=ch, **a)
+        if C.LAUNCHES["dgrad_x3s"]:
+            assert torch.equal(ch, per_ch(gx)), kw
+    if C.LAUNCHES["dgrad_x3s"]:
+        assert C.LAUNCHES["amax_channels"] == n0, dict(C.LAUNCHES)
+
+
+@pytest.mark.parametrize("min_blocks", [0, 384])
+@pytest.mark.parametrize("case", [(565, 128, 1, 8, 24, 28), (128, 128, 2, 8, 12, 14), (243, 128, 1, 4, 48, 56), (128, 96, 1, 2, 40, 24), (64, 64, 1, 8, 24, 28)],
+                         ids=lambda c: f"{c[0]}to{c[1]}d{c[2]}_{c[3]}x{c[4]}x{c[5]}")
+def test_conv_x3_kernel_folds_channel_maxima(case, min_blocks, h2_everywhere):
+    """irr_conv_x3_next_chmax on conv_x3_kernel's fp16x2 form: unsplit launches fold in the kernel's epilogue, K-split launches (the
+    routing of the small pyramid levels, min_blocks = 384) in the plane-wise finishing kernel -- forward and masked / accumulating data
+    gradient, equal to a pass over the stored tensor, no irr_amax_channels_f32 launch."""
+    from irr_amd import conv as C, hip
+    cin, cout, dil, B, H, W = case
+    hip.lib().irr_conv_x3_set_min_blocks(min_blocks)
+    code = C.h2_code(B, cin, H, W, cout, 3, 1, dil)
+    if not code or code == 9001:
+        pytest.skip("not a conv_x3_kernel problem under this routing")
+    split = hip.lib().irr_conv2d_fwd_x3_ws_elems(B, cin, H, W, cout, dil) > 0
+    assert split == (min_blocks > 0), (case, min_blocks)
+    x, w, gy = _operands(case, "per_channel")
+    xc, wc = x.cuda(), w.cuda()
+    per_ch = lambda t: t.abs().amax(dim=(0, 2, 3))
+    n0 = C.LAUNCHES["amax_channels"]
+    ch = C.zero_slots(xc.device, cout)
+    ya = C.Amax.zeros(xc.device, 1)
+    y = C.conv_forward(xc, wc, None, 1, dil, True, y_amax=ya, y_chmax=ch)
+    assert torch.equal(ch, per_ch(y)) and ya.slots[ya.first].item() == y.abs().max().item()
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), None, padding=dil, dilation=dil), 0.1)
+    assert _rel(y, ref) <= 5e-6
+    if C.h2_code(B, cout, H, W, cin, 3, 1, dil) not in (0, 9001):
+        g = torch.Generator().manual_seed(3)
+        gx0 = torch.randn(B, cin, H, W, generator=g).cuda()
+        mask = torch.randn(B, cin, H, W, generator=g).cuda()
+        ch = C.zero_slots(xc.device, cin)
+        gx = C.conv_dgrad(gy.cuda(), wc, 1, dil, (H, W), gx=gx0, accumulate=True, mask=mask, nmask=cin // 2, gx_chmax=ch)
+        assert torch.equal(ch, per_ch(gx))
+    assert C.LAUNCHES["amax_channels"] == n0, dict(C.LAUNCHES)
 
 
 B_CASES = [(32, 32, 2, 40, 64), (16, 32, 1, 24, 96), (32, 32, 3, 23, 92), (32, 24, 1, 31, 60)]   # (Cin, Cout, B, H, W)
