@@ -507,6 +507,9 @@ int irr_cat_channels_f32(float* dst, long dst_bs, const void* parts, int nparts,
  * models/pwc_modules.py:169-170 head) as one coalesced pass instead of ATen's strided-iterator kernel (ABI 7). */
 int irr_add_planes_f32(float* out, const float* x, const float* y, int B, long n, long out_bs, long x_bs, long y_bs, void* stream);
 int irr_cat_channels_amax_f32(float* dst, long dst_bs, const void* parts, int nparts, int B, long hw, float* amax, void* stream);
+/* (ABI 12) ... and chmax[c] = max(chmax[c], max |dst[:, c]| as written) per destination channel (zero-initialised floats, one per channel
+ * written by this call; amax nullable): the channel maxima of an assembled decoder input without a pass (irr_conv2d_wgrad_h2_ch). */
+int irr_cat_channels_amax_ch_f32(float* dst, long dst_bs, const void* parts, int nparts, int B, long hw, float* amax, float* chmax, void* stream);
 
 /* ---- fused Adam over one flat arena ------------------------------------------------------------------
  * torch.optim.Adam semantics (runtime.py:189; lr 1e-4, weight_decay 4e-4 as L2-in-gradient,

@@ -390,6 +390,8 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
         hip.call("irr_conv2d_smallco_dgrad_f32", hip.ptr(gy), hip.ptr(wc), hip.ptr(gx), margs[0], B, cin, H, W, cout, dil,
                  hip.bs(gy), hip.bs(gx), margs[1], margs[2], int(accumulate),
                  gx_amax.ptr() if gx_amax is not None else None, nam if gx_amax is not None else 0, hip.stream())
+        if gx_chmax is not None:                            # (this kernel folds no channel maxima)
+            channel_amax(gx, gx_chmax)
         return gx
     if stride == 1 and cout == 1:
         # the MFMA kernel consumes input channels in pairs: give the single-channel gradient a zero partner
@@ -484,7 +486,7 @@ def channel_amax(t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     LAUNCHES["amax_channels"] += 1
     if CHANNEL_PASS_LOG is not None:                        # (tools/r6_chs_census.py: which tensors still need a pass)
         import traceback
-        CHANNEL_PASS_LOG.append((tuple(t.shape), [f.name for f in traceback.extract_stack(limit=8)][:-1]))
+        CHANNEL_PASS_LOG.append((tuple(t.shape), [f"{f.name}:{f.lineno}" for f in traceback.extract_stack(limit=8)][:-1]))
     hip.call("irr_amax_channels_f32", hip.ptr(t), B, C, H * W, hip.bs(t), hip.ptr(out), 1, hip.stream())
     return out
 

@@ -141,7 +141,7 @@ class _CatPart(ctypes.Structure):
 CAT_MAX_PARTS = 8            # IRR_CAT_MAX_PARTS
 
 
-def cat_channels_into(dst: torch.Tensor, parts, zero_tail: int = 0, amax: Optional[Amax] = None) -> None:
+def cat_channels_into(dst: torch.Tensor, parts, zero_tail: int = 0, amax: Optional[Amax] = None, chmax: Optional[torch.Tensor] = None) -> None:
     """dst[:, :sum(channels)] = cat(parts, dim=1) (+ ``zero_tail`` zero channels behind them) in ONE launch
     (irr_cat_channels_f32) -- dst is a channel-slice view of the consumer's buffer.  Parts whose planes are not dense are made
     contiguous first.  amax: a slot that receives max |.| of everything written (irr_cat_channels_amax_f32: the copy folds the
@@ -156,7 +156,10 @@ def cat_channels_into(dst: torch.Tensor, parts, zero_tail: int = 0, amax: Option
         chunk = recs[i:i + CAT_MAX_PARTS]
         arr = (_CatPart * len(chunk))(*[_CatPart(s_, bs_, ch_, 0) for s_, bs_, ch_ in chunk])
         view = dst[:, c0:]
-        if amax is not None:
+        if chmax is not None:                                  # (zeroed slots, one per channel written: the copy folds max |.| per channel too)
+            hip.call("irr_cat_channels_amax_ch_f32", hip.ptr(view), dst.stride(0), ctypes.addressof(arr), len(chunk), B, H * W,
+                     amax.ptr() if amax is not None else None, hip.ptr(chmax[c0:]), hip.stream())
+        elif amax is not None:
             hip.call("irr_cat_channels_amax_f32", hip.ptr(view), dst.stride(0), ctypes.addressof(arr), len(chunk), B, H * W, amax.ptr(),
                      hip.stream())
         else:
@@ -256,13 +259,12 @@ class _DenseEstimatorFn(hip.Function):
         S = None
         if _fwd_h2(buf[:, 448:ctot], ws[0], 1, 1):
             S = Amax.zeros(buf.device, 7)                        # (slot 6: the est slot behind the parts, when there is one)
-        cat_channels_into(buf[:, 448:], parts, amax=S.sub(5) if S is not None else None)
         # round 6: max |buf[:, c]| per channel, for the weight gradients whose launch takes the buffer as the operand in its gy role
-        # (conv3 / conv5: exchanged roles) -- every layer's launch folds its own slice, the input part costs one small pass
+        # (conv3 / conv5: exchanged roles) -- every layer's launch folds its own slice, the copy that assembles the input part folds that one
         Bch = None
         if S is not None and _c.WGRAD_CHANNEL_SCALE and any(ctx.needs_input_grad[3 + nparts:]):      # (a training pass: some weight wants its gradient)
             Bch = _c.zero_slots(buf.device, ctot)
-            _c.channel_amax(buf[:, 448:ctot], Bch[448:ctot])
+        cat_channels_into(buf[:, 448:], parts, amax=S.sub(5) if S is not None else None, chmax=Bch[448:] if Bch is not None else None)
         off = 448
         for i in range(5):
             co = _DenseEstimatorFn.GROW[i]
@@ -383,7 +385,7 @@ class _DenseEstimatorFn(hip.Function):
                            else (200000 if use_x3[k_] == 2 else 100000) + code)
                 if use_x3[k_] == 2:
                     args, _ = _h2_args(args, G[:, :t0], Gs.sub(0, k_ + 1), Gs.sub(k_ + 1) if not last else None)
-                    Gch_valid[0] = ch_on and not last and code != 9001
+                    Gch_valid[0] = ch_on and not last               # (either kernel family folds them)
                     if Gch_valid[0]:
                         hip.lib().irr_conv_x3_next_chmax(Gch[t0:t1].data_ptr())      # (one-shot: this column's launch)
                 else:

@@ -19,7 +19,8 @@ struct CatArgs {
 // AMAX: max |value written| (zero-fill parts included) folded into *amax -- the consumer of the buffer runs on the fp16x2 conv
 // kernels and needs the magnitude of its input: a separate pass over the buffer costs as much as this copy (round 5)
 template <bool VEC, bool AMAX>
-__global__ __launch_bounds__(256) void cat_channels_kernel(float* __restrict__ dst, long dst_bs, const CatArgs a, long hw, float* __restrict__ amax) {
+__global__ __launch_bounds__(256) void cat_channels_kernel(float* __restrict__ dst, long dst_bs, const CatArgs a, long hw, float* __restrict__ amax,
+                                                           float* __restrict__ chmax) {
   const int c = blockIdx.y, b = blockIdx.z;
   int part = 0;
 #pragma unroll
@@ -45,12 +46,25 @@ __global__ __launch_bounds__(256) void cat_channels_kernel(float* __restrict__ d
         }
     }
   }
-  if (AMAX) x3_amax_publish_block256(m, amax);              // (every thread of the block arrives)
+  if (AMAX) {                                               // (every thread of the block arrives)
+    // a block copies pixels of ONE destination channel: its maximum also serves chmax[c] (ABI 12: the channel maxima of the assembled
+    // input, for the weight gradients that take it as the operand in their gy role) -- one more look-then-atomic per block
+    __shared__ float wm[4];
+    m = x3_amax_wave(m);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float r = x3_amax_fold(x3_amax_fold(wm[0], wm[1]), x3_amax_fold(wm[2], wm[3]));
+      if (amax) x3_amax_commit(r, amax);
+      if (chmax) x3_amax_commit(r, chmax + c);
+    }
+  }
 }
 
 }  // namespace
 
-static int cat_channels_impl(float* dst, long dst_bs, const void* parts, int nparts, int B, long hw, float* amax, void* stream) {
+static int cat_channels_impl(float* dst, long dst_bs, const void* parts, int nparts, int B, long hw, float* amax, void* stream,
+                             float* chmax = nullptr) {
   if (!dst || !parts || nparts < 1 || nparts > IRR_CAT_MAX_PARTS || B <= 0 || B > 65535 || hw <= 0) return IRR_EINVAL;
   const IrrCatPart* p = (const IrrCatPart*)parts;
   CatArgs a;
@@ -73,12 +87,12 @@ static int cat_channels_impl(float* dst, long dst_bs, const void* parts, int npa
   if (c > 65535) return IRR_EINVAL;
   const dim3 grid(irr_cdiv(hw, 1024), c, B);
   hipStream_t st = (hipStream_t)stream;
-  if (amax) {
-    if (vec) hipLaunchKernelGGL((cat_channels_kernel<true, true>), grid, dim3(256), 0, st, dst, dst_bs, a, hw, amax);
-    else hipLaunchKernelGGL((cat_channels_kernel<false, true>), grid, dim3(256), 0, st, dst, dst_bs, a, hw, amax);
+  if (amax || chmax) {
+    if (vec) hipLaunchKernelGGL((cat_channels_kernel<true, true>), grid, dim3(256), 0, st, dst, dst_bs, a, hw, amax, chmax);
+    else hipLaunchKernelGGL((cat_channels_kernel<false, true>), grid, dim3(256), 0, st, dst, dst_bs, a, hw, amax, chmax);
   } else {
-    if (vec) hipLaunchKernelGGL((cat_channels_kernel<true, false>), grid, dim3(256), 0, st, dst, dst_bs, a, hw, amax);
-    else hipLaunchKernelGGL((cat_channels_kernel<false, false>), grid, dim3(256), 0, st, dst, dst_bs, a, hw, amax);
+    if (vec) hipLaunchKernelGGL((cat_channels_kernel<true, false>), grid, dim3(256), 0, st, dst, dst_bs, a, hw, amax, chmax);
+    else hipLaunchKernelGGL((cat_channels_kernel<false, false>), grid, dim3(256), 0, st, dst, dst_bs, a, hw, amax, chmax);
   }
   IRR_LAUNCH_CHECK();
   return 0;
@@ -92,6 +106,13 @@ extern "C" int irr_cat_channels_f32(float* dst, long dst_bs, const void* parts, 
 extern "C" int irr_cat_channels_amax_f32(float* dst, long dst_bs, const void* parts, int nparts, int B, long hw, float* amax, void* stream) {
   if (!amax) return IRR_EINVAL;
   return cat_channels_impl(dst, dst_bs, parts, nparts, B, hw, amax, stream);
+}
+
+// (ABI 12) the same, and chmax[c] = max(chmax[c], max |dst[:, c]| as written) for every destination channel c (amax nullable here)
+extern "C" int irr_cat_channels_amax_ch_f32(float* dst, long dst_bs, const void* parts, int nparts, int B, long hw, float* amax,
+                                            float* chmax, void* stream) {
+  if (!chmax) return IRR_EINVAL;
+  return cat_channels_impl(dst, dst_bs, parts, nparts, B, hw, amax, stream, chmax);
 }
 
 // ---- out[b, :] = x[b, :] + y[b, :] for B samples of n plane-dense floats with independent batch strides ------------------------
