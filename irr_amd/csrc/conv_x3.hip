@@ -311,8 +311,9 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
           float v = acc[s][r0 + k] + bv[k];
           if (a.lrelu) v = irr_lrelu(v);
           v *= a.alpha;
-          if (want_amax && vo[k] != OOB) ymax = x3_amax_fold(ymax, v);
-          if (want_ch && vo[k] != OOB) chm[r0 + k] = x3_amax_fold(chm[r0 + k], v);
+          // (one fold per stored value: with channel maxima wanted the tensor's maximum is taken from them at the end)
+          if (want_ch) { if (vo[k] != OOB) chm[r0 + k] = x3_amax_fold(chm[r0 + k], v); }
+          else if (want_amax && vo[k] != OOB) ymax = x3_amax_fold(ymax, v);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)vo[k], 0, 0);
         }
         continue;
@@ -335,11 +336,15 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
         v = a.res ? rv[k] + a.alpha * v : v * a.alpha;
         v += dv[k];                                   // 0 unless accumulating
         if (a.mask && co < a.nmask) v *= irr_lrelu_grad(mv[k]);
-        if (want_amax && vo[k] != OOB) ymax = x3_amax_fold(ymax, v);
-        if (want_ch && vo[k] != OOB) chm[r] = x3_amax_fold(chm[r], v);
+        if (want_ch) { if (vo[k] != OOB) chm[r] = x3_amax_fold(chm[r], v); }
+        else if (want_amax && vo[k] != OOB) ymax = x3_amax_fold(ymax, v);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)vo[k], 0, 0);
       }
     }
+  }
+  if (want_ch && want_amax) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ymax = __builtin_bit_cast(float, max(__builtin_bit_cast(uint32_t, ymax), __builtin_bit_cast(uint32_t, chm[r])));
   }
   if (want_amax) x3_amax_publish(ymax, a.y_amax);
   if (want_ch) {
