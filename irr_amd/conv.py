@@ -134,6 +134,7 @@ def x3_code(B: int, cin: int, H: int, W: int, cout: int, k: int, stride: int, di
 # libraries, the plain-low-piece build 7 of 8 runs NaN, the scaled-low-piece build (x3_split.h "Range") 0 of 31.
 # IRR_X3S_H2=0 / set_x3s_h2(False): the bf16x3 form.
 X3S_H2 = bool(int(os.environ.get("IRR_X3S_H2", "1")))
+_X3S_NO_CH_FOLD = bool(os.environ.get("IRR_X3S_NO_CH_FOLD"))         # A/B: channel maxima of the streaming kernel's outputs by a pass (as before ABI 12)
 _X3S_NO_FUSED_AMAX = bool(os.environ.get("IRR_X3S_NO_FUSED_AMAX"))     # diagnosis switch of NOTES C.5: the streaming kernel's output
                                                                        # magnitude by a separate pass instead of its epilogue
 
@@ -289,7 +290,7 @@ def conv_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                 hip.bs(x), hip.bs(out), hip.bs(res) if res is not None else 0,
                 int(lrelu), float(alpha), int(accumulate), None, 0, 0, hip.stream())
         variant = None
-    if y_chmax is not None and h2 and args[0] in ("irr_conv2d_fwd_h2", "irr_conv2d_fwd_h2_bits") and not (code == 9001 and _X3S_NO_FUSED_AMAX):
+    if y_chmax is not None and h2 and args[0] in ("irr_conv2d_fwd_h2", "irr_conv2d_fwd_h2_bits") and not (code == 9001 and (_X3S_NO_FUSED_AMAX or _X3S_NO_CH_FOLD)):
         hip.lib().irr_conv_x3_next_chmax(y_chmax.data_ptr())      # (one-shot: the launch below)
         y_chmax = None
     if TIMER is None:
@@ -328,7 +329,7 @@ def conv_forward_skip(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
             xa = x_amax if x_amax is not None else amax_measure(x)
             args += (xa.ptr(), xa.n, y_amax.ptr() if y_amax is not None else None)
         args += (hip.stream(),)
-        if y_chmax is not None and h2:
+        if y_chmax is not None and h2 and not _X3S_NO_CH_FOLD:
             hip.lib().irr_conv_x3_next_chmax(y_chmax.data_ptr())      # (one-shot: the launch below; y_chmax bounds y, the sum)
             y_chmax = None
         if TIMER is None:
@@ -423,7 +424,7 @@ def conv_dgrad(gy: torch.Tensor, weight: torch.Tensor, stride: int, dil: int, in
                     k, 1, dil, hip.bs(gy), hip.bs(gx), hip.bs(res) if res is not None else 0, 0, float(alpha),
                     int(accumulate), *margs, hip.stream())
             variant = None
-        fold_ch = gx_chmax is not None and h2 and not (code == 9001 and _X3S_NO_FUSED_AMAX)     # (either kernel family folds them in its epilogue)
+        fold_ch = gx_chmax is not None and h2 and not (code == 9001 and (_X3S_NO_FUSED_AMAX or _X3S_NO_CH_FOLD))     # (either kernel family folds them in its epilogue)
         if fold_ch:
             hip.lib().irr_conv_x3_next_chmax(gx_chmax.data_ptr())      # (one-shot: the launch below)
             gx_chmax = None

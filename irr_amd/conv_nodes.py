@@ -156,6 +156,10 @@ def cat_channels_into(dst: torch.Tensor, parts, zero_tail: int = 0, amax: Option
         chunk = recs[i:i + CAT_MAX_PARTS]
         arr = (_CatPart * len(chunk))(*[_CatPart(s_, bs_, ch_, 0) for s_, bs_, ch_ in chunk])
         view = dst[:, c0:]
+        if chmax is not None and os.environ.get("IRR_CAT_NO_CH_FOLD"):      # (A/B: a pass over what the copy wrote)
+            cat_channels_into(dst, parts, zero_tail, amax)
+            _c.channel_amax(dst[:, :chmax.numel()], chmax)
+            return
         if chmax is not None:                                  # (zeroed slots, one per channel written: the copy folds max |.| per channel too)
             hip.call("irr_cat_channels_amax_ch_f32", hip.ptr(view), dst.stride(0), ctypes.addressof(arr), len(chunk), B, H * W,
                      amax.ptr() if amax is not None else None, hip.ptr(chmax[c0:]), hip.stream())
@@ -385,7 +389,7 @@ class _DenseEstimatorFn(hip.Function):
                            else (200000 if use_x3[k_] == 2 else 100000) + code)
                 if use_x3[k_] == 2:
                     args, _ = _h2_args(args, G[:, :t0], Gs.sub(0, k_ + 1), Gs.sub(k_ + 1) if not last else None)
-                    Gch_valid[0] = ch_on and not last               # (either kernel family folds them)
+                    Gch_valid[0] = ch_on and not last and not (code == 9001 and _c._X3S_NO_CH_FOLD)      # (either kernel family folds them)
                     if Gch_valid[0]:
                         hip.lib().irr_conv_x3_next_chmax(Gch[t0:t1].data_ptr())      # (one-shot: this column's launch)
                 else:
@@ -718,7 +722,7 @@ class _OccUpsampleFn(hip.Function):
         if dual:
             g_x2 = torch.empty(B_, w_out.shape[1], H_, W_, device=dev, dtype=torch.float32)
             gpre_e = torch.empty_like(g_x2)
-            ech = chv(w_end.shape[1], w_end.shape[0])
+            ech = chv(w_end.shape[1], w_end.shape[0]) if not os.environ.get("IRR_DUAL_NO_CH_FOLD") else None      # (A/B)
             LAUNCHES["dgrad_smallco"] += 1
             hip.call("irr_conv2d_smallco_dgrad_dual_ch_f32", hip.ptr(gpre_o), hip.ptr(w_out.detach().contiguous()), hip.ptr(gpre_e),
                      hip.ptr(g_x2), hip.ptr(e), B_, w_out.shape[1], H_, W_, 1, hip.bs(gpre_o), hip.bs(gpre_e), hip.bs(g_x2), hip.bs(e),

@@ -80,6 +80,27 @@ class _PackRegistry:
         return True
 
 
+    def pin(self):
+        """strong references to everything the batched repack launch touches right now: every live registered weight, its packed copy,
+        the job table, the weights' maximum slots.  A CAPTURED step replays that launch with the pointers of capture time -- including
+        the packs of any OTHER model alive in the process then (this registry is per device, not per model): were such a model freed
+        later, every replay would write its packs into memory that belongs to somebody else by now.  irr_amd.train.GraphedTrainStep
+        holds the result for as long as its graph lives (and takes it BEFORE the capture starts, so that no entry can disappear -- and
+        the job table be rebuilt with a host-to-device copy -- in the middle of it)."""
+        held = []
+        for _, (ref, dst, _b, _r) in list(self.entries.items()):
+            w = ref()
+            if w is not None:
+                held.append((w, dst))
+        for _, (ref, t) in list(self.amax_sources.items()):
+            w = ref()
+            if w is not None:
+                held.append((w, t))
+        for refs, g in self.amax_groups:
+            held.append(([r() for r in refs], g))
+        held.append(self._table)
+        return held
+
     def refresh_amax(self) -> None:
         """max |w| of every weight with an h2 pack (one multi-tensor launch + one copy per weight's slot) and the group maxima of
         the combined matrices -- before the batched repack reads them"""
@@ -105,6 +126,11 @@ class _PackRegistry:
 
 
 _REGISTRIES = {}
+
+
+def pin_all():
+    """_PackRegistry.pin() of every device's registry"""
+    return [r.pin() for r in _REGISTRIES.values()]
 
 
 def _registry(device) -> _PackRegistry:

@@ -1277,7 +1277,7 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
     if (rc) return rc;
     if (a.ksplit > 1) {
       const long n = (long)a.B * Cout * H * W;
-      if (a.y_chmax && (long)H * W <= 4096) {               // (the small pyramid levels: waves that stay inside a plane fold the channel's maximum)
+      if (a.y_chmax && (long)H * W <= 4096 && !IRR_ENV_FLAG("IRR_X3_NO_PLANES_EPILOGUE")) {       // (A/B switch: the flat kernel + a pass)               // (the small pyramid levels: waves that stay inside a plane fold the channel's maximum)
         const int spb = (long)H * W >= 256 ? 1 : (int)(256 / ((long)H * W));
         const long blocks = (long)Cout * irr_cdiv(a.B, spb);
         hipLaunchKernelGGL(x3_splitk_epilogue_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ws, bias, a.res, a.y, a.mask,
@@ -1288,7 +1288,7 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
                            Cout, (long)H * W, a.ksplit, y_bs, res_bs, mask_bs, nmask, lrelu, alpha, accumulate, np == 2 ? y_amax : nullptr);
       IRR_LAUNCH_CHECK();
       // (larger planes with a K split: one pass over the finished slice of y)
-      if (a.y_chmax && (long)H * W > 4096) { const int rc2 = irr_amax_channels_launch(a.y, a.B, Cout, (long)H * W, y_bs, a.y_chmax, st, false); if (rc2) return rc2; }
+      if (a.y_chmax && ((long)H * W > 4096 || IRR_ENV_FLAG("IRR_X3_NO_PLANES_EPILOGUE"))) { const int rc2 = irr_amax_channels_launch(a.y, a.B, Cout, (long)H * W, y_bs, a.y_chmax, st, false); if (rc2) return rc2; }
     }
   }
   return 0;

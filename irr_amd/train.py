@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import conv as _conv
+from . import conv_pack as _conv_pack
 
 
 _GRAD_FINITE_LOG = bool(os.environ.get("IRR_GRAD_FINITE_LOG"))
@@ -165,6 +166,7 @@ class GraphedTrainStep:
         self.warmup = warmup
         self.check_nan = bool(step.check_nan)
         self.graph = None
+        self._pinned = None                       # what the captured repack launch touches (conv_pack.pin_all)
         self.hyper = None
         self.static_in: Dict[str, torch.Tensor] = {}
         self.result = None
@@ -174,6 +176,11 @@ class GraphedTrainStep:
         self.static_in = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in example_dict.items()}
         eager = TrainStep(self.step.model_and_loss, self.step.optimizer, self.step.training_key, self.step.grad_sync,
                           check_nan=False, augmentation=self.step.augmentation)
+        # The batched repack launch of the captured step covers EVERY conv weight registered on the device -- other models of the
+        # process included (conv_pack._PackRegistry.pin): drop what is garbage already, then hold the rest for the life of the graph
+        import gc
+        gc.collect()
+        self._pinned = _conv_pack.pin_all() if not os.environ.get("IRR_GRAPH_NO_PIN") else None      # (diagnosis switch: the fault of tests/test_train_gpu.py::test_graphed_step_survives_the_death_of_another_model)
         snap = self.step.optimizer.snapshot()         # the warm-up steps below must not count as training steps
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(device=cur.device)
@@ -184,6 +191,8 @@ class GraphedTrainStep:
         cur.wait_stream(side)
         self.step.optimizer.restore(snap)
         torch.cuda.synchronize()
+        if self._pinned is not None:
+            self._pinned = _conv_pack.pin_all()       # (+ what the warm-up registered: the table the capture will reuse)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):            # (records the step; nothing executes until replay())
             self.result = eager(self.static_in)
