@@ -1093,12 +1093,18 @@ __global__ __launch_bounds__(256) void x3_splitk_epilogue_planes_kernel(const fl
   const float bv = bias ? bias[co] : 0.f;
   const bool masked = mask && co < nmask;
   float m = 0.f;
-  for (long e = threadIdx.x; e < (long)spb * hw; e += 256) {
-    const long b = b0 + e / hw;
-    const long pix = e % hw;
+  const int ihw = (int)hw;                                   // (hw <= 4096 here)
+  // spb > 1: hw < 256 and a thread owns at most one element (sample e / hw, pixel e % hw: one 32-bit division per thread);
+  // spb == 1: the pixels of one plane, no division
+  const int s0 = spb > 1 ? (int)threadIdx.x / ihw : 0;
+  const int p0 = spb > 1 ? (int)threadIdx.x - s0 * ihw : (int)threadIdx.x;
+  const int pstep = spb > 1 ? ihw : 256;                     // (spb > 1: one trip)
+  for (int pix = p0; pix < ihw && s0 < spb; pix += pstep) {
+    const long b = b0 + s0;
     if (b >= B) break;
     const long i = (b * Cout + co) * hw + pix;
     float v = 0.f;
+#pragma unroll 4
     for (int k = 0; k < ksplit; ++k) v += part[(long)k * n + i];
     v += bv;
     if (lrelu) v = irr_lrelu(v);
