@@ -475,6 +475,19 @@ def main():
         extra["without_kernel_timer"] = {"value": round(nt["value"], 3), "ms_per_step": round(nt["dt"] / 5 * 1e3, 3), "steps": 5,
                                          "note": "same process, same step, KernelTimer off (the headline's timed region records two "
                                                  "HIP events around every conv launch for the roofline object)"}
+    if world == 1 and not a.no_extra_legs and a.harness == "own":
+        # what the reference's legacy `requires_grad_(True)` on the INPUT IMAGES costs (runtime.py:158-162; TrainStep(input_grads=)): 5 steps
+        # of the same workload whose backward does not produce the two image gradients nobody reads.  Information, not the headline.
+        def make_noig(batch_pairs, _m=make_step):
+            st = _m(batch_pairs)
+            st.input_grads = False
+            return st
+        ng = run(make_noig, a.batch, a.height, a.width, 5, 1, False)
+        extra["without_input_grads"] = {"value": round(ng["value"], 3), "unit": "image-pairs/s", "ms_per_step": round(ng["dt"] / 5 * 1e3, 3),
+                                        "steps": 5, "warmup": 1, "loss": ng["loss"],
+                                        "note": "TrainStep(input_grads=False): the input images are not marked requires_grad (the reference marks "
+                                                "them, runtime.py:158-162, and so does the headline); same losses, same parameter gradients, no "
+                                                "d loss / d image"}
     if world == 1 and not a.no_extra_legs and a.harness == "own" and C.MATH == "h2":
         # the range-free fall-back arithmetic beside the headline: 5 steps of the same workload, same process, with every
         # split-operand conv on the bf16x3 form (three bf16 pieces, six products: 24 significant bits whatever the operand range)

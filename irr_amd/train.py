@@ -71,7 +71,7 @@ class TrainStep:
     """Holds model+loss+optimizer and runs reference-equivalent steps on device-resident batches."""
 
     def __init__(self, model_and_loss: ModelAndLoss, optimizer: torch.optim.Optimizer, training_key: str = "total_loss",
-                 grad_sync=None, check_nan=True, augmentation=None):
+                 grad_sync=None, check_nan=True, augmentation=None, input_grads: bool = True):
         """augmentation: optional callable(example_dict) -> example_dict applied under ``no_grad`` to the device-resident batch
         before the forward pass, where the reference's ``_step`` runs its GPU augmentation (runtime.py:151-153), e.g.
         ``irr_amd.augment.RandomAffineFlowOcc`` (augmentations.py:368-653).
@@ -79,12 +79,17 @@ class TrainStep:
         STEP: the loss is copied to pinned host memory right after the forward pass, backward is enqueued, and the host reads the
         value (already there by then) before optimizer.step() -- same exception, no update of the weights on NaN, but no drain of
         the GPU pipeline between forward and backward.  "before_backward": the reference's exact placement (``.item()`` before
-        ``backward()``; the GPU idles while the host re-issues the backward pass).  False: no check."""
+        ``backward()``; the GPU idles while the host re-issues the backward pass).  False: no check.
+        input_grads: True = the reference's ``_step`` literally (runtime.py:158-162 marks every INPUT tensor ``requires_grad_(True)``, a
+        pre-0.4 Variable idiom): backward also produces d loss / d image for both images -- through the warps of the raw images, the five
+        image resizes of the refinement levels and the first pyramid convolution -- which nothing reads.  False: the inputs are plain
+        tensors; losses, parameter gradients and the update are bit-identical (tests/test_train_gpu.py), ``input1.grad`` stays None."""
         self.model_and_loss = model_and_loss
         self.optimizer = optimizer
         self.training_key = training_key
         self.grad_sync = grad_sync              # callable() run between backward and optimizer.step (data parallel)
         self.augmentation = augmentation
+        self.input_grads = bool(input_grads)
         if check_nan not in (True, False, "before_step", "before_backward"):
             raise ValueError(check_nan)
         self.check_nan = "before_step" if check_nan is True else check_nan
@@ -96,7 +101,7 @@ class TrainStep:
                 example_dict = self.augmentation(example_dict)
         for key, t in example_dict.items():      # runtime.py:158-162
             if "input" in key:
-                t.requires_grad_(True)
+                t.requires_grad_(self.input_grads)
             elif "target" in key:
                 t.requires_grad_(False)
         self.optimizer.zero_grad()

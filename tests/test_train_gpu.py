@@ -476,6 +476,32 @@ def test_graphed_step_without_the_lane_matches_eager(lane):
         Fn._WARP_BWD_ATOMIC = False
 
 
+def test_train_step_without_input_gradients_is_the_same_step():
+    """TrainStep(input_grads=False): the reference marks the input IMAGES requires_grad (runtime.py:158-162, a pre-0.4 idiom) and so
+    does TrainStep by default; without it backward skips d loss / d image (image warps, the five image resizes of the refinement levels,
+    the first pyramid convolution's data gradient) -- losses identical, parameter gradients equal up to the float-atomic noise of two
+    eager runs, ``input1.grad`` None instead of a tensor."""
+    grads, losses, igrad = {}, {}, {}
+    for ig in (True, False):
+        m, mal, arena, opt, step = _setup(2, lane=True)
+        try:
+            step.input_grads = ig
+            batch = _batch(2, 128, 192, 77)
+            arena.zero_grad()
+            ld, _, _ = step(batch)
+            torch.cuda.synchronize()
+            losses[ig] = [float(ld[k].detach()) for k in ("flow_loss", "occ_loss", "total_loss")]
+            igrad[ig] = batch["input1"].grad
+            # (the step has been applied: compare the first Adam moment = (1 - beta1) * gradient of this single step)
+            grads[ig] = opt.exp_avg.double().clone() if hasattr(opt, "exp_avg") else torch.cat([p.grad.reshape(-1) for p in m.parameters()]).double()
+        finally:
+            arena.disable_async_wgrad()
+    assert losses[True] == losses[False], losses
+    assert igrad[True] is not None and float(igrad[True].abs().max()) > 0 and igrad[False] is None
+    d = float((grads[True] - grads[False]).norm() / grads[True].norm())
+    assert d <= 1e-5, d
+
+
 def test_graphed_step_survives_the_death_of_another_model():
     """End of round 6.  The batched weight-repack launch covers EVERY conv weight registered on the device (conv_pack._PackRegistry is
     per device, not per model), so a captured step replays it with the pack pointers of ANY model that was alive at capture time.  If

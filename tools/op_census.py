@@ -54,6 +54,7 @@ for ev in prof.events():
     t[1] += ev.device_time_total
 # launches by the outermost enclosing profiler range (autograd node in backward, module-level op in forward)
 top = collections.defaultdict(lambda: [0, 0.0])
+acc = collections.defaultdict(lambda: [0, 0.0])
 for ev in prof.events():
     if ev.device_time_total <= 0 or not ev.name.startswith("aten::") or (ev.cpu_parent is not None and ev.cpu_parent.name.startswith("aten::")):
         continue
@@ -63,9 +64,16 @@ for ev in prof.events():
     key = (anc.name[:70], ev.name)
     top[key][0] += 1
     top[key][1] += ev.device_time_total
+    if ev.name in ("aten::add_", "aten::add"):                 # the engine's gradient accumulations: which node's outputs, which shapes
+        k2 = (anc.name.replace("autograd::engine::evaluate_function: ", "")[:40], str(ev.input_shapes[0])[:30])
+        acc[k2][0] += 1
+        acc[k2][1] += ev.device_time_total
 print("== torch ops by outermost range (autograd node) ==")
 for k, v in sorted(top.items(), key=lambda kv: -kv[1][0])[:45]:
     print(f"{v[0]:5d} {v[1] / 1e3:7.2f} ms  {k[0]:70s} {k[1]}")
+print("== gradient accumulations (aten::add_ / add) by producing node and shape ==")
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])[:40]:
+    print(f"{v[0]:5d} {v[1] / 1e3:7.2f} ms  {k[0]:40s} {k[1]}")
 print("== per op ==")
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1][1])[:25]:
     print(f"{k:40s} {v[0]:5d} launches {v[1] / 1e3:8.2f} ms")
