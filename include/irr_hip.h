@@ -122,6 +122,10 @@ int irr_resize_bilinear_ac_fwd_f32(const float* x, float* out, int B, int C, int
 /* gx = alpha * resize^T(gout); gx fully overwritten (gather form, deterministic). */
 int irr_resize_bilinear_ac_bwd_f32(const float* gout, float* gx, int B, int C, int H, int W, int OH, int OW,
                                    long gout_bs, long gx_bs, float alpha, void* stream);
+/* (ABI 12) accumulate = 1: gx += alpha * resize^T(gout) -- the gradients of one tensor that was resized to several sizes meet in one
+ * buffer (calls on one stream are ordered; no atomics); 0: irr_resize_bilinear_ac_bwd_f32. */
+int irr_resize_bilinear_ac_bwd_acc_f32(const float* gout, float* gx, int B, int C, int H, int W, int OH, int OW,
+                                       long gout_bs, long gx_bs, float alpha, int accumulate, void* stream);
 /* The same with align_corners=False (half-pixel centres, ATen's F.interpolate(x, [OH, OW], mode="bilinear")): the fallback
  * of upsample_factor2 when the nearest-x2 map does not have the guide's size, i.e. odd pyramid sizes
  * (models/irr_modules.py:21-27; Sintel 436x1024 -> 218, 109, 55, ...). */

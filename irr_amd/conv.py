@@ -175,7 +175,17 @@ from .conv_amax import Amax, measure as amax_measure  # noqa: E402,F401
 # ----------------------------------------------------------------------------------------------
 def _call_conv(args) -> None:
     """Launch a conv entry point from its argument tuple.  irr_conv2d_fwd_x3 problems that are too small to fill the chip
-    get a scratch buffer and run through the K-split entry point (csrc/conv_x3.hip: blockIdx.z splits the channel chunks)."""
+    get a scratch buffer and run through the K-split entry point (csrc/conv_x3.hip: blockIdx.z splits the channel chunks).
+    A caller may have armed irr_conv_x3_next_chmax for this launch: if anything fails before the library consumes it (the scratch
+    allocation), it is disarmed here -- a one-shot pointer must never reach a LATER launch of this thread."""
+    try:
+        _call_conv_(args)
+    except BaseException:
+        hip.lib().irr_conv_x3_next_chmax(None)
+        raise
+
+
+def _call_conv_(args) -> None:
     if args[0] in ("irr_conv2d_fwd_x3", "irr_conv2d_fwd_h2"):
         B, cin, H, W, cout, dil = args[6:12]
         n = hip.lib().irr_conv2d_fwd_x3_ws_elems(B, cin, H, W, cout, dil)

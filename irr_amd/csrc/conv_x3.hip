@@ -1343,8 +1343,10 @@ extern "C" int irr_conv2d_fwd_h2_bits(const float* x, const void* wq, const floa
                                       int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
                                       float alpha, int accumulate, const void* mask_bits, int nmask, void* bits_out,
                                       const float* x_amax, int n_amax, float* y_amax, void* stream) {
-  if (!mask_bits && !bits_out) return IRR_EINVAL;
-  if (((uintptr_t)mask_bits | (uintptr_t)bits_out) & 3) return IRR_EINVAL;
+  if ((!mask_bits && !bits_out) || (((uintptr_t)mask_bits | (uintptr_t)bits_out) & 3)) {
+    g_next_chmax = nullptr;                                  // (a rejected launch consumes the one-shot too: it must not reach a later one)
+    return IRR_EINVAL;
+  }
   return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, accumulate, nullptr, 0, nmask,
                      nullptr, 0, stream, nullptr, 0, 2, x_amax, n_amax, y_amax, (const uint32_t*)mask_bits, (uint32_t*)bits_out);
 }
@@ -1353,7 +1355,10 @@ extern "C" int irr_conv2d_fwd_h2_bits(const float* x, const void* wq, const floa
 extern "C" int irr_conv2d_fwd_h2_dual(const float* x, const void* wq, const float* bias, const float* res, float* y, float* y2, int B,
                                       int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, long y2_bs,
                                       int lrelu, float alpha, const float* x_amax, int n_amax, float* y_amax, void* stream) {
-  if (!y2 || !res) return IRR_EINVAL;
+  if (!y2 || !res) {
+    g_next_chmax = nullptr;                                  // (see irr_conv2d_fwd_h2_bits)
+    return IRR_EINVAL;
+  }
   return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, 0, nullptr, 0, 0, nullptr, 0, stream,
                      y2, y2_bs, 2, x_amax, n_amax, y_amax);
 }

@@ -62,7 +62,7 @@ __device__ __forceinline__ float tap_weight(int i, int o, int in, float scale) {
   return w;
 }
 
-template <bool HP>
+template <bool HP, bool ACC = false>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gx, int C,
                                                         int H, int W, int OH, int OW, long gout_bs, long gx_bs,
                                                         float alpha) {
@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
         if (wx != 0.f) acc += wy * wx * gc[(long)oy * OW + ox];
       }
     }
-    gx[(long)b * gx_bs + (long)c * plane + p] = alpha * acc;
+    float* dst = gx + (long)b * gx_bs + (long)c * plane + p;
+    *dst = ACC ? *dst + alpha * acc : alpha * acc;
   }
 }
 
@@ -102,6 +103,9 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
 // neighbouring output pixels are >= 2 input pixels apart, so their 2 x 2 footprints are disjoint and gx is zero everywhere else.  The
 // gather form above evaluates ~9 candidate taps for every INPUT pixel (215 us for 384x448 -> 6x7 at 64 x 3 planes, five such calls
 // per step); here gx is zero-filled and one thread per OUTPUT pixel stores its (at most) four contributions -- plain stores, no atomics.
+// ACC: gx += ... (the zero fill is the caller's, or an earlier call's: irr_resize_bilinear_ac_bwd_acc_f32) -- footprints of ONE call are
+// disjoint, calls on one stream are ordered, so the read-modify-write needs no atomics either.
+template <bool ACC = false>
 __global__ __launch_bounds__(256) void resize_bwd_sparse_kernel(const float* __restrict__ gout, float* __restrict__ gx, int C, int H,
                                                                int W, int OH, int OW, long gout_bs, long gx_bs, float alpha) {
   const long oplane = (long)OH * OW;
@@ -119,11 +123,12 @@ __global__ __launch_bounds__(256) void resize_bwd_sparse_kernel(const float* __r
   for (int c = blockIdx.y; c < C; c += gridDim.y) {
     const float g = gout[(long)b * gout_bs + (long)c * oplane + p];
     float* gc = gx + (long)b * gx_bs + (long)c * plane;
-    gc[(long)y0 * W + x0] = alpha * (wy0 * wx0 * g);
-    if (x1 != x0) gc[(long)y0 * W + x1] = alpha * (wy0 * lx1 * g);
+    auto put = [&](long o, float v) { gc[o] = ACC ? gc[o] + v : v; };
+    put((long)y0 * W + x0, alpha * (wy0 * wx0 * g));
+    if (x1 != x0) put((long)y0 * W + x1, alpha * (wy0 * lx1 * g));
     if (y1 != y0) {
-      gc[(long)y1 * W + x0] = alpha * (ly1 * wx0 * g);
-      if (x1 != x0) gc[(long)y1 * W + x1] = alpha * (ly1 * lx1 * g);
+      put((long)y1 * W + x0, alpha * (ly1 * wx0 * g));
+      if (x1 != x0) put((long)y1 * W + x1, alpha * (ly1 * lx1 * g));
     }
   }
 }
@@ -140,27 +145,47 @@ extern "C" int irr_resize_bilinear_ac_fwd_f32(const float* x, float* out, int B,
   return 0;
 }
 
-extern "C" int irr_resize_bilinear_ac_bwd_f32(const float* gout, float* gx, int B, int C, int H, int W, int OH, int OW,
-                                              long gout_bs, long gx_bs, float alpha, void* stream) {
+static int resize_ac_bwd_impl(const float* gout, float* gx, int B, int C, int H, int W, int OH, int OW,
+                              long gout_bs, long gx_bs, float alpha, int accumulate, void* stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || !gout || !gx || B > 65535) return IRR_EINVAL;
   if (OH > 1 && OW > 1 && (H - 1) >= 2 * (OH - 1) && (W - 1) >= 2 * (OW - 1) && !IRR_ENV_FLAG("IRR_RESIZE_BWD_GATHER")) {
     // downsampling by >= 2 per axis: disjoint 2 x 2 footprints (see resize_bwd_sparse_kernel)
     const size_t per = sizeof(float) * (size_t)C * H * W;
-    if (gx_bs == (long)C * H * W) {
-      IRR_HIP_TRY(irr_zero_async(gx, per * (size_t)B, (hipStream_t)stream));
-    } else {
-      for (int b = 0; b < B; ++b) IRR_HIP_TRY(irr_zero_async(gx + (long)b * gx_bs, per, (hipStream_t)stream));
+    if (!accumulate) {
+      if (gx_bs == (long)C * H * W) {
+        IRR_HIP_TRY(irr_zero_async(gx, per * (size_t)B, (hipStream_t)stream));
+      } else {
+        for (int b = 0; b < B; ++b) IRR_HIP_TRY(irr_zero_async(gx + (long)b * gx_bs, per, (hipStream_t)stream));
+      }
     }
     dim3 gs(irr_cdiv((long)OH * OW, 256), C < 8 ? C : 8, B);
-    hipLaunchKernelGGL(resize_bwd_sparse_kernel, gs, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs, gx_bs, alpha);
+    if (accumulate)
+      hipLaunchKernelGGL(resize_bwd_sparse_kernel<true>, gs, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs, gx_bs, alpha);
+    else
+      hipLaunchKernelGGL(resize_bwd_sparse_kernel<false>, gs, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs, gx_bs, alpha);
     IRR_LAUNCH_CHECK();
     return 0;
   }
   dim3 grid(irr_cdiv((long)H * W, 256), C < 8 ? C : 8, B);
-  hipLaunchKernelGGL(resize_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs,
-                     gx_bs, alpha);
+  if (accumulate)
+    hipLaunchKernelGGL((resize_bwd_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs, gx_bs, alpha);
+  else
+    hipLaunchKernelGGL((resize_bwd_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs, gx_bs, alpha);
   IRR_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int irr_resize_bilinear_ac_bwd_f32(const float* gout, float* gx, int B, int C, int H, int W, int OH, int OW,
+                                              long gout_bs, long gx_bs, float alpha, void* stream) {
+  return resize_ac_bwd_impl(gout, gx, B, C, H, W, OH, OW, gout_bs, gx_bs, alpha, 0, stream);
+}
+
+// gx += alpha * resize^T(gout) (accumulate = 1; 0: irr_resize_bilinear_ac_bwd_f32): the gradients of ONE tensor resized to several sizes
+// meet in one buffer -- the raw images at the five refinement levels (models/IRR_PWC.py:126-127): one zero fill and five sparse
+// read-modify-write launches instead of five fills and four dense additions of maps that are 75-99.9 % zeros
+extern "C" int irr_resize_bilinear_ac_bwd_acc_f32(const float* gout, float* gx, int B, int C, int H, int W, int OH, int OW,
+                                                  long gout_bs, long gx_bs, float alpha, int accumulate, void* stream) {
+  return resize_ac_bwd_impl(gout, gx, B, C, H, W, OH, OW, gout_bs, gx_bs, alpha, accumulate ? 1 : 0, stream);
 }
 
 extern "C" int irr_resize_bilinear_hp_fwd_f32(const float* x, float* out, int B, int C, int H, int W, int OH, int OW,
@@ -177,7 +202,7 @@ extern "C" int irr_resize_bilinear_hp_bwd_f32(const float* gout, float* gx, int 
                                               long gout_bs, long gx_bs, float alpha, void* stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || !gout || !gx || B > 65535) return IRR_EINVAL;
   dim3 grid(irr_cdiv((long)H * W, 256), C < 8 ? C : 8, B);
-  hipLaunchKernelGGL(resize_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs,
+  hipLaunchKernelGGL((resize_bwd_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, gout, gx, C, H, W, OH, OW, gout_bs,
                      gx_bs, alpha);
   IRR_LAUNCH_CHECK();
   return 0;

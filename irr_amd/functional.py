@@ -195,6 +195,49 @@ class _ResizeAC(hip.Function):
         return gx, None, None, None, None
 
 
+class _ResizeACMulti(hip.Function):
+    """x resized (align_corners=True) to SEVERAL sizes by one node: forward = the plain launches, backward = ONE gradient buffer that
+    the first size's launch overwrites and the others accumulate into (irr_resize_bilinear_ac_bwd_acc_f32) -- as separate nodes the
+    autograd engine adds their full-size gradients pairwise.  The raw images at the refinement levels (models/IRR_PWC.py:126-127): five
+    downsamplings of a (2B, 3, H, W) tensor whose gradients are 75-99.9 % zeros."""
+
+    @staticmethod
+    def forward(ctx, x, *sizes):
+        _need_cuda(x)
+        x = _pd(x)
+        B, C, H, W = x.shape
+        outs = []
+        for oh, ow in sizes:
+            out = torch.empty(B, C, oh, ow, device=x.device, dtype=torch.float32)
+            hip.call("irr_resize_bilinear_ac_fwd_f32", hip.ptr(x), hip.ptr(out), B, C, H, W, oh, ow, hip.bs(x), hip.bs(out), 1.0, hip.stream())
+            outs.append(out)
+        ctx.cfg = (B, C, H, W, tuple(sizes))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        B, C, H, W, sizes = ctx.cfg
+        gx, first = None, True
+        for (oh, ow), g in zip(sizes, gouts):
+            if g is None:
+                continue
+            g = _pd(g)
+            if gx is None:
+                gx = torch.empty(B, C, H, W, device=g.device, dtype=torch.float32)
+            hip.call("irr_resize_bilinear_ac_bwd_acc_f32", hip.ptr(g), hip.ptr(gx), B, C, H, W, oh, ow, hip.bs(g), hip.bs(gx), 1.0,
+                     0 if first else 1, hip.stream())
+            first = False
+        return (gx,) + (None,) * len(sizes)
+
+
+def resize_bilinear_ac_multi(x, sizes):
+    """[F.interpolate(x, [oh, ow], mode='bilinear', align_corners=True) for (oh, ow) in sizes] as one autograd node (one gradient buffer)"""
+    sizes = tuple((int(h), int(w)) for h, w in sizes)
+    if not x.requires_grad or len(sizes) < 2:
+        return [resize_bilinear_ac(x, h, w) for h, w in sizes]
+    return list(_ResizeACMulti.apply(x, *sizes))
+
+
 def resize_bilinear_ac(x, oh: int, ow: int, alpha: float = 1.0):
     """alpha * F.interpolate(x, [oh, ow], mode='bilinear', align_corners=True)."""
     return _ResizeAC.apply(x, int(oh), int(ow), float(alpha), "ac")

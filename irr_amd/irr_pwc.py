@@ -179,6 +179,12 @@ class PWCNet(nn.Module):
         flow = torch.zeros(2 * B, 2, h0, w0, device=dev)          # [flow_f; flow_b]
         occ = torch.zeros(2 * B, 1, h0, w0, device=dev)           # [occ_f ; occ_b ]
         flows, occs = [], []
+        # the raw images at every refinement level (models/IRR_PWC.py:126-127): one autograd node for the five resizes -- when the inputs
+        # require grad (the reference's _step marks them, runtime.py:158-162) their five sparse full-size gradients meet in ONE buffer
+        # instead of being added pairwise by the engine (IRR_NO_RESIZE_MULTI=1: A/B switch)
+        n_ref = min(self.output_level + 1, len(pyr))
+        imgs = (Fn.resize_bilinear_ac_multi(raw, [tuple(pyr[l_].shape[2:]) for l_ in range(n_ref)])
+                if not os.environ.get("IRR_NO_RESIZE_MULTI") else None)
 
         for l, x in enumerate(pyr):
             h, w = x.shape[2:]
@@ -224,7 +230,7 @@ class PWCNet(nn.Module):
                     pending_join = None
 
                 # refinement (models/IRR_PWC.py:126-138, alias-free)
-                img = Fn.resize_bilinear_ac(raw, h, w)
+                img = imgs[l] if imgs is not None else Fn.resize_bilinear_ac(raw, h, w)
                 G = flow_cont * t_glb
                 img_o_warp = warp_other(img, G)
                 flow = self.refine_flow(G.detach(), img - img_o_warp, x_1by1, scale=s_glb)   # incl. to_global

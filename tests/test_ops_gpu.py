@@ -361,3 +361,35 @@ def test_warp_swap_halves_equals_swapped_copy():
     np.testing.assert_allclose(fb.grad.cpu().numpy(), fa.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
     with pytest.raises(Exception):
         Fn.warp(x[:3].cuda(), fl[:3].cuda(), 4 * H, 4 * W, 0.05, 1.0, swap_halves=True)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 3, 37, 53), (2, 2, 24, 28)])
+def test_resize_multi_is_the_sum_of_the_single_nodes(shape):
+    """Fn.resize_bilinear_ac_multi (round 6): one autograd node for several sizes of one tensor -- outputs identical to the single
+    launches, the ONE gradient buffer (first size overwrites, the others accumulate: sparse footprints for downsampling by >= 2,
+    gather form otherwise, an upsampling size included) equal to the sum the autograd engine forms from separate nodes."""
+    from irr_amd import functional as Fn
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, C, H, W, generator=g).cuda()
+    sizes = [(max(1, H // 16), max(1, W // 16)), (H // 8, W // 8), (H // 4, W // 4), (H // 2 + 1, W // 2), (H - 1, W - 3), (H + 5, W + 2)]
+    gouts = [torch.randn(B, C, h, w, generator=g).cuda() for h, w in sizes]
+    xa = x.clone().requires_grad_(True)
+    outs_a = Fn.resize_bilinear_ac_multi(xa, sizes)
+    xb = x.clone().requires_grad_(True)
+    outs_b = [Fn.resize_bilinear_ac(xb, h, w) for h, w in sizes]
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    torch.autograd.backward(outs_a, gouts)
+    torch.autograd.backward(outs_b, gouts)
+    ref = xb.grad.double()
+    assert float((xa.grad.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+    # a size without a gradient (a truncated pass) is skipped
+    xc = x.clone().requires_grad_(True)
+    outs_c = Fn.resize_bilinear_ac_multi(xc, sizes[:3])
+    outs_c[1].backward(gouts[1])
+    xd = x.clone().requires_grad_(True)
+    Fn.resize_bilinear_ac(xd, *sizes[1]).backward(gouts[1])
+    assert torch.equal(xc.grad, xd.grad)
+    # without requires_grad: plain launches, nothing recorded
+    assert all(not o.requires_grad for o in Fn.resize_bilinear_ac_multi(x, sizes))
