@@ -316,6 +316,16 @@ int irr_conv2d_fwd_h2(const float* x, const void* wq, const float* bias, const f
                       int lrelu, float alpha, int accumulate,
                       const float* mask, long mask_bs, int nmask, float* ws, long ws_elems,
                       const float* x_amax, int n_amax, float* y_amax, void* stream);
+/* (ABI 12, end of round 6) irr_conv2d_fwd_h2 whose K-split launches (problems with irr_conv2d_fwd_x3_ws_elems > 0: the small pyramid levels)
+ * finish INSIDE the launch: kcnt = kcnt_elems >= irr_conv2d_fwd_x3_kcounters(...) ZEROED 32-bit device counters (zero again afterwards).  The
+ * block that arrives last at a pixel tile sums the slices' partial images in slice order and runs the epilogue: no finishing launch, results
+ * bit-identical.  kcnt == NULL (or too few counters): exactly irr_conv2d_fwd_h2. */
+long irr_conv2d_fwd_x3_kcounters(int B, int Cin, int H, int W, int Cout, int dil);
+int irr_conv2d_fwd_h2_kfused(const float* x, const void* wq, const float* bias, const float* res, float* y, int B,
+                             int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
+                             float alpha, int accumulate, const float* mask, long mask_bs, int nmask, float* ws,
+                             long ws_elems, void* kcnt, long kcnt_elems, const float* x_amax, int n_amax, float* y_amax,
+                             void* stream);
 int irr_conv2d_fwd_h2_dual(const float* x, const void* wq, const float* bias, const float* res, float* y, float* y2,
                            int B, int Cin, int H, int W, int Cout, int dil,
                            long x_bs, long y_bs, long res_bs, long y2_bs, int lrelu, float alpha,

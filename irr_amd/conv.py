@@ -191,6 +191,12 @@ def _call_conv_(args) -> None:
         n = hip.lib().irr_conv2d_fwd_x3_ws_elems(B, cin, H, W, cout, dil)
         ws = torch.empty(n, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device())) if n > 0 else None
         if args[0] == "irr_conv2d_fwd_h2":                  # (args: the x3 tuple + (x_amax ptr, n_amax, y_amax ptr) before the stream)
+            if n > 0 and KSPLIT_FUSED:
+                # K-split launch (small pyramid levels): zeroed counters let the launch finish itself -- no finishing launch
+                nc = int(hip.lib().irr_conv2d_fwd_x3_kcounters(B, cin, H, W, cout, dil))
+                cnt = zero_slots(ws.device, nc)
+                hip.call("irr_conv2d_fwd_h2_kfused", *args[1:-4], hip.ptr(ws), n, hip.ptr(cnt), nc, *args[-4:])
+                return
             hip.call("irr_conv2d_fwd_h2", *args[1:-4], hip.ptr(ws), n, *args[-4:])
             return
         if n > 0:
@@ -198,6 +204,12 @@ def _call_conv_(args) -> None:
             return
     hip.call(*args)
 
+
+# IRR_X3_KSPLIT_FUSED=1: K-split launches of the fp16x2 kernel finish inside the launch (irr_conv2d_fwd_h2_kfused: the last block at a pixel
+# tile sums the slices and runs the epilogue; 52 finishing launches per step less).  Bit-identical and, measured same-box, exactly as fast as
+# the finishing launch (profiles/r6_ksplit_fused_ab.txt) -- OFF by default: it leans on agent-scope store / load ordering across the eight
+# L2s where the two-launch route leans on a kernel boundary.
+KSPLIT_FUSED = os.environ.get("IRR_X3_KSPLIT_FUSED", "0") != "0"
 
 _CHECK_FINITE = os.environ.get("IRR_CONV_CHECK_FINITE", "")       # debugging aid: finiteness check behind every conv launch -- "1":
                                                                   # synchronising, raises at once; "async": device-side flags, read by

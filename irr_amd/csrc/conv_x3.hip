@@ -67,6 +67,9 @@ struct X3Args {
   int n_amax;
   float* y_amax;                           // nullable: slot that receives max |y| of this launch's output (atomic max on the bit pattern)
   float* y_chmax;                          // nullable (round 6): Cout slots that receive max |y[:, co]| PER OUTPUT CHANNEL (irr_conv_x3_next_chmax)
+  unsigned int* kcnt;                      // nullable (end of round 6, ksplit > 1): one ZEROED counter per block of the x grid -- the block that
+                                           // arrives LAST at a pixel tile sums the slices' partial images in slice order and runs the epilogue
+                                           // itself (no finishing launch); the counters wrap back to zero (atomicInc)
 };
 
 // Block = CT*PG symmetric waves, two blocks per CU (256 registers per wave, 128 of them accumulators): every wave
@@ -250,22 +253,85 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
     }
     __syncthreads();
   }
-  if (!active) return;
-  if (NP == 2) {                             // back to the operands' own scale (two exact power-of-two factors)
+  if (active && NP == 2) {                   // back to the operands' own scale (two exact power-of-two factors)
 #pragma unroll
     for (int s = 0; s < NT; ++s)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][r] = (acc[s][r] * inv_x) * inv_w;
   }
+  const long ohw = hw;
+  bool split_out = a.ksplit > 1;             // this block stores a raw partial image and somebody else finishes
+  if (a.ksplit > 1 && a.kcnt != nullptr) {   // (uniform) K split finished IN THE LAUNCH: every wave of the block takes part in the barriers
+    // The slices of a pixel tile are the blocks (blockIdx.x, z = 0 .. ksplit-1).  Each stores its partial image at agent scope (the eight
+    // XCDs' L2s are not coherent with each other for plain stores), waits for the stores and counts itself; the block that counts LAST
+    // replaces its accumulators by the sum of all slices IN SLICE ORDER (the finishing kernel's order: results
+    // are bit-identical to the two-launch route, whichever block happens to be last) and falls through to the ordinary epilogue.
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < NT; ++s) {
+        const int t = (pg * NT + s) * 32 + j;
+        const int row = t / a.TC, col = t - row * a.TC;
+        const int oys = y0 + row, ox = x0 + col;
+        if (oys >= Hs || ox >= a.W) continue;
+        float* pb = a.part + (((long)blockIdx.z * a.B + b) * a.Cout) * ohw + (long)(rr + oys * a.RD) * a.W + ox;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          // (agent-scope atomic store: written THROUGH this XCD's L2 -- a release FENCE instead would write back the whole L2 of the XCD,
+          // and the acquire on the other side invalidate one: measured +4.8 ms per step with the lane's kernels sharing those caches)
+          if (co < a.Cout) __hip_atomic_store(pb + (long)co * ohw, acc[s][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    __shared__ unsigned int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's partial image has reached the device's coherence point
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned int old = atomicInc(a.kcnt + blockIdx.x, (unsigned int)a.ksplit - 1u);     // wraps to 0 behind the last arrival
+      s_last = old == (unsigned int)a.ksplit - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // (the slices are read with agent-scope atomic loads below: served from the coherence point, never from a stale line of this XCD's L2)
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < NT; ++s) {
+        const int t = (pg * NT + s) * 32 + j;
+        const int row = t / a.TC, col = t - row * a.TC;
+        const int oys = y0 + row, ox = x0 + col;
+        if (oys >= Hs || ox >= a.W) continue;
+        const long pofs0 = ((long)b * a.Cout) * ohw + (long)(rr + oys * a.RD) * a.W + ox;
+        const long kstride = (long)a.B * a.Cout * ohw;
+        // slice by slice, the sixteen rows of the sub-tile in flight together (one row after the other, slice after slice, was a chain
+        // of 16 * NT * ksplit dependent round trips for the one block that finishes a tile: +2.7 ms per step)
+        f32x16 sum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum[r] = 0.f;
+        for (int k = 0; k < a.ksplit; ++k) {
+          float tv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const int cc = co < a.Cout ? co : a.Cout - 1;    // (clamped: the row of a channel past the end is never stored)
+            tv[r] = __hip_atomic_load(a.part + pofs0 + (long)cc * ohw + (long)k * kstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sum[r] += tv[r];
+        }
+        acc[s] = sum;
+      }
+    }
+    split_out = false;
+  }
+  if (!active) return;
   float ymax = 0.f;
-  const bool want_amax = NP == 2 && a.y_amax != nullptr && a.ksplit <= 1;
-  const bool want_ch = NP == 2 && a.y_chmax != nullptr && a.ksplit <= 1;
+  const bool want_amax = NP == 2 && a.y_amax != nullptr && !split_out;
+  const bool want_ch = NP == 2 && a.y_chmax != nullptr && !split_out;
   float chm[16];                                           // max |stored value| of this lane per accumulator row (= output channel)
 #pragma unroll
   for (int r = 0; r < 16; ++r) chm[r] = 0.f;
 
   // ---- epilogue: D[i][jj], i = (r&3) + 8*(r>>2) + 4*g, jj = lane&31 ----
-  const long ohw = hw;
   // per-sample bases: the byte offsets inside a sample stay below the 2 GiB out-of-range marker for any batch
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long)b * a.y_bs), (short)0, (int)0x80000000u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsr =
@@ -279,7 +345,7 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
     const int oys = y0 + row, ox = x0 + col;
     if (oys >= Hs || ox >= a.W) continue;
     const long pofs = (long)(rr + oys * a.RD) * a.W + ox;
-    if (a.ksplit > 1) {                      // raw partial sums of this chunk slice; the epilogue runs in a second kernel
+    if (split_out) {                         // raw partial sums of this chunk slice; the epilogue runs in a second kernel
       float* pb = a.part + (((long)blockIdx.z * a.B + b) * a.Cout) * ohw + pofs;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -1140,7 +1206,8 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
                        int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
                        float alpha, int accumulate, const float* mask, long mask_bs, int nmask, float* ws, long ws_elems,
                        void* stream, float* y2 = nullptr, long y2_bs = 0, int np = 3, const float* x_amax = nullptr, int n_amax = 0,
-                       float* y_amax = nullptr, const uint32_t* mask_bits = nullptr, uint32_t* bits_out = nullptr) {
+                       float* y_amax = nullptr, const uint32_t* mask_bits = nullptr, uint32_t* bits_out = nullptr,
+                       unsigned int* kcnt = nullptr, long kcnt_elems = 0) {
   float* const next_chmax = g_next_chmax;                   // (irr_conv_x3_next_chmax: consumed by this launch, whatever happens to it)
   g_next_chmax = nullptr;
   if (!x || !wq || !y || B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1) return IRR_EINVAL;
@@ -1246,6 +1313,7 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
   a.part = ws;
   a.x_amax = x_amax; a.n_amax = n_amax; a.y_amax = y_amax;
   a.y_chmax = np == 2 ? next_chmax : nullptr;
+  a.kcnt = (a.ksplit > 1 && kcnt && kcnt_elems >= p.blocks) ? kcnt : nullptr;       // (zeroed counters: the launch finishes its K split itself)
   // 32-bit byte voffsets below the 2 GiB out-of-range marker: split the batch accordingly
   const long lim = (1L << 29) - (long)(Cin + 16) * H * W - 64;        // elements
   if (lim <= 0) return IRR_EINVAL;
@@ -1281,6 +1349,10 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
       default: return IRR_EINVAL;
     }
     if (rc) return rc;
+    if (a.kcnt) {                                            // (finished inside the launch; the next batch chunk counts on its own counters)
+      a.kcnt += (long)a.B * a.RD * a.tiles_x * a.tiles_y * a.ngy;
+      continue;
+    }
     if (a.ksplit > 1) {
       const long n = (long)a.B * Cout * H * W;
       if (a.y_chmax && (long)H * W <= 4096 && !IRR_ENV_FLAG("IRR_X3_NO_PLANES_EPILOGUE")) {       // (A/B switch: the flat kernel + a pass)               // (the small pyramid levels: waves that stay inside a plane fold the channel's maximum)
@@ -1331,6 +1403,27 @@ extern "C" int irr_conv2d_fwd_h2(const float* x, const void* wq, const float* bi
                                  long ws_elems, const float* x_amax, int n_amax, float* y_amax, void* stream) {
   return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, accumulate, mask, mask_bs, nmask,
                      ws, ws_elems, stream, nullptr, 0, 2, x_amax, n_amax, y_amax);
+}
+
+// (ABI 12) irr_conv2d_fwd_h2 whose K-split launches (the small pyramid levels) finish INSIDE the launch: kcnt = kcnt_elems >=
+// irr_conv2d_fwd_x3_kcounters(...) ZEROED 32-bit counters (they are zero again when the launch has finished: atomicInc wraps).  The block that
+// arrives last at a pixel tile sums the slices' partial images in slice order and runs the epilogue (bias, LeakyReLU, residual, accumulate,
+// mask, magnitude folds): no finishing launch, results bit-identical to irr_conv2d_fwd_h2.  kcnt == NULL: irr_conv2d_fwd_h2.
+extern "C" long irr_conv2d_fwd_x3_kcounters(int B, int Cin, int H, int W, int Cout, int dil) {
+  if (B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1 || x3s_ok(B, Cin, H, W, Cout, dil)) return 0;
+  Plan p;
+  if (!make_plan(B, Cin, H, W, Cout, dil, &p) || p.ksplit <= 1) return 0;
+  return p.blocks;
+}
+
+extern "C" int irr_conv2d_fwd_h2_kfused(const float* x, const void* wq, const float* bias, const float* res, float* y, int B,
+                                        int Cin, int H, int W, int Cout, int dil, long x_bs, long y_bs, long res_bs, int lrelu,
+                                        float alpha, int accumulate, const float* mask, long mask_bs, int nmask, float* ws,
+                                        long ws_elems, void* kcnt, long kcnt_elems, const float* x_amax, int n_amax, float* y_amax,
+                                        void* stream) {
+  if (((uintptr_t)kcnt) & 3) { g_next_chmax = nullptr; return IRR_EINVAL; }
+  return fwd_x3_impl(x, wq, bias, res, y, B, Cin, H, W, Cout, dil, x_bs, y_bs, res_bs, lrelu, alpha, accumulate, mask, mask_bs, nmask,
+                     ws, ws_elems, stream, nullptr, 0, 2, x_amax, n_amax, y_amax, nullptr, nullptr, (unsigned int*)kcnt, kcnt_elems);
 }
 
 // irr_conv2d_fwd_h2 for the problems of the streaming kernel (irr_conv2d_h2_eligible == 9001, Cout <= 32) with LeakyReLU' masks as bits

@@ -354,6 +354,52 @@ def test_conv_x3_kernel_folds_channel_maxima(case, min_blocks, h2_everywhere):
     assert C.LAUNCHES["amax_channels"] == n0, dict(C.LAUNCHES)
 
 
+@pytest.mark.parametrize("case", [(565, 128, 1, 8, 24, 28), (128, 128, 2, 8, 12, 14), (243, 128, 1, 4, 48, 56), (371, 96, 1, 8, 24, 28), (467, 64, 1, 16, 12, 14),
+                                  (128, 565, 1, 8, 24, 28)], ids=lambda c: f"{c[0]}to{c[1]}d{c[2]}_{c[3]}x{c[4]}x{c[5]}")
+def test_k_split_finished_inside_the_launch_is_bit_identical(case, h2_everywhere):
+    """irr_conv2d_fwd_h2_kfused (end of round 6): the block that arrives last at a pixel tile sums the slices' partial images in slice
+    order and runs the epilogue -- against the two-launch route (partial images + x3_splitk_epilogue_kernel): BIT-identical outputs,
+    magnitude and channel-maxima folds for the plain, residual and accumulate + mask epilogues, 25 repetitions each (whichever block
+    happens to be last), counters back at zero."""
+    from irr_amd import conv as C, hip
+    cin, cout, dil, B, H, W = case
+    hip.lib().irr_conv_x3_set_min_blocks(384)
+    if not C.h2_code(B, cin, H, W, cout, 3, 1, dil) or hip.lib().irr_conv2d_fwd_x3_ws_elems(B, cin, H, W, cout, dil) <= 0:
+        pytest.skip("not a K-split problem")
+    assert hip.lib().irr_conv2d_fwd_x3_kcounters(B, cin, H, W, cout, dil) > 0
+    x, w, gy = _operands(case, "per_channel")
+    g = torch.Generator().manual_seed(21)
+    xc, wc = x.cuda(), w.cuda()
+    b = (torch.linspace(-1, 1, cout) * 0.1).cuda()
+    res = torch.randn(B, cout, H, W, generator=g).cuda()
+    acc0 = torch.randn(B, cout, H, W, generator=g).cuda()
+    xa = C.amax_measure(xc)
+
+    def run(fused, variant):
+        old = C.KSPLIT_FUSED
+        C.KSPLIT_FUSED = fused
+        try:
+            ya, ch = C.Amax.zeros(xc.device, 1), C.zero_slots(xc.device, cout)
+            if variant == 0:
+                y = C.conv_forward(xc, wc, b, 1, dil, True, x_amax=xa, y_amax=ya, y_chmax=ch)
+            elif variant == 1:
+                y = C.conv_forward(xc, wc, b, 1, dil, False, res=res, alpha=0.1, x_amax=xa, y_amax=ya)
+            else:
+                y = C.conv_forward(xc, wc, None, 1, dil, False, out=acc0.clone(), accumulate=True, x_amax=xa, y_amax=ya, y_chmax=ch)
+            return y, ya.slots[ya.first].clone(), ch.clone()
+        finally:
+            C.KSPLIT_FUSED = old
+
+    n0 = C.LAUNCHES["amax_channels"]
+    for variant in range(3):
+        ref = run(False, variant)
+        for _ in range(25):
+            got = run(True, variant)
+            for a_, b_ in zip(got, ref):
+                assert torch.equal(a_, b_), variant
+    torch.cuda.synchronize()
+
+
 B_CASES = [(32, 32, 2, 40, 64), (16, 32, 1, 24, 96), (32, 32, 3, 23, 92), (32, 24, 1, 31, 60)]   # (Cin, Cout, B, H, W)
 
 
