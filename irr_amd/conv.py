@@ -193,8 +193,8 @@ def _call_conv_(args) -> None:
         if args[0] == "irr_conv2d_fwd_h2":                  # (args: the x3 tuple + (x_amax ptr, n_amax, y_amax ptr) before the stream)
             if n > 0 and KSPLIT_FUSED:
                 # K-split launch (small pyramid levels): zeroed counters let the launch finish itself -- no finishing launch
-                nc = int(hip.lib().irr_conv2d_fwd_x3_kcounters(B, cin, H, W, cout, dil))
-                cnt = zero_slots(ws.device, nc)
+                nc = int(hip.lib().irr_conv2d_fwd_x3_kcounters(B, cin, H, W, cout, dil))      # (0: a tile shape whose kernel has no in-launch finish)
+                cnt = zero_slots(ws.device, max(nc, 1))
                 hip.call("irr_conv2d_fwd_h2_kfused", *args[1:-4], hip.ptr(ws), n, hip.ptr(cnt), nc, *args[-4:])
                 return
             hip.call("irr_conv2d_fwd_h2", *args[1:-4], hip.ptr(ws), n, *args[-4:])

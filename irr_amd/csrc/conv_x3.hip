@@ -253,6 +253,11 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
     }
     __syncthreads();
   }
+  // (the in-launch K split below exists for NT <= 4 only -- the tiles the planner gives the small pyramid levels: in the register-tight
+  // NT = 7 / 8 instantiations its mere presence cost the level-4 launches 8-15 %; for them the code is what it was)
+  if constexpr (NT > 4) {
+    if (!active) return;
+  }
   if (active && NP == 2) {                   // back to the operands' own scale (two exact power-of-two factors)
 #pragma unroll
     for (int s = 0; s < NT; ++s)
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(CT* PG * 64, 2) void conv_x3_kernel(const X3Args a)
   }
   const long ohw = hw;
   bool split_out = a.ksplit > 1;             // this block stores a raw partial image and somebody else finishes
+  if constexpr (NT <= 4)
   if (a.ksplit > 1 && a.kcnt != nullptr) {   // (uniform) K split finished IN THE LAUNCH: every wave of the block takes part in the barriers
     // The slices of a pixel tile are the blocks (blockIdx.x, z = 0 .. ksplit-1).  Each stores its partial image at agent scope (the eight
     // XCDs' L2s are not coherent with each other for plain stores), waits for the stores and counts itself; the block that counts LAST
@@ -1313,7 +1319,7 @@ static int fwd_x3_impl(const float* x, const void* wq, const float* bias, const 
   a.part = ws;
   a.x_amax = x_amax; a.n_amax = n_amax; a.y_amax = y_amax;
   a.y_chmax = np == 2 ? next_chmax : nullptr;
-  a.kcnt = (a.ksplit > 1 && kcnt && kcnt_elems >= p.blocks) ? kcnt : nullptr;       // (zeroed counters: the launch finishes its K split itself)
+  a.kcnt = (a.ksplit > 1 && p.t.nt <= 4 && kcnt && kcnt_elems >= p.blocks) ? kcnt : nullptr;       // (zeroed counters: the launch finishes its K split itself; NT <= 4 kernels only)
   // 32-bit byte voffsets below the 2 GiB out-of-range marker: split the batch accordingly
   const long lim = (1L << 29) - (long)(Cin + 16) * H * W - 64;        // elements
   if (lim <= 0) return IRR_EINVAL;
@@ -1412,7 +1418,7 @@ extern "C" int irr_conv2d_fwd_h2(const float* x, const void* wq, const float* bi
 extern "C" long irr_conv2d_fwd_x3_kcounters(int B, int Cin, int H, int W, int Cout, int dil) {
   if (B <= 0 || Cin < 16 || Cout <= 0 || H <= 0 || W <= 0 || dil < 1 || x3s_ok(B, Cin, H, W, Cout, dil)) return 0;
   Plan p;
-  if (!make_plan(B, Cin, H, W, Cout, dil, &p) || p.ksplit <= 1) return 0;
+  if (!make_plan(B, Cin, H, W, Cout, dil, &p) || p.ksplit <= 1 || p.t.nt > 4) return 0;
   return p.blocks;
 }
 
